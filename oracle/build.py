@@ -1,0 +1,85 @@
+"""Build the oracle (TEST INFRASTRUCTURE ONLY -- never imported by sniper_amd/).
+
+Two artefacts:
+
+* ``oracle/libsniper_oracle.so`` -- our plain-C restatement (``sniper_oracle.c``).
+* ``oracle/_ref/{chips,bbox}*.so`` -- the reference's *own* native code (``lib/chips/cchips.cpp``
+  + ``lib/chips/chips.pyx``, ``lib/bbox/bbox.pyx``) compiled from the sources where they lie
+  under ``/root/reference``.  No reference source is copied into this repository: Cython's
+  generated C/C++ goes to a scratch directory outside the repo, only the shared objects land in
+  ``oracle/_ref/`` (git-ignored, but shipped to the GPU box).  Built only when the reference
+  checkout is present; the GPU box uses the prebuilt files.
+
+The reference's own build (``lib/chips/setup.py``, ``scripts/compile.sh``) is not used: it is
+distutils/py2 only and ``std::random_shuffle`` needs ``-std=c++14``.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("SNIPER_REFERENCE", "/root/reference")
+REF_OUT = os.path.join(HERE, "_ref")
+
+
+def _run(cmd):
+    subprocess.check_call(cmd)
+
+
+def _newer(target, *sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def build_restatement(force=False):
+    src = os.path.join(HERE, "sniper_oracle.c")
+    out = os.path.join(HERE, "libsniper_oracle.so")
+    if force or not _newer(out, src):
+        _run(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", out, src, "-lm"])
+    return out
+
+
+def have_reference():
+    return os.path.isfile(os.path.join(REF, "lib", "chips", "cchips.cpp"))
+
+
+def build_reference(force=False):
+    """Compile the reference's chips/bbox extension modules into oracle/_ref/."""
+    if not have_reference():
+        return None
+    import numpy
+
+    os.makedirs(REF_OUT, exist_ok=True)
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    py_inc = sysconfig.get_paths()["include"]
+    np_inc = numpy.get_include()
+    out_chips = os.path.join(REF_OUT, "chips" + ext)
+    out_bbox = os.path.join(REF_OUT, "bbox" + ext)
+    if not force and os.path.exists(out_chips) and os.path.exists(out_bbox):
+        return REF_OUT
+    with tempfile.TemporaryDirectory(prefix="sniper_ref_build_") as tmp:
+        chips_dir = os.path.join(REF, "lib", "chips")
+        gen_cpp = os.path.join(tmp, "chips.cpp")
+        _run([sys.executable, "-m", "cython", "-2", "--cplus", "-I", chips_dir, "-o", gen_cpp,
+              os.path.join(chips_dir, "chips.pyx")])
+        _run(["g++", "-O2", "-std=c++14", "-shared", "-fPIC", "-w", "-I", py_inc, "-I", np_inc, "-I", chips_dir,
+              gen_cpp, os.path.join(chips_dir, "cchips.cpp"), "-o", out_chips])
+        bbox_dir = os.path.join(REF, "lib", "bbox")
+        gen_c = os.path.join(tmp, "bbox.c")
+        _run([sys.executable, "-m", "cython", "-2", "-o", gen_c, os.path.join(bbox_dir, "bbox.pyx")])
+        _run(["gcc", "-O2", "-shared", "-fPIC", "-w", "-I", py_inc, "-I", np_inc, gen_c, "-o", out_bbox])
+    return REF_OUT
+
+
+def build_all(force=False):
+    build_restatement(force)
+    build_reference(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("oracle built; reference modules:", sorted(os.listdir(REF_OUT)) if os.path.isdir(REF_OUT) else None)
