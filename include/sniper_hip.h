@@ -1,0 +1,200 @@
+/*
+ * sniper_hip.h -- C ABI of libsniper_hip.so, the MI355X (gfx950) kernel library behind the SNIPER
+ * hot path.  Plain C: pointers, sizes, no C++/torch types.
+ *
+ * Conventions ("Inner boundary"):
+ *   - every pointer named d_* / documented "device" is a HIP device pointer owned by the caller;
+ *   - no allocation, no synchronisation and no global state inside any call: kernels are enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = default stream) and the call returns;
+ *   - scratch memory comes from the caller: sn_*_workspace_bytes() tells how much;
+ *   - return value: 0 = ok, SN_ERR_* otherwise (argument errors are detected before any launch).
+ * The only native ABI the reference itself defines is
+ *     void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+ *               float nms_overlap_thresh, int device_id);            (lib/nms/gpu_nms.hpp:1-2)
+ * which sn_nms_host() replaces one-to-one; everything else replaces a Cython/C++ extension entry
+ * point or an operator of the un-vendored SNIPER-mxnet fork and cites it below.
+ */
+#ifndef SNIPER_HIP_H
+#define SNIPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *sn_stream_t; /* hipStream_t */
+
+enum { SN_OK = 0, SN_ERR_ARG = 1, SN_ERR_HIP = 2, SN_ERR_WORKSPACE = 3, SN_ERR_UNSUPPORTED = 4 };
+
+/* Library / device sanity. */
+int sn_version(void);
+const char *sn_last_error(void); /* thread-local text of the last failure */
+
+/* ------------------------------------------------------------------ box geometry ------------- */
+/* bbox_overlaps_cython / ignore_overlaps_cython (lib/bbox/bbox.pyx:17-57, 59-95).
+ * boxes (N,4) f64, query (K,4) f64 -> out (N,K) f64 row-major.  mode 0 = IoU, 1 = intersection/query-area. */
+int sn_iou_f64(const double *d_boxes, int N, const double *d_query, int K, double *d_out, int mode, sn_stream_t stream);
+
+/* ------------------------------------------------------------------ chip generation ---------- */
+/* chips::cgenerate (lib/chips/cchips.cpp:54-177) for a ragged batch of U (image, scale) units.
+ *   d_boxes       (total_boxes,4) f32, already scaled + clipped (chip_generator.py:24);
+ *   d_box_off     (U+1) i32 prefix offsets into d_boxes;
+ *   d_meta        (U,4) i32 = width, height, chipsize, stride;
+ *   d_perm        (total_cand) i32 candidate order after the shuffle of cchips.cpp:117, or NULL for identity;
+ *   d_cand_off    (U+1) i32 prefix offsets into d_perm (= candidate counts, sn_chips_num_candidates);
+ *   d_mask_ws     workspace, sn_chips_workspace_bytes(total_cand, max_boxes_per_unit);
+ *   d_out_chips   (total_boxes,4) f32: unit u writes its chips at row d_box_off[u] (a unit never
+ *                 selects more chips than it has boxes);  d_out_ids same layout, slot index in the
+ *                 shuffled candidate list;  d_out_count (U) i32.
+ */
+int sn_chips_num_candidates(int width, int height, int chipsize, int stride);
+size_t sn_chips_workspace_bytes(int total_cand, int max_boxes_per_unit);
+int sn_chips_generate_batch(const float *d_boxes, const int32_t *d_box_off, const int32_t *d_meta, const int32_t *d_perm,
+                            const int32_t *d_cand_off, int U, int max_boxes_per_unit, void *d_mask_ws, float *d_out_chips,
+                            int32_t *d_out_ids, int32_t *d_out_count, sn_stream_t stream);
+
+/* ------------------------------------------------------------------ RPN anchor labelling ----- */
+/* anchor_worker.worker (lib/data_utils/data_workers.py:164-371) + the dense scatter of
+ * MNIteratorE2E._get_batch (lib/iterators/MNIteratorE2E.py:175-194), batched over B chips.
+ * Geometry is fixed per call: F x F feature cells, A anchors per cell, d_base_anchors (A,4) f64 =
+ * generate_anchors() output, feat_stride, chip height/width (im_info).
+ * Per chip b:
+ *   d_gt         (B,G,4) f32 GT boxes in image coordinates (rows >= d_ngt[b] ignored), G <= 128
+ *   d_gt_cls     (B,G)   f32 class id
+ *   d_gt_inchip  (B,G)   u8  1 if that GT row is in props_in_chips of this chip (gtids ∩ nids)
+ *   d_ngt        (B)     i32
+ *   d_crop       (B,2)   f64 chip origin x,y in image coordinates;  d_scale (B) f32 im_scale
+ * Sub-sampling (data_workers.py:327-338): the kept fg / bg anchors are those with the smallest
+ * 47-bit key (d_keys[b][anchor] << 15 | anchor); d_keys (B, A*F*F) u32 in reference anchor order
+ * (cell-major, anchor-minor) is either supplied by the host (bit-exact replay of numpy's draws) or
+ * NULL, in which case keys come from a counter-based hash of (seed, b, anchor).
+ * Outputs (all device, layouts of the reference batch tensors):
+ *   d_label (B, A*F*F) f32 in (a,y,x) order, values {-1,0,1};
+ *   d_bbox_target, d_bbox_weight (B, 4A, F, F) f32;  d_gt_out (B,100,5) f32 (-1 padded);
+ *   d_counts (B,4) i32 = n_inside, n_fg_before, n_bg_before, n_valid_gt  (diagnostics / host RNG replay);
+ *   d_label_pre (B, A*F*F) i8 optional (may be NULL): labels before sub-sampling in reference
+ *   anchor order, -2 for anchors outside the chip.
+ */
+size_t sn_anchor_workspace_bytes(int B, int A, int F, int G);
+int sn_anchor_assign(const float *d_gt, const float *d_gt_cls, const uint8_t *d_gt_inchip, const int32_t *d_ngt,
+                     const double *d_crop, const float *d_scale, int B, int G, const double *d_base_anchors, int A, int F,
+                     int feat_stride, int im_h, int im_w, double pos_thresh, double neg_thresh, int rpn_batch, int num_fg,
+                     const uint32_t *d_keys, uint64_t seed, void *d_ws, float *d_label, float *d_bbox_target,
+                     float *d_bbox_weight, float *d_gt_out, int32_t *d_counts, int8_t *d_label_pre, sn_stream_t stream);
+
+/* ------------------------------------------------------------------ NMS ----------------------- */
+/* Bitmask hard NMS (lib/nms/nms_kernel.cu:34-78 mask, :118-140 scan; IoU > thresh suppresses),
+ * batched: d_boxes (B, N, dim) f32 sorted by descending score, rows >= d_n[b] ignored (d_n may be
+ * NULL = all N).  Keeps at most max_keep survivors (<=0: N).  d_keep (B, max_keep) i32 row indices,
+ * d_nkeep (B) i32.  The mask never leaves the device. */
+size_t sn_nms_workspace_bytes(int B, int N);
+int sn_nms_batch(const float *d_boxes, const int32_t *d_n, int B, int N, int dim, float thresh, int max_keep, void *d_ws,
+                 int32_t *d_keep, int32_t *d_nkeep, sn_stream_t stream);
+/* Drop-in for the reference's _nms() (host buffers, synchronous, allocates like the original).
+ * Returns 0/err; keep_out[num_out] are row indices into the (sorted) input. */
+int sn_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
+                float nms_overlap_thresh, int device_id);
+
+
+/* ================================================================ network operators ===========
+ * The graph operators of the un-vendored SNIPER-mxnet fork, at the call sites of
+ * symbols/faster/resnet_mx_101_e2e.py / mobilenetv2_e2e.py.  Activations are channels-last fp16
+ * ("NHWC", explicit pixel stride in elements so a tensor may be a channel slice of a wider buffer);
+ * loss-side tensors are fp32 in the reference's NCHW order.  Weights are [Cout][KH*KW][Cin].
+ * dtype codes: 0 = fp16, 1 = fp32. */
+
+/* Convolution / FullyConnected forward (resnet_mx_101_e2e.py:43-66,147-155,256,288-303).
+ * y[n,oy,ox,co] = bias[co] + residual + sum x[n, oy*s-p+kh*d, ox*s-p+kw*d, ci] * w[co][kh*KW+kw][ci];
+ * optional ReLU; output fp16 or fp32.  FC = 1x1 convolution over H=W=1. */
+int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
+                int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
+                int relu, int out_f32, sn_stream_t stream);
+/* conv0 on the packed stem input (xp (N,Hp,Wp,4) fp16 from sn_pack_stem_input; w [Cout][KH][KWP*4]). */
+int sn_conv_stem_fwd(const void *xp, const void *w, const float *bias, void *y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
+                     int out_pix_stride, int KH, int KWP, int stride, int relu, int out_f32, sn_stream_t stream);
+/* Data gradient; wt = weights as [Cin][KH*KW][Cout] fp16; `accumulate` (fp16, may alias dx) is added. */
+int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
+                  int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil,
+                  int out_f32, sn_stream_t stream);
+/* Weight gradient, accumulated (+=) into dw fp32 [Cout][KH*KW][Cin]. */
+int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride, int Cout,
+                  int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, sn_stream_t stream);
+/* bias gradient: db[c] += sum_rows dy[r][c] */
+int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, sn_stream_t stream);
+
+/* Stem: NCHW fp32 images -> zero padded NHWC4 fp16 with the bn_data affine folded in (:402-404). */
+int sn_pack_stem_input(const float *x_nchw, void *out, int N, int C, int H, int W, int Hp, int Wp, int pad_t, int pad_l,
+                       const float *scale, const float *shift, sn_stream_t stream);
+
+/* BatchNorm (eps, momentum; :38-58).  sum/sumsq/ws are fp64 scratch of C (2C for ws) elements. */
+int sn_bn_stats(const void *x, int M, int C, int ps, double *sum, double *sumsq, sn_stream_t stream);
+int sn_bn_finalize(const double *sum, const double *sumsq, int M, int C, float eps, float momentum, const float *gamma,
+                   const float *beta, float *run_mean, float *run_var, float *scale, float *shift, float *save_mean,
+                   float *save_invstd, sn_stream_t stream);
+int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int C, float eps,
+                             float *scale, float *shift, sn_stream_t stream);
+int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, const float *scale, const float *shift, int relu,
+                sn_stream_t stream);
+int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy, int ps_x, int ps_acc,
+                   int ps_dx, const float *scale, const float *shift, const float *mean, const float *invstd, int relu, double *ws,
+                   float *dgamma, float *dbeta, sn_stream_t stream);
+
+/* fp16 channels-last element-wise: mode 0 relu(a), 1 a+b, 2 relu-backward (ref>0 ? a : 0) [+ b]. */
+int sn_ew_f16(const void *a, const void *b, const void *ref, void *y, long rows, int C, int ps_a, int ps_b, int ps_ref, int ps_y,
+              int mode, sn_stream_t stream);
+/* fp32 element-wise: op 0 a-b, 1 a+b, 2 a*b, 3 a*scalar, 4 fill(scalar). */
+int sn_ew_f32(const float *a, const float *b, float *out, long n, int op, float scalar, sn_stream_t stream);
+int sn_maxpool_fwd(const void *x, void *y, int N, int H, int W, int C, int k, int stride, int pad, sn_stream_t stream);
+/* out[b][c][r] = in[b][r][c] with dtype conversion (NHWC <-> NCHW). */
+int sn_transpose_batched(const void *in, void *out, int batch, int rows, int cols, long in_batch_stride, long out_batch_stride,
+                         int in_ld, int out_ld, int in_dtype, int out_dtype, sn_stream_t stream);
+int sn_copy2d(const void *in, void *out, long rows, int cols, int in_ld, int out_ld, int in_dtype, int out_dtype,
+              sn_stream_t stream);
+
+/* SoftmaxOutput (:279-281,310-311): data viewed as (outer, K, inner) fp32. */
+int sn_softmax_fwd(const float *x, float *p, long outer, int K, long inner, sn_stream_t stream);
+int sn_softmax_output_bwd(const float *p, const float *label, float *grad, long outer, int K, long inner, float ignore_label,
+                          int use_ignore, float grad_scale, int normalize_valid, int *ws, sn_stream_t stream);
+/* weight * smooth_l1(pred - target) and the MakeLoss gradient (:317-319,330-334). */
+int sn_smooth_l1_loss(const float *pred, const float *target, const float *weight, float *loss, float *dpred, long n, float sigma,
+                      float grad_scale, sn_stream_t stream);
+
+/* MultiProposal (:347-355) / MultiProposalTarget (:283-284).  cls_prob (B,2,A*F,F), bbox_pred (B,4A,F,F),
+ * im_info (B,3), gt_boxes (B,G,5), valid_ranges (B,2), base_anchors (A,4): all fp32 device. */
+size_t sn_proposal_workspace_bytes(int B, int A, int F, int pre_nms_top_n, int post_nms_top_n);
+int sn_multi_proposal(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *base_anchors, int B, int A,
+                      int F, int feat_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, void *ws,
+                      float *rois, float *scores, sn_stream_t stream);
+int sn_multi_proposal_target(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *gt_boxes,
+                             const float *valid_ranges, const float *base_anchors, int B, int A, int F, int feat_stride, int G,
+                             int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float fg_thresh,
+                             const float *bbox_stds4, void *ws, float *rois, float *label, float *bbox_target,
+                             float *bbox_weight, sn_stream_t stream);
+
+/* DeformablePSROIPooling, group_size 1 (:286-293).  data (B,H,W,C) fp16, rois (R,5), trans (R,2,P,P) or NULL,
+ * out (R,P,P,C) fp16.  Backward scatters into zeroed fp32 d_data / d_trans. */
+int sn_dpsroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int C, int pooled,
+                       int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream);
+int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, float *d_data, float *d_trans,
+                       int R, int H, int W, int C, int pooled, int sample_per_part, float spatial_scale, float trans_std,
+                       sn_stream_t stream);
+
+/* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward. */
+int sn_deform_im2col(const void *data, const float *offset, void *col, int N, int H, int W, int C, int KH, int KW, int stride,
+                     int pad, int dil, int deformable_groups, int offset_pix_stride, sn_stream_t stream);
+int sn_deform_col2im(const void *dcol, const void *data, const float *offset, float *d_data, float *d_offset, int N, int H, int W,
+                     int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups, int offset_pix_stride,
+                     sn_stream_t stream);
+
+/* Multi-precision SGD with momentum (lib/train_utils/utils.py:26-33). */
+int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void *w16, long n, float lr, float wd, float momentum,
+                      float rescale, sn_stream_t stream);
+/* fp32 [O][T][I] -> fp16 [I][T][O] (weights for sn_conv_dgrad). */
+int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, sn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNIPER_HIP_H */

@@ -1,0 +1,260 @@
+"""CPU restatements of the network operators whose source lives in the un-vendored SNIPER-mxnet
+fork (TEST INFRASTRUCTURE ONLY).  **Parity unpinned**: the reference tree holds neither the
+operator sources nor any test vector for them; these follow the published
+definitions (Faster R-CNN proposal layer, Deformable ConvNets v1) and, where those are silent, the
+choices documented in DESIGN.md.  Standard ops (conv, BN, softmax) are cross-checked against
+torch-CPU fp32 in tests/.  numpy, loops -> small sizes only.
+"""
+import numpy as np
+
+from . import capi
+from .data_path import generate_anchors
+
+
+# ---------------------------------------------------------------------------------------------
+# MultiProposal / MultiProposalTarget (symbols/faster/resnet_mx_101_e2e.py:283-284, 347-355)
+# ---------------------------------------------------------------------------------------------
+def proposals(cls_prob, bbox_pred, im_info, feat_stride, scales, ratios, pre_nms, post_nms, nms_thresh, min_size=0):
+    """cls_prob (B,2,A*F,F), bbox_pred (B,4A,F,F) float32.  Returns rois (B*post,5), scores (B*post,)
+    and per image the sorted pre-NMS boxes + kept indices (for set-level checks).
+    Steps: anchors (generate_anchor.py) in (y, x, a) order; float32 decode = nonlinear_pred
+    (bbox_transform.py:93-130); clip to (im_h-1, im_w-1); boxes below min_size*scale get score -1;
+    stable sort by descending score; top pre_nms; NMS (nms.py:90-127 semantics); first post_nms,
+    cyclically repeated when fewer survive."""
+    B = cls_prob.shape[0]
+    F = cls_prob.shape[3]
+    A = cls_prob.shape[2] // F
+    base = generate_anchors(feat_stride, ratios, np.array(scales, np.float32)).astype(np.float32)
+    rois = np.zeros((B * post_nms, 5), np.float32)
+    scores_out = np.zeros((B * post_nms,), np.float32)
+    dbg = []
+    f32 = np.float32
+    for b in range(B):
+        fg = cls_prob[b, 1].reshape(A, F, F).transpose(1, 2, 0).reshape(-1)  # (y,x,a)
+        d = bbox_pred[b].reshape(A, 4, F, F).transpose(2, 3, 0, 1).reshape(-1, 4).astype(f32)
+        sx, sy = np.meshgrid(np.arange(F) * feat_stride, np.arange(F) * feat_stride)
+        shifts = np.stack((sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()), 1).astype(f32)
+        anc = (base[None, :, :] + shifts[:, None, :]).reshape(-1, 4).astype(f32)
+        aw = anc[:, 2] - anc[:, 0] + f32(1)
+        ah = anc[:, 3] - anc[:, 1] + f32(1)
+        cx = anc[:, 0] + f32(0.5) * (aw - f32(1))
+        cy = anc[:, 1] + f32(0.5) * (ah - f32(1))
+        pcx = d[:, 0] * aw + cx
+        pcy = d[:, 1] * ah + cy
+        pw = np.exp(d[:, 2]).astype(f32) * aw
+        ph = np.exp(d[:, 3]).astype(f32) * ah
+        boxes = np.stack((pcx - f32(0.5) * (pw - f32(1)), pcy - f32(0.5) * (ph - f32(1)),
+                          pcx + f32(0.5) * (pw - f32(1)), pcy + f32(0.5) * (ph - f32(1))), 1).astype(f32)
+        im_h, im_w, im_s = [f32(v) for v in im_info[b]]
+        boxes[:, 0::2] = np.clip(boxes[:, 0::2], 0, im_w - 1)
+        boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, im_h - 1)
+        sc = fg.astype(f32).copy()
+        ms = f32(min_size) * im_s
+        sc[((boxes[:, 2] - boxes[:, 0] + 1) < ms) | ((boxes[:, 3] - boxes[:, 1] + 1) < ms)] = -1
+        order = np.argsort(-sc, kind='stable')[:pre_nms]
+        sb = np.concatenate((boxes[order], sc[order, None]), 1).astype(f32)
+        keep = capi.nms_sorted(sb, nms_thresh, post_nms)
+        idx = keep[np.arange(post_nms) % len(keep)]
+        rois[b * post_nms:(b + 1) * post_nms, 0] = b
+        rois[b * post_nms:(b + 1) * post_nms, 1:] = sb[idx, :4]
+        scores_out[b * post_nms:(b + 1) * post_nms] = sb[idx, 4]
+        dbg.append((order, sb, keep))
+    return rois, scores_out, dbg
+
+
+def proposal_targets(rois, gt_boxes, valid_ranges, post_nms, fg_thresh=0.5, stds=(0.1, 0.1, 0.2, 0.2)):
+    """RoI labelling, our documented semantics: a GT (class >= 0) is *valid* for the chip
+    iff lo <= sqrt(w*h) <= hi (+1 pixel convention); fg = IoU with a valid GT >= fg_thresh (label =
+    class of the first arg-max GT, bbox_target = nonlinear_transform / stds, weight 1); else ignore
+    (-1) if IoU with an invalid GT >= fg_thresh; else background 0."""
+    R = rois.shape[0]
+    f32 = np.float32
+    label = np.zeros((R,), f32)
+    tgt = np.zeros((R, 4), f32)
+    wgt = np.zeros((R, 4), f32)
+    for r in range(R):
+        b = int(rois[r, 0])
+        x1, y1, x2, y2 = [f32(v) for v in rois[r, 1:]]
+        area = (x2 - x1 + f32(1)) * (y2 - y1 + f32(1))
+        lo, hi = [f32(v) for v in valid_ranges[b]]
+        best_v, best_i, arg = f32(-1), f32(-1), -1
+        for g in range(gt_boxes.shape[1]):
+            gx1, gy1, gx2, gy2, c = [f32(v) for v in gt_boxes[b, g]]
+            if c < 0:
+                continue
+            size = np.sqrt((gx2 - gx1 + f32(1)) * (gy2 - gy1 + f32(1)), dtype=f32)
+            valid = size >= lo and size <= hi
+            iw = min(x2, gx2) - max(x1, gx1) + f32(1)
+            ov = f32(0)
+            if iw > 0:
+                ih = min(y2, gy2) - max(y1, gy1) + f32(1)
+                if ih > 0:
+                    ov = f32(iw * ih) / f32(f32(area + f32((gx2 - gx1 + f32(1)) * (gy2 - gy1 + f32(1)))) - f32(iw * ih))
+            if valid:
+                if ov > best_v:
+                    best_v, arg = ov, g
+            elif ov > best_i:
+                best_i = ov
+        if arg >= 0 and best_v >= f32(fg_thresh):
+            gx1, gy1, gx2, gy2, c = [f32(v) for v in gt_boxes[b, arg]]
+            label[r] = c
+            wgt[r] = 1
+            ew, eh = x2 - x1 + f32(1), y2 - y1 + f32(1)
+            ecx, ecy = x1 + f32(0.5) * (ew - f32(1)), y1 + f32(0.5) * (eh - f32(1))
+            gw, gh = gx2 - gx1 + f32(1), gy2 - gy1 + f32(1)
+            gcx, gcy = gx1 + f32(0.5) * (gw - f32(1)), gy1 + f32(0.5) * (gh - f32(1))
+            tgt[r] = [(gcx - ecx) / (ew + f32(1e-7)) / f32(stds[0]), (gcy - ecy) / (eh + f32(1e-7)) / f32(stds[1]),
+                      np.log(gw / (ew + f32(1e-7))) / f32(stds[2]), np.log(gh / (eh + f32(1e-7))) / f32(stds[3])]
+        elif best_i >= f32(fg_thresh):
+            label[r] = -1
+    return label, tgt, wgt
+
+
+# ---------------------------------------------------------------------------------------------
+# DeformablePSROIPooling, group_size 1 (Deformable ConvNets v1; call site :286-293)
+# data (B,C,H,W), rois (R,5), trans (R,2,P,P) or None -> out (R,C,P,P), and its gradients.
+# ---------------------------------------------------------------------------------------------
+def _roi_bins(roi, trans, r, ph, pw, P, S, scale, trans_std):
+    f32 = np.float32
+    rnd = lambda v: f32(np.floor(abs(v) + 0.5) * np.sign(v))  # C round(): half away from zero
+    sw, sh = rnd(roi[1]) * f32(scale) - f32(0.5), rnd(roi[2]) * f32(scale) - f32(0.5)
+    ew, eh = (rnd(roi[3]) + 1) * f32(scale) - f32(0.5), (rnd(roi[4]) + 1) * f32(scale) - f32(0.5)
+    rw, rh = max(ew - sw, f32(0.1)), max(eh - sh, f32(0.1))
+    bw, bh = rw / P, rh / P
+    tx = ty = f32(0)
+    if trans is not None:
+        tx, ty = trans[r, 0, ph, pw] * f32(trans_std), trans[r, 1, ph, pw] * f32(trans_std)
+    return pw * bw + sw + tx * rw, ph * bh + sh + ty * rh, bw / S, bh / S, rw, rh
+
+
+def dpsroi_pool(data, rois, trans, P, S, scale, trans_std=0.0):
+    B, C, H, W = data.shape
+    R = rois.shape[0]
+    out = np.zeros((R, C, P, P), np.float64)
+    for r in range(R):
+        b = int(rois[r, 0])
+        for ph in range(P):
+            for pw in range(P):
+                ws, hs, sw_, sh_, _, _ = _roi_bins(rois[r], trans, r, ph, pw, P, S, scale, trans_std)
+                acc = np.zeros(C)
+                cnt = 0
+                for ih in range(S):
+                    for iw in range(S):
+                        w, h = ws + iw * sw_, hs + ih * sh_
+                        if w < -0.5 or w > W - 0.5 or h < -0.5 or h > H - 0.5:
+                            continue
+                        w, h = min(max(w, 0.0), W - 1.0), min(max(h, 0.0), H - 1.0)
+                        x0, x1, y0, y1 = int(np.floor(w)), int(np.ceil(w)), int(np.floor(h)), int(np.ceil(h))
+                        dx, dy = w - x0, h - y0
+                        acc += ((1 - dx) * (1 - dy) * data[b, :, y0, x0] + dx * (1 - dy) * data[b, :, y0, x1] +
+                                (1 - dx) * dy * data[b, :, y1, x0] + dx * dy * data[b, :, y1, x1])
+                        cnt += 1
+                if cnt:
+                    out[r, :, ph, pw] = acc / cnt
+    return out
+
+
+def dpsroi_pool_backward(dout, data, rois, trans, P, S, scale, trans_std=0.0):
+    B, C, H, W = data.shape
+    R = rois.shape[0]
+    d_data = np.zeros(data.shape, np.float64)
+    d_trans = None if trans is None else np.zeros(trans.shape, np.float64)
+    for r in range(R):
+        b = int(rois[r, 0])
+        for ph in range(P):
+            for pw in range(P):
+                ws, hs, sw_, sh_, rw, rh = _roi_bins(rois[r], trans, r, ph, pw, P, S, scale, trans_std)
+                pts = []
+                for ih in range(S):
+                    for iw in range(S):
+                        w, h = ws + iw * sw_, hs + ih * sh_
+                        if w < -0.5 or w > W - 0.5 or h < -0.5 or h > H - 0.5:
+                            continue
+                        pts.append((min(max(w, 0.0), W - 1.0), min(max(h, 0.0), H - 1.0)))
+                if not pts:
+                    continue
+                dv = dout[r, :, ph, pw] / len(pts)
+                for w, h in pts:
+                    x0, x1, y0, y1 = int(np.floor(w)), int(np.ceil(w)), int(np.floor(h)), int(np.ceil(h))
+                    dx, dy = w - x0, h - y0
+                    d_data[b, :, y0, x0] += (1 - dx) * (1 - dy) * dv
+                    d_data[b, :, y0, x1] += dx * (1 - dy) * dv
+                    d_data[b, :, y1, x0] += (1 - dx) * dy * dv
+                    d_data[b, :, y1, x1] += dx * dy * dv
+                    if trans is not None:
+                        U00, U01, U10, U11 = data[b, :, y0, x0], data[b, :, y0, x1], data[b, :, y1, x0], data[b, :, y1, x1]
+                        d_trans[r, 0, ph, pw] += np.sum((U11 * dy + U01 * (1 - dy) - U10 * dy - U00 * (1 - dy)) * dv) * trans_std * rw
+                        d_trans[r, 1, ph, pw] += np.sum((U11 * dx + U10 * (1 - dx) - U01 * dx - U00 * (1 - dx)) * dv) * trans_std * rh
+    return d_data, d_trans
+
+
+# ---------------------------------------------------------------------------------------------
+# DeformableConvolution v1 sampling (call site :124-128): column tensor (N, Ho, Wo, T, C)
+# ---------------------------------------------------------------------------------------------
+def _deform_sample(py, px, H, W):
+    ok = py >= 0 and px >= 0 and py < H and px < W
+    y0, x0 = int(np.floor(py)), int(np.floor(px))
+    if y0 >= H - 1:
+        y0 = y1 = H - 1
+        ly = 0.0
+    else:
+        y1, ly = y0 + 1, py - y0
+    if x0 >= W - 1:
+        x0 = x1 = W - 1
+        lx = 0.0
+    else:
+        x1, lx = x0 + 1, px - x0
+    return ok, y0, y1, x0, x1, ly, lx
+
+
+def deform_im2col(data, offset, KH, KW, stride, pad, dil, DG):
+    """data (N,C,H,W), offset (N, 2*T*DG, Ho, Wo) -> col (N,Ho,Wo,T,C)."""
+    N, C, H, W = data.shape
+    Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    T, cg = KH * KW, C // DG
+    col = np.zeros((N, Ho, Wo, T, C), np.float64)
+    for n in range(N):
+        for oy in range(Ho):
+            for ox in range(Wo):
+                for t in range(T):
+                    kh, kw = divmod(t, KW)
+                    for g in range(DG):
+                        py = oy * stride - pad + kh * dil + offset[n, g * 2 * T + 2 * t, oy, ox]
+                        px = ox * stride - pad + kw * dil + offset[n, g * 2 * T + 2 * t + 1, oy, ox]
+                        ok, y0, y1, x0, x1, ly, lx = _deform_sample(py, px, H, W)
+                        if not ok:
+                            continue
+                        cs = slice(g * cg, (g + 1) * cg)
+                        col[n, oy, ox, t, cs] = ((1 - ly) * (1 - lx) * data[n, cs, y0, x0] + (1 - ly) * lx * data[n, cs, y0, x1] +
+                                                 ly * (1 - lx) * data[n, cs, y1, x0] + ly * lx * data[n, cs, y1, x1])
+    return col
+
+
+def deform_col2im(dcol, data, offset, KH, KW, stride, pad, dil, DG):
+    N, C, H, W = data.shape
+    _, Ho, Wo, T, _ = dcol.shape
+    cg = C // DG
+    d_data = np.zeros(data.shape, np.float64)
+    d_off = np.zeros(offset.shape, np.float64)
+    for n in range(N):
+        for oy in range(Ho):
+            for ox in range(Wo):
+                for t in range(T):
+                    kh, kw = divmod(t, KW)
+                    for g in range(DG):
+                        py = oy * stride - pad + kh * dil + offset[n, g * 2 * T + 2 * t, oy, ox]
+                        px = ox * stride - pad + kw * dil + offset[n, g * 2 * T + 2 * t + 1, oy, ox]
+                        ok, y0, y1, x0, x1, ly, lx = _deform_sample(py, px, H, W)
+                        if not ok:
+                            continue
+                        cs = slice(g * cg, (g + 1) * cg)
+                        d = dcol[n, oy, ox, t, cs]
+                        d_data[n, cs, y0, x0] += (1 - ly) * (1 - lx) * d
+                        d_data[n, cs, y0, x1] += (1 - ly) * lx * d
+                        d_data[n, cs, y1, x0] += ly * (1 - lx) * d
+                        d_data[n, cs, y1, x1] += ly * lx * d
+                        a, b, c, e = data[n, cs, y0, x0], data[n, cs, y0, x1], data[n, cs, y1, x0], data[n, cs, y1, x1]
+                        d_off[n, g * 2 * T + 2 * t, oy, ox] = np.sum(d * ((1 - lx) * (c - a) + lx * (e - b)))
+                        d_off[n, g * 2 * T + 2 * t + 1, oy, ox] = np.sum(d * ((1 - ly) * (b - a) + ly * (e - c)))
+    return d_data, d_off

@@ -1,0 +1,45 @@
+// common.h -- shared helpers for the gfx950 kernel library (internal, not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sniper_hip.h"
+
+#define SN_EXPORT extern "C" __attribute__((visibility("default")))
+
+void sn_set_error(const char *fmt, ...);
+
+#define SN_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      sn_set_error(__VA_ARGS__);   \
+      return SN_ERR_ARG;           \
+    }                              \
+  } while (0)
+
+// Launch-time errors only (no sync): a failed launch is reported, asynchronous faults surface at
+// the caller's next synchronisation like any HIP error.
+#define SN_CHECK_LAUNCH()                                                      \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      sn_set_error("%s:%d HIP launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return SN_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+
+#define SN_HIP(call)                                                           \
+  do {                                                                         \
+    hipError_t e__ = (call);                                                   \
+    if (e__ != hipSuccess) {                                                   \
+      sn_set_error("%s:%d %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return SN_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+
+static inline hipStream_t sn_stream(sn_stream_t s) { return (hipStream_t)s; }
+static inline int sn_div_up(int a, int b) { return (a + b - 1) / b; }
+static inline size_t sn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+constexpr int kWave = 64;  // CDNA wavefront width

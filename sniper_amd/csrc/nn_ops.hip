@@ -1,0 +1,702 @@
+// nn_ops.hip -- the HBM-bound graph operators of the SNIPER training step on gfx950:
+// stem input packing, BatchNorm (batch-stat and global-stat) fused with ReLU, max pooling,
+// SoftmaxOutput, smooth-L1, element-wise glue, layout conversion, multi-precision SGD.
+//
+// They replace operators of the un-vendored SNIPER-mxnet fork; call sites are cited per kernel
+// (symbols/faster/resnet_mx_101_e2e.py).  All activations are channels-last fp16 with an explicit
+// pixel stride so that producers can write into slices of a wider buffer (free Concat).
+// Roofline: every kernel here is bound by HBM bytes; all global accesses are 16 bytes per lane.
+#include "common.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------------
+// Stem input: NCHW fp32 image batch -> zero-padded NHWC4 fp16, with the bn_data affine folded in
+// (resnet_mx_101_e2e.py:402, use_global_stats, fix_gamma).  The 7x7/2 conv0 then runs on the
+// generic implicit-GEMM kernel as a (7 taps) x (8 pixels x 4 channels) contraction: one kernel row
+// of conv0 is one contiguous 64-byte run of this buffer.
+// out[n][y][x][c], y in [0,Hp), x in [0,Wp); source pixel (y-pad_t, x-pad_l); channel 3 = 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_stem_kernel(const float *__restrict__ x, half_t *__restrict__ out, int N, int C,
+                                                        int H, int W, int Hp, int Wp, int pad_t, int pad_l,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift) {
+  const long total = (long)N * Hp * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xp = (int)(i % Wp);
+    const long t = i / Wp;
+    const int yp = (int)(t % Hp), n = (int)(t / Hp);
+    const int sy = yp - pad_t, sx = xp - pad_l;
+    half_t v[4] = {0, 0, 0, 0};
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+      for (int c = 0; c < C && c < 4; ++c) {
+        float f = x[(((long)n * C + c) * H + sy) * W + sx];
+        if (scale) f = f * scale[c] + shift[c];
+        v[c] = (half_t)f;
+      }
+    }
+    *reinterpret_cast<uint2 *>(out + i * 4) = *reinterpret_cast<uint2 *>(v);
+  }
+}
+
+SN_EXPORT int sn_pack_stem_input(const float *x_nchw, void *out, int N, int C, int H, int W, int Hp, int Wp, int pad_t,
+                                 int pad_l, const float *scale, const float *shift, sn_stream_t stream) {
+  SN_REQUIRE(x_nchw && out && N > 0 && C >= 1 && C <= 4 && Hp >= H + pad_t && Wp >= W + pad_l,
+             "sn_pack_stem_input: bad arguments");
+  const long total = (long)N * Hp * Wp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_stem_kernel, dim3(blocks), dim3(256), 0, sn_stream(stream), x_nchw, (half_t *)out, N, C, H, W,
+                     Hp, Wp, pad_t, pad_l, scale, shift);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm.  x is (M pixels, C channels) fp16 with pixel stride ps; C/8 must divide 256.
+// Thread t owns the 8-channel chunk t % (C/8) and walks rows t / (C/8), +256/(C/8), ...
+//   bn_stats    : per-channel sum and sum of squares -> fp64 accumulators (atomic, caller zeroes)
+//   bn_finalize : mean/var -> scale = gamma*invstd, shift = beta - mean*scale; running stats
+//   bn_apply    : y = relu?(x*scale + shift)
+//   bn_bwd_reduce / bn_bwd_dx : gradients through (ReLU o BN) in training mode
+// BatchNorm(fix_gamma=False, eps=2e-5, momentum) call sites: resnet_mx_101_e2e.py:38-58.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBnThreads = 256;
+
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const half_t *__restrict__ x, int M, int C, int ps,
+                                                              int rows_per_block, double *__restrict__ sum,
+                                                              double *__restrict__ sumsq) {
+  const int cpr = C >> 3, rpp = kBnThreads / cpr;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  for (int r = r0 + rl; r < r1; r += rpp) {
+    const half8 v = *reinterpret_cast<const half8 *>(x + (size_t)r * ps + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)v[j];
+      s[j] += f;
+      q[j] += f * f;
+    }
+  }
+  __shared__ float red[kBnThreads][17];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[threadIdx.x][j] = s[j];
+    red[threadIdx.x][8 + j] = q[j];
+  }
+  __syncthreads();
+  // thread (chunk, j) for j < 16 sums over row-lanes: cpr*16 <= 4096 work items over 256 threads
+  for (int w = threadIdx.x; w < cpr * 16; w += kBnThreads) {
+    const int ch = w >> 4, j = w & 15;
+    float a = 0.f;
+    for (int k = 0; k < rpp; ++k) a += red[k * cpr + ch][j];
+    const int c = ch * 8 + (j & 7);
+    if (j < 8) atomicAdd(&sum[c], (double)a);
+    else atomicAdd(&sumsq[c], (double)a);
+  }
+}
+
+__global__ void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq, int M, int C, float eps,
+                                   float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ run_mean, float *__restrict__ run_var, float *__restrict__ scale,
+                                   float *__restrict__ shift, float *__restrict__ save_mean,
+                                   float *__restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sum[c] / M;
+  double var = sumsq[c] / M - mean * mean;  // biased
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  scale[c] = g * invstd;
+  shift[c] = beta[c] - (float)mean * g * invstd;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (run_mean) {
+    run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
+    run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+  }
+}
+
+// scale/shift from running statistics (use_global_stats=True)
+__global__ void bn_global_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                 const float *__restrict__ mean, const float *__restrict__ var, int C, float eps,
+                                 float *__restrict__ scale, float *__restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  scale[c] = g * invstd;
+  shift[c] = beta[c] - mean[c] * g * invstd;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const half_t *__restrict__ x, half_t *__restrict__ y, int M, int C,
+                                                       int ps_in, int ps_out, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, int relu) {
+  const int cpr = C >> 3;
+  const long total = (long)M * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int chunk = (int)(i % cpr);
+    const long r = i / cpr;
+    const half8 v = *reinterpret_cast<const half8 *>(x + r * ps_in + chunk * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * scale[chunk * 8 + j] + shift[chunk * 8 + j];
+      if (relu) f = f > 0.f ? f : 0.f;
+      o[j] = (half_t)f;
+    }
+    *reinterpret_cast<half8 *>(y + r * ps_out + chunk * 8) = o;
+  }
+}
+
+// dbeta[c] = sum g, dgamma[c] = sum g * xhat, g = dy * (relu ? (x*scale+shift > 0) : 1)
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t *__restrict__ dy, const half_t *__restrict__ x,
+                                                                   int M, int C, int ps_dy, int ps_x, int rows_per_block,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   const float *__restrict__ mean,
+                                                                   const float *__restrict__ invstd, int relu,
+                                                                   double *__restrict__ dgamma, double *__restrict__ dbeta) {
+  const int cpr = C >> 3, rpp = kBnThreads / cpr;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float sc[8], sh[8], mu[8], is[8], s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = chunk * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+    s[j] = q[j] = 0.f;
+  }
+  for (int r = r0 + rl; r < r1; r += rpp) {
+    const half8 g = *reinterpret_cast<const half8 *>(dy + (size_t)r * ps_dy + chunk * 8);
+    const half8 v = *reinterpret_cast<const half8 *>(x + (size_t)r * ps_x + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = (float)v[j];
+      float gf = (float)g[j];
+      if (relu && !(xf * sc[j] + sh[j] > 0.f)) gf = 0.f;
+      s[j] += gf;
+      q[j] += gf * (xf - mu[j]) * is[j];
+    }
+  }
+  __shared__ float red[kBnThreads][17];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[threadIdx.x][j] = s[j];
+    red[threadIdx.x][8 + j] = q[j];
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < cpr * 16; w += kBnThreads) {
+    const int ch = w >> 4, j = w & 15;
+    float a = 0.f;
+    for (int k = 0; k < rpp; ++k) a += red[k * cpr + ch][j];
+    const int c = ch * 8 + (j & 7);
+    if (j < 8) atomicAdd(&dbeta[c], (double)a);
+    else atomicAdd(&dgamma[c], (double)a);
+  }
+}
+
+// dx = scale * (g - dbeta/M - xhat*dgamma/M) [+ acc]; also emits fp32 dgamma/dbeta for the optimizer
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const half_t *__restrict__ dy, const half_t *__restrict__ x,
+                                                        const half_t *__restrict__ acc, half_t *__restrict__ dx, int M, int C,
+                                                        int ps_dy, int ps_x, int ps_acc, int ps_dx,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                        const double *__restrict__ dgamma, const double *__restrict__ dbeta,
+                                                        int relu) {
+  const int cpr = C >> 3;
+  const long total = (long)M * cpr;
+  const float invM = 1.f / (float)M;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int chunk = (int)(i % cpr);
+    const long r = i / cpr;
+    const half8 g = *reinterpret_cast<const half8 *>(dy + r * ps_dy + chunk * 8);
+    const half8 v = *reinterpret_cast<const half8 *>(x + r * ps_x + chunk * 8);
+    half8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (acc) a = *reinterpret_cast<const half8 *>(acc + r * ps_acc + chunk * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = chunk * 8 + j;
+      const float xf = (float)v[j];
+      float gf = (float)g[j];
+      if (relu && !(xf * scale[c] + shift[c] > 0.f)) gf = 0.f;
+      const float xhat = (xf - mean[c]) * invstd[c];
+      const float d = scale[c] * (gf - (float)dbeta[c] * invM - xhat * (float)dgamma[c] * invM);
+      o[j] = (half_t)(d + (float)a[j]);
+    }
+    *reinterpret_cast<half8 *>(dx + r * ps_dx + chunk * 8) = o;
+  }
+}
+
+__global__ void f64_to_f32_accum_kernel(const double *__restrict__ a, float *__restrict__ out, int n, float mul) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += (float)a[i] * mul;
+}
+
+static int bn_shape_ok(int C) { return C >= 64 && C % 8 == 0 && (256 % (C / 8)) == 0; }
+static int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+SN_EXPORT int sn_bn_stats(const void *x, int M, int C, int ps, double *sum, double *sumsq, sn_stream_t stream) {
+  SN_REQUIRE(x && sum && sumsq && M > 0 && bn_shape_ok(C), "sn_bn_stats: C=%d unsupported (C/8 must divide 256)", C);
+  hipStream_t s = sn_stream(stream);
+  SN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * C, s));
+  SN_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * C, s));
+  const int rpp = kBnThreads / (C / 8);
+  int blocks = sn_div_up(M, rpp * 8);  // >= 8 rows per thread
+  if (blocks > 2048) blocks = 2048;
+  const int rows_per_block = sn_div_up(M, blocks);
+  blocks = sn_div_up(M, rows_per_block);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(kBnThreads), 0, s, (const half_t *)x, M, C, ps, rows_per_block, sum,
+                     sumsq);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+SN_EXPORT int sn_bn_finalize(const double *sum, const double *sumsq, int M, int C, float eps, float momentum,
+                             const float *gamma, const float *beta, float *run_mean, float *run_var, float *scale,
+                             float *shift, float *save_mean, float *save_invstd, sn_stream_t stream) {
+  SN_REQUIRE(sum && sumsq && beta && scale && shift && save_mean && save_invstd, "sn_bn_finalize: null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, sn_stream(stream), sum, sumsq, M, C, eps,
+                     momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean, save_invstd);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+SN_EXPORT int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int C,
+                                       float eps, float *scale, float *shift, sn_stream_t stream) {
+  SN_REQUIRE(beta && mean && var && scale && shift, "sn_bn_global_scale_shift: null pointer");
+  hipLaunchKernelGGL(bn_global_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, sn_stream(stream), gamma, beta, mean, var, C,
+                     eps, scale, shift);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+SN_EXPORT int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, const float *scale,
+                          const float *shift, int relu, sn_stream_t stream) {
+  SN_REQUIRE(x && y && scale && shift && M > 0 && C % 8 == 0, "sn_bn_apply: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks((long)M * (C / 8))), dim3(256), 0, sn_stream(stream),
+                     (const half_t *)x, (half_t *)y, M, C, ps_in, ps_out, scale, shift, relu);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// Backward of y = relu?(BN_train(x)).  dgamma/dbeta (fp32, length C) are ACCUMULATED into
+// (+=, the optimizer's gradient arena is zeroed once per step); ws = 2*C doubles.
+SN_EXPORT int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy,
+                             int ps_x, int ps_acc, int ps_dx, const float *scale, const float *shift, const float *mean,
+                             const float *invstd, int relu, double *ws, float *dgamma, float *dbeta,
+                             sn_stream_t stream) {
+  SN_REQUIRE(dy && x && scale && shift && mean && invstd && ws && bn_shape_ok(C) && M > 0,
+             "sn_bn_backward: bad arguments (C=%d)", C);
+  hipStream_t s = sn_stream(stream);
+  SN_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s));
+  const int rpp = kBnThreads / (C / 8);
+  int blocks = sn_div_up(M, rpp * 8);
+  if (blocks > 2048) blocks = 2048;
+  const int rows_per_block = sn_div_up(M, blocks);
+  blocks = sn_div_up(M, rows_per_block);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x, M, C,
+                     ps_dy, ps_x, rows_per_block, scale, shift, mean, invstd, relu, ws, ws + C);
+  SN_CHECK_LAUNCH();
+  if (dx) {
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks((long)M * (C / 8))), dim3(256), 0, s, (const half_t *)dy,
+                       (const half_t *)x, (const half_t *)accumulate, (half_t *)dx, M, C, ps_dy, ps_x, ps_acc, ps_dx, scale,
+                       shift, mean, invstd, ws, ws + C, relu);
+    SN_CHECK_LAUNCH();
+  }
+  if (dgamma) {
+    hipLaunchKernelGGL(f64_to_f32_accum_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, s, ws, dgamma, C, 1.f);
+    SN_CHECK_LAUNCH();
+  }
+  if (dbeta) {
+    hipLaunchKernelGGL(f64_to_f32_accum_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, s, ws + C, dbeta, C, 1.f);
+    SN_CHECK_LAUNCH();
+  }
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ReLU / add / relu-gradient on channels-last fp16 (used where BN fusion does not apply)
+// ---------------------------------------------------------------------------------------------
+// mode 0: y = relu(a);  1: y = a + b;  2: y = (ref > 0) ? a : 0 [+ b]  (relu backward, optional accumulate)
+__global__ __launch_bounds__(256) void ew_f16_kernel(const half_t *__restrict__ a, const half_t *__restrict__ b,
+                                                     const half_t *__restrict__ ref, half_t *__restrict__ y, long rows, int C,
+                                                     int ps_a, int ps_b, int ps_ref, int ps_y, int mode) {
+  const int cpr = C >> 3;
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr) * 8;
+    const long r = i / cpr;
+    const half8 va = *reinterpret_cast<const half8 *>(a + r * ps_a + ch);
+    half8 o;
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = va[j] > (half_t)0 ? va[j] : (half_t)0;
+    } else if (mode == 1) {
+      const half8 vb = *reinterpret_cast<const half8 *>(b + r * ps_b + ch);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)va[j] + (float)vb[j]);
+    } else {
+      const half8 vr = *reinterpret_cast<const half8 *>(ref + r * ps_ref + ch);
+      half8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (b) vb = *reinterpret_cast<const half8 *>(b + r * ps_b + ch);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)((vr[j] > (half_t)0 ? (float)va[j] : 0.f) + (float)vb[j]);
+    }
+    *reinterpret_cast<half8 *>(y + r * ps_y + ch) = o;
+  }
+}
+
+SN_EXPORT int sn_ew_f16(const void *a, const void *b, const void *ref, void *y, long rows, int C, int ps_a, int ps_b,
+                        int ps_ref, int ps_y, int mode, sn_stream_t stream) {
+  SN_REQUIRE(a && y && rows > 0 && C % 8 == 0 && mode >= 0 && mode <= 2, "sn_ew_f16: bad arguments");
+  SN_REQUIRE(mode != 1 || b, "sn_ew_f16: add needs b");
+  SN_REQUIRE(mode != 2 || ref, "sn_ew_f16: relu backward needs ref");
+  hipLaunchKernelGGL(ew_f16_kernel, dim3(ew_blocks(rows * (C / 8))), dim3(256), 0, sn_stream(stream), (const half_t *)a,
+                     (const half_t *)b, (const half_t *)ref, (half_t *)y, rows, C, ps_a, ps_b, ps_ref, ps_y, mode);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Max pooling, channels-last fp16 (resnet_mx_101_e2e.py:409: 3x3 stride 2 pad 1).  Forward only:
+// the stem is frozen (network.FIXED_PARAMS), nothing upstream needs a gradient.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const half_t *__restrict__ x, half_t *__restrict__ y, int N, int H,
+                                                      int W, int C, int Ho, int Wo, int k, int stride, int pad) {
+  const int cpr = C >> 3;
+  const long total = (long)N * Ho * Wo * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr) * 8;
+    long t = i / cpr;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -65504.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int sy = oy * stride - pad + ky;
+      if ((unsigned)sy >= (unsigned)H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int sx = ox * stride - pad + kx;
+        if ((unsigned)sx >= (unsigned)W) continue;
+        const half8 v = *reinterpret_cast<const half8 *>(x + (((long)n * H + sy) * W + sx) * C + ch);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+      }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)m[j];
+    *reinterpret_cast<half8 *>(y + i * 8) = o;
+  }
+}
+
+SN_EXPORT int sn_maxpool_fwd(const void *x, void *y, int N, int H, int W, int C, int k, int stride, int pad,
+                             sn_stream_t stream) {
+  SN_REQUIRE(x && y && C % 8 == 0 && k > 0 && stride > 0, "sn_maxpool_fwd: bad arguments");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 8))), dim3(256), 0, sn_stream(stream),
+                     (const half_t *)x, (half_t *)y, N, H, W, C, Ho, Wo, k, stride, pad);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout / dtype conversion between the reference's NCHW tensors and internal NHWC.
+//   nhwc(src, pixel stride ps, dtype f16|f32) -> nchw (dst contiguous, dtype f16|f32) and back.
+// Tiled through LDS so that both sides are coalesced.
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI *__restrict__ in, TO *__restrict__ out, int rows, int cols,
+                                                        long in_batch, long out_batch, int in_ld, int out_ld) {
+  // out[b][c][r] = in[b][r][c]  (rows x cols per batch)
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) tile[k][tx] = (float)in[(long)b * in_batch + (long)r * in_ld + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (r < rows && c < cols) out[(long)b * out_batch + (long)c * out_ld + r] = (TO)tile[tx][k];
+  }
+}
+
+// dtype codes: 0 = f16, 1 = f32
+SN_EXPORT int sn_transpose_batched(const void *in, void *out, int batch, int rows, int cols, long in_batch_stride,
+                                   long out_batch_stride, int in_ld, int out_ld, int in_dtype, int out_dtype,
+                                   sn_stream_t stream) {
+  SN_REQUIRE(in && out && batch > 0 && rows > 0 && cols > 0, "sn_transpose_batched: bad arguments");
+  SN_REQUIRE(batch <= 65535, "sn_transpose_batched: batch too large");
+  dim3 grid(sn_div_up(cols, 32), sn_div_up(rows, 32), batch);
+  hipStream_t s = sn_stream(stream);
+  if (in_dtype == 0 && out_dtype == 0)
+    hipLaunchKernelGGL((transpose_kernel<half_t, half_t>), grid, dim3(256), 0, s, (const half_t *)in, (half_t *)out, rows, cols,
+                       in_batch_stride, out_batch_stride, in_ld, out_ld);
+  else if (in_dtype == 0 && out_dtype == 1)
+    hipLaunchKernelGGL((transpose_kernel<half_t, float>), grid, dim3(256), 0, s, (const half_t *)in, (float *)out, rows, cols,
+                       in_batch_stride, out_batch_stride, in_ld, out_ld);
+  else if (in_dtype == 1 && out_dtype == 0)
+    hipLaunchKernelGGL((transpose_kernel<float, half_t>), grid, dim3(256), 0, s, (const float *)in, (half_t *)out, rows, cols,
+                       in_batch_stride, out_batch_stride, in_ld, out_ld);
+  else
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float *)in, (float *)out, rows, cols,
+                       in_batch_stride, out_batch_stride, in_ld, out_ld);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// strided 2-D copy with dtype conversion: out[r][c] = in[r][c], c < cols (Concat slices, Cast)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy2d_kernel(const TI *__restrict__ in, TO *__restrict__ out, long rows, int cols,
+                                                     int in_ld, int out_ld) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i - r * cols);
+    out[r * out_ld + c] = (TO)in[r * in_ld + c];
+  }
+}
+
+SN_EXPORT int sn_copy2d(const void *in, void *out, long rows, int cols, int in_ld, int out_ld, int in_dtype, int out_dtype,
+                        sn_stream_t stream) {
+  SN_REQUIRE(in && out && rows > 0 && cols > 0, "sn_copy2d: bad arguments");
+  hipStream_t s = sn_stream(stream);
+  const dim3 grid(ew_blocks(rows * cols));
+  if (in_dtype == 0 && out_dtype == 0)
+    hipLaunchKernelGGL((copy2d_kernel<half_t, half_t>), grid, dim3(256), 0, s, (const half_t *)in, (half_t *)out, rows, cols, in_ld, out_ld);
+  else if (in_dtype == 0 && out_dtype == 1)
+    hipLaunchKernelGGL((copy2d_kernel<half_t, float>), grid, dim3(256), 0, s, (const half_t *)in, (float *)out, rows, cols, in_ld, out_ld);
+  else if (in_dtype == 1 && out_dtype == 0)
+    hipLaunchKernelGGL((copy2d_kernel<float, half_t>), grid, dim3(256), 0, s, (const float *)in, (half_t *)out, rows, cols, in_ld, out_ld);
+  else
+    hipLaunchKernelGGL((copy2d_kernel<float, float>), grid, dim3(256), 0, s, (const float *)in, (float *)out, rows, cols, in_ld, out_ld);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SoftmaxOutput(multi_output, use_ignore, ignore_label, normalization='valid', grad_scale)
+// (resnet_mx_101_e2e.py:279-281, 310-311, 314-315).  Logical view: data (outer, K, inner) fp32
+// contiguous, label (outer, inner).  forward: softmax over K.  backward:
+//     grad = grad_scale / max(1, #labels != ignore) * (p - onehot(label)),  0 where label == ignore
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ p, long outer, int K,
+                                                          long inner) {
+  const long total = outer * inner;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long o = i / inner, s = i - o * inner;
+    const float *xi = x + o * K * inner + s;
+    float m = xi[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, xi[(long)k * inner]);
+    float z = 0.f;
+    for (int k = 0; k < K; ++k) z += expf(xi[(long)k * inner] - m);
+    const float iz = 1.f / z;
+    float *pi = p + o * K * inner + s;
+    for (int k = 0; k < K; ++k) pi[(long)k * inner] = expf(xi[(long)k * inner] - m) * iz;
+  }
+}
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const float *__restrict__ label, long n, float ignore,
+                                                          int *__restrict__ count) {
+  int c = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    c += (label[i] != ignore);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restrict__ p, const float *__restrict__ label,
+                                                          float *__restrict__ g, long outer, int K, long inner,
+                                                          float ignore, int use_ignore, float grad_scale, int normalize_valid,
+                                                          const int *__restrict__ valid_count) {
+  const long total = outer * inner;
+  float mul = grad_scale;
+  if (normalize_valid) {
+    const int vc = *valid_count;
+    mul = grad_scale / (float)(vc > 1 ? vc : 1);
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long o = i / inner, s = i - o * inner;
+    const float l = label[i];
+    const bool ign = use_ignore && l == ignore;
+    const int li = (int)l;
+    for (int k = 0; k < K; ++k) {
+      const long idx = o * K * inner + (long)k * inner + s;
+      g[idx] = ign ? 0.f : mul * (p[idx] - (k == li ? 1.f : 0.f));
+    }
+  }
+}
+
+SN_EXPORT int sn_softmax_fwd(const float *x, float *p, long outer, int K, long inner, sn_stream_t stream) {
+  SN_REQUIRE(x && p && outer > 0 && K > 0 && inner > 0, "sn_softmax_fwd: bad arguments");
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(ew_blocks(outer * inner)), dim3(256), 0, sn_stream(stream), x, p, outer, K, inner);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ws: one int (valid-label counter)
+SN_EXPORT int sn_softmax_output_bwd(const float *p, const float *label, float *grad, long outer, int K, long inner,
+                                    float ignore_label, int use_ignore, float grad_scale, int normalize_valid, int *ws,
+                                    sn_stream_t stream) {
+  SN_REQUIRE(p && label && grad && ws, "sn_softmax_output_bwd: null pointer");
+  hipStream_t s = sn_stream(stream);
+  if (normalize_valid) {
+    SN_HIP(hipMemsetAsync(ws, 0, sizeof(int), s));
+    hipLaunchKernelGGL(count_valid_kernel, dim3(ew_blocks(outer * inner)), dim3(256), 0, s, label, outer * inner,
+                       use_ignore ? ignore_label : -1e30f, ws);
+    SN_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ew_blocks(outer * inner)), dim3(256), 0, s, p, label, grad, outer, K, inner,
+                     ignore_label, use_ignore, grad_scale, normalize_valid, ws);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight * smooth_l1(pred - target, sigma) and its MakeLoss gradient (resnet_mx_101_e2e.py:317-319,
+// 330-334).  fwd: loss = w * f(d), d = pred - target;  bwd: dpred = grad_scale * w * f'(d)
+//   f(d) = 0.5 (sigma d)^2 if |d| < 1/sigma^2 else |d| - 0.5/sigma^2
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float *__restrict__ pred, const float *__restrict__ target,
+                                                        const float *__restrict__ weight, float *__restrict__ loss,
+                                                        float *__restrict__ dpred, long n, float sigma, float grad_scale) {
+  const float s2 = sigma * sigma, th = 1.f / s2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = pred[i] - target[i], w = weight[i];
+    const float ad = fabsf(d);
+    if (loss) loss[i] = w * (ad < th ? 0.5f * s2 * d * d : ad - 0.5f * th);
+    if (dpred) dpred[i] = grad_scale * w * (ad < th ? s2 * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+  }
+}
+
+SN_EXPORT int sn_smooth_l1_loss(const float *pred, const float *target, const float *weight, float *loss, float *dpred,
+                                long n, float sigma, float grad_scale, sn_stream_t stream) {
+  SN_REQUIRE(pred && target && weight && n > 0, "sn_smooth_l1_loss: bad arguments");
+  hipLaunchKernelGGL(smooth_l1_kernel, dim3(ew_blocks(n)), dim3(256), 0, sn_stream(stream), pred, target, weight, loss, dpred,
+                     n, sigma, grad_scale);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-precision SGD with momentum (lib/train_utils/utils.py:26-33 -> mx 'sgd', multi_precision):
+//   g   = rescale * grad + wd * w32
+//   mom = momentum * mom - lr * g ;  w32 += mom ;  w16 = half(w32)
+// One launch per parameter group (same lr/wd); grad is the fp32 arena the wgrad kernels and the
+// RCCL all-reduce work on.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ w32, const float *__restrict__ grad, float *__restrict__ mom,
+                                                  half_t *__restrict__ w16, long n, float lr, float wd, float momentum,
+                                                  float rescale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float w = w32[i];
+    const float g = rescale * grad[i] + wd * w;
+    const float m = momentum * mom[i] - lr * g;
+    mom[i] = m;
+    const float nw = w + m;
+    w32[i] = nw;
+    if (w16) w16[i] = (half_t)nw;
+  }
+}
+
+SN_EXPORT int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void *w16, long n, float lr, float wd,
+                                float momentum, float rescale, sn_stream_t stream) {
+  SN_REQUIRE(w32 && grad && mom && n >= 0, "sn_sgd_mom_update: bad arguments");
+  if (n == 0) return SN_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, sn_stream(stream), w32, grad, mom, (half_t *)w16, n, lr, wd,
+                     momentum, rescale);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// fp32 [O][T][I] -> fp16 [I][T][O]  (weights for the data-gradient GEMM), and plain fp32->fp16
+__global__ __launch_bounds__(256) void weight_oti_to_ito_kernel(const float *__restrict__ w, half_t *__restrict__ wt, int O, int T,
+                                                                int I) {
+  const long total = (long)O * T * I;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // i indexes the destination so that writes are coalesced
+    const int o = (int)(i % O);
+    const long r = i / O;
+    const int t = (int)(r % T), ci = (int)(r / T);
+    wt[i] = (half_t)w[((long)o * T + t) * I + ci];
+  }
+}
+
+SN_EXPORT int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, sn_stream_t stream) {
+  SN_REQUIRE(w_oti && wt_ito_f16 && O > 0 && T > 0 && I > 0, "sn_weight_transpose: bad arguments");
+  hipLaunchKernelGGL(weight_oti_to_ito_kernel, dim3(ew_blocks((long)O * T * I)), dim3(256), 0, sn_stream(stream), w_oti,
+                     (half_t *)wt_ito_f16, O, T, I);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// generic fp32 element-wise helpers for the small loss-side tensors: out = a (op) b
+// op 0: a - b, 1: a + b, 2: a * b, 3: a * scalar, 4: fill(scalar)
+__global__ __launch_bounds__(256) void ew_f32_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out,
+                                                     long n, int op, float scalar) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    switch (op) {
+      case 0: v = a[i] - b[i]; break;
+      case 1: v = a[i] + b[i]; break;
+      case 2: v = a[i] * b[i]; break;
+      case 3: v = a[i] * scalar; break;
+      default: v = scalar; break;
+    }
+    out[i] = v;
+  }
+}
+
+SN_EXPORT int sn_ew_f32(const float *a, const float *b, float *out, long n, int op, float scalar, sn_stream_t stream) {
+  SN_REQUIRE(out && n > 0 && op >= 0 && op <= 4, "sn_ew_f32: bad arguments");
+  SN_REQUIRE(op == 4 || a, "sn_ew_f32: null a");
+  SN_REQUIRE(op > 2 || b, "sn_ew_f32: null b");
+  hipLaunchKernelGGL(ew_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, sn_stream(stream), a, b, out, n, op, scalar);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// bias gradient: db[c] += sum over rows of dy[r][c]   (dy fp16 or fp32, row stride ld)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dy, float *__restrict__ db, long rows, int C, int ld,
+                                                        long rows_per_block) {
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + rl; r < r1; r += 4) s += (float)dy[r * ld + c];
+  __shared__ float red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(&db[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+SN_EXPORT int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, sn_stream_t stream) {
+  SN_REQUIRE(dy && db && rows > 0 && C > 0, "sn_bias_grad: bad arguments");
+  int by = (int)((rows + 255) / 256);
+  if (by > 512) by = 512;
+  const long rpb = (rows + by - 1) / by;
+  by = (int)((rows + rpb - 1) / rpb);
+  dim3 grid(sn_div_up(C, 64), by);
+  if (dtype == 0)
+    hipLaunchKernelGGL((bias_grad_kernel<half_t>), grid, dim3(256), 0, sn_stream(stream), (const half_t *)dy, db, rows, C, ld, rpb);
+  else
+    hipLaunchKernelGGL((bias_grad_kernel<float>), grid, dim3(256), 0, sn_stream(stream), (const float *)dy, db, rows, C, ld, rpb);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}

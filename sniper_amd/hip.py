@@ -1,0 +1,56 @@
+"""Glue between torch device tensors and the C ABI: torch owns memory and streams (plumbing), the
+kernels are ours.  `call("sn_xxx", tensor_or_scalar, ...)` passes `tensor.data_ptr()` for tensors,
+None -> NULL, and appends nothing implicitly -- the stream is passed explicitly via `stream()`."""
+import ctypes
+
+import torch
+
+from ._lib import SniperHipError, lib  # noqa: F401
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("sniper_amd needs a HIP device (MI355X); no CPU fallback exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    """hipStream_t of torch's current stream (so our kernels order with torch's allocator/events)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv(a):
+    if isinstance(a, torch.Tensor):
+        return ctypes.c_void_p(a.data_ptr())
+    return a
+
+
+def call(name, *args):
+    return lib().call(name, *[_conv(a) for a in args])
+
+
+def query(name, *args):
+    """For non-status entry points (workspace sizes, counts)."""
+    return lib().raw(name)(*[_conv(a) for a in args])
+
+
+def dev(x, dtype=None, device=None):
+    """numpy / tensor -> contiguous device tensor."""
+    device = device or require_gpu()
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device).contiguous()
+
+
+class Workspace(object):
+    """Grow-only device scratch buffer (no allocation inside the hot calls)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=require_gpu())
+        return self.buf

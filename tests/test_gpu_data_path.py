@@ -1,0 +1,190 @@
+"""-m gpu: the HIP data-path kernels (through the C ABI) against the oracle and the golden vectors.
+Bit-exact for chips / IoU / labels / NMS survivor sets; bbox targets (float64 log on the device vs
+numpy) within 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from oracle import data_path  # noqa: E402
+from golden_util import anchor_case, golden, ref_cfg  # noqa: E402
+
+
+def test_library_loads_on_gpu():
+    from sniper_amd import hip
+    assert hip.lib().raw('sn_version')() >= 100
+    assert torch.cuda.is_available()
+
+
+def test_iou_golden_and_random():
+    from sniper_amd.ext import bbox
+    g = golden()
+    for t in range(int(g['iou_count'])):
+        a, q = g['iou_%d_a' % t], g['iou_%d_q' % t]
+        assert np.array_equal(bbox.bbox_overlaps_cython(a, q), g['iou_%d_iou' % t])
+        assert np.array_equal(bbox.ignore_overlaps_cython(a, q), g['iou_%d_ign' % t])
+    rs = np.random.RandomState(0)
+    a = np.round(rs.uniform(0, 512, (21504, 4)))
+    a[:, 2:] += a[:, :2]
+    q = np.round(rs.uniform(0, 512, (100, 4)))
+    q[:, 2:] += q[:, :2]
+    assert np.array_equal(bbox.bbox_overlaps_cython(a, q), oracle.bbox_overlaps(a, q))
+    assert bbox.bbox_overlaps_cython(np.zeros((0, 4)), q).shape == (0, 100)
+
+
+def test_chips_golden_batched():
+    from sniper_amd.ext import chips
+    g = golden()
+    n = int(g['chips_count'])
+    units, perms, want = [], [], []
+    for t in range(n):
+        W, H, cs, stride, seed = [int(v) for v in g['chips_%02d_meta' % t]]
+        units.append((g['chips_%02d_boxes' % t], W, H, cs, stride))
+        perms.append(g['chips_%02d_perm' % t])
+        want.append(g['chips_%02d_out' % t])
+        assert chips.num_candidates(W, H, cs, stride) == len(perms[-1])
+    got = chips.generate_batch(units, perms)
+    for t in range(n):
+        assert got[t].shape == want[t].shape and np.array_equal(got[t], want[t]), (t, got[t], want[t])
+    # single-unit reference signature, identity permutation vs oracle
+    b = units[5][0]
+    one = chips.generate(b, *units[5][1:], perm=np.arange(len(perms[5]), dtype=np.int32))
+    assert np.array_equal(np.array(one, np.float32).reshape(-1, 4), oracle.chips_generate(b, *units[5][1:]))
+
+
+def test_chips_random_many_boxes_vs_oracle():
+    """ragged batch incl. empty units and >64 boxes (multi-word masks); property: every box that some
+    candidate contains is covered by a selected chip."""
+    from sniper_amd.ext import chips
+    rs = np.random.RandomState(3)
+    units, perms = [], []
+    for t in range(40):
+        W, H = int(rs.randint(300, 2100)), int(rs.randint(300, 1600))
+        n = int(rs.choice([0, 1, 5, 70, 300]))
+        side = np.exp(rs.uniform(np.log(4), np.log(300), size=n))
+        x1, y1 = rs.uniform(0, W - 2, size=n), rs.uniform(0, H - 2, size=n)
+        b = np.stack((x1, y1, np.minimum(x1 + side, W - 2), np.minimum(y1 + side, H - 2)), 1).astype(np.float32)
+        stride = int(rs.randint(56, 60))
+        units.append((b, W, H, 512, stride))
+        perms.append(rs.permutation(chips.num_candidates(W, H, 512, stride)).astype(np.int32))
+    got = chips.generate_batch(units, perms)
+    for (b, W, H, cs, st), p, gch in zip(units, perms, got):
+        want = oracle.chips_generate(b, W, H, cs, st, p)
+        assert np.array_equal(gch, want)
+
+
+def _np_sorted(rs, n):
+    c = rs.uniform(0, 600, size=(n, 2))
+    wh = np.exp(rs.uniform(np.log(8), np.log(300), size=(n, 2)))
+    d = np.concatenate((c - wh / 2, c + wh / 2, rs.uniform(0, 1, size=(n, 1))), 1).astype(np.float32)
+    return d[np.argsort(-d[:, 4], kind='stable')]
+
+
+def test_nms_survivor_sets_bit_exact():
+    from sniper_amd import hip
+    from sniper_amd.ext import gpu_nms
+    rs = np.random.RandomState(5)
+    for n in (1, 63, 64, 65, 129, 1000, 6000):
+        d = _np_sorted(rs, n)
+        for th in (0.3, 0.7):
+            keep, nk = gpu_nms.nms_sorted_device(hip.dev(d[None]), th)
+            got = keep[0, :int(nk[0])].cpu().numpy()
+            want = oracle.nms_sorted(d, th)
+            assert np.array_equal(got, want), (n, th, len(got), len(want))
+    # batched + max_keep (the proposal op's 6000 -> 300)
+    ds = np.stack([_np_sorted(rs, 6000) for _ in range(4)])
+    keep, nk = gpu_nms.nms_sorted_device(hip.dev(ds), 0.7, 300)
+    for b in range(4):
+        want = oracle.nms_sorted(ds[b], 0.7, 300)
+        assert int(nk[b]) == len(want) and np.array_equal(keep[b, :len(want)].cpu().numpy(), want)
+    # reference-signature wrappers: unsorted input, idempotence, cpu_nms tie rule
+    d = _np_sorted(rs, 500)[rs.permutation(500)]
+    k = gpu_nms.gpu_nms(d, 0.5)
+    srt = d[np.argsort(-d[:, 4], kind='stable')]
+    assert sorted(map(int, k)) == sorted(map(int, np.argsort(-d[:, 4], kind='stable')[oracle.nms_sorted(srt, 0.5)]))
+    assert len(gpu_nms.gpu_nms(d[k], 0.5)) == len(k)
+    from sniper_amd.ext import cpu_nms
+    two = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    th = float(np.float32(50.0) / np.float32(150.0))
+    assert list(map(int, gpu_nms.gpu_nms(two, th))) == [0, 1]
+    assert list(map(int, cpu_nms.cpu_nms(two, th))) == [0]
+
+
+def test_nms_host_abi_drop_in():
+    """sn_nms_host has the reference's _nms() signature (lib/nms/gpu_nms.hpp)."""
+    import ctypes
+    from sniper_amd import hip
+    rs = np.random.RandomState(6)
+    d = _np_sorted(rs, 777)
+    keep = np.zeros(777, np.int32)
+    num = ctypes.c_int(0)
+    rc = hip.lib().raw('sn_nms_host')(keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num),
+                                      d.ctypes.data_as(ctypes.c_void_p), 777, 5, ctypes.c_float(0.7), 0)
+    assert rc == 0
+    assert np.array_equal(keep[:num.value], oracle.nms_sorted(d, 0.7))
+
+
+def test_anchor_assign_golden_bit_exact():
+    from sniper_amd.data.anchors import AnchorAssigner
+    cfg = ref_cfg()
+    aa = AnchorAssigner(cfg, 512)
+    at = data_path.AnchorTarget(512, 16, cfg.network.ANCHOR_RATIOS, cfg.network.ANCHOR_SCALES)
+    assert np.array_equal(aa.base, data_path.generate_anchors(16, cfg.network.ANCHOR_RATIOS,
+                                                              np.array(cfg.network.ANCHOR_SCALES, np.float32)))
+    g = golden()
+    n = int(g['anchor_count'])
+    cases = [anchor_case(k) for k in range(n)]
+    chips = [c[0] for c in cases]
+    pre = aa.assign(chips, want_label_pre=True)
+    lp = pre['label_pre'].cpu().numpy()
+    counts = pre['counts'].cpu().numpy()
+    # labels before sub-sampling vs the oracle's intermediate
+    for k, (args, seed, want) in enumerate(cases):
+        valid, invalid, agt, classes, _ = at.prepare_boxes(*[np.copy(a) if isinstance(a, np.ndarray) else a for a in args])
+        inside, anchors, labels, argmax = at.label_anchors(args[0], valid, invalid)
+        assert counts[k, 0] == len(inside) and counts[k, 3] == len(valid), (k, counts[k], len(inside), len(valid))
+        assert np.array_equal(lp[k][inside], labels.astype(np.int8)), k
+        assert (lp[k][np.setdiff1d(np.arange(lp.shape[1]), inside)] == -2).all()
+    # replay numpy's sub-sampling draws chip by chip (each golden case was generated with its own seed)
+    keys = np.zeros(lp.shape, np.uint32)
+    for k, (args, seed, want) in enumerate(cases):
+        np.random.seed(seed)
+        keys[k] = aa.numpy_replay_keys(lp[k:k + 1])[0]
+    out = aa.assign(chips, keys=keys)
+    label = out['label'].cpu().numpy()
+    tgt = out['bbox_target'].cpu().numpy()
+    wgt = out['bbox_weight'].cpu().numpy()
+    gtb = out['gt_boxes'].cpu().numpy()
+    for k, (args, seed, want) in enumerate(cases):
+        assert np.array_equal(label[k], want[0]), (k, np.argwhere(label[k] != want[0])[:5])
+        assert np.array_equal(wgt[k], want[2]), k
+        assert np.array_equal(gtb[k], want[3]), k
+        assert np.allclose(tgt[k], want[1], rtol=0, atol=1e-6), (k, np.abs(tgt[k] - want[1]).max())
+
+
+def test_anchor_assign_device_rng_invariants():
+    """No host keys: on-device hashed sub-sampling must satisfy data_workers.py:327-338's invariants
+    and leave everything that is not sub-sampled identical to the oracle."""
+    from sniper_amd.data.anchors import AnchorAssigner
+    cfg = ref_cfg()
+    aa = AnchorAssigner(cfg, 512)
+    cases = [anchor_case(k) for k in range(12)]
+    out = aa.assign([c[0] for c in cases], seed=1234, want_label_pre=True)
+    label = out['label'].cpu().numpy()
+    lp = out['label_pre'].cpu().numpy()
+    wgt = out['bbox_weight'].cpu().numpy()
+    A, F = aa.A, aa.F
+    for k in range(len(cases)):
+        fg, bg = (label[k] == 1).sum(), (label[k] == 0).sum()
+        pre = lp[k].reshape(F * F, A).T.reshape(-1)  # (a, cell) order of the label output
+        n_fg_pre, n_bg_pre = (pre == 1).sum(), (pre == 0).sum()
+        assert fg == min(n_fg_pre, 128)
+        assert bg == min(n_bg_pre, 256 - fg)
+        assert ((label[k] == 1) <= (pre == 1)).all() and ((label[k] == 0) <= (pre == 0)).all()
+        assert wgt[k].sum() == 4 * fg
+    out2 = aa.assign([c[0] for c in cases], seed=1234)
+    assert torch.equal(out2['label'], out['label'])
+    out3 = aa.assign([c[0] for c in cases], seed=99)
+    assert not torch.equal(out3['label'], out['label'])
