@@ -1,0 +1,232 @@
+"""bench.py -- SNIPER training throughput on MI355X (BASELINE.json metric: train chips/s, 512x512, R101).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (config.workload): BASELINE configs[1] -- ResNet-101 Faster-RCNN SNIPER, 3-scale chips,
+20 x 512 x 512 chips per GPU, fp16 storage / fp32 accumulate, seeded synthetic COCO-shaped data
+(sniper_amd/synthetic.py), random-init weights.  One *step* = one pass of the hot path over one chip
+minibatch that is already resident in HBM: GPU anchor labelling of the 20 chips -> forward (conv
+backbone, RPN, MultiProposalTarget, deformable PS-RoI pooling, heads, losses) -> backward -> gradient
+all-reduce (RCCL, N > 1) -> multi-precision SGD update.  Every GPU owns an independent chip
+minibatch (weak scaling, no sync-BN); value = N * B * K / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel family (implicit-GEMM MFMA convolution: forward + data gradient +
+                weight gradient launches) measured live with HIP events on the launch stream:
+                achieved = algorithmic FLOPs of those launches / their summed duration, peak = 2.5 PFLOP/s
+                dense fp16 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline  the reference's CPU iterator path (chip extraction + box assignment + RPN anchor
+                labelling; oracle/ restatement of lib/data_utils/data_workers.py) timed on this node's
+                host cores on a bounded sample, in chips/s.  kind "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(name, a):
+    """Algorithmic FLOPs of one conv-family launch from its C-ABI arguments."""
+    if name == 'sn_conv_fwd':
+        N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[5:18]
+    elif name == 'sn_conv_dgrad':
+        N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[4:17]
+    elif name == 'sn_conv_wgrad':
+        N, H, W, Cin, _, Cout, _, KH, KW, s, p, d = a[3:15]
+    elif name == 'sn_conv_stem_fwd':
+        N, Hp, Wp, Ho, Wo, Cout, _, KH, KWP, s = a[4:14]
+        return 2.0 * N * Ho * Wo * Cout * KH * 7 * 3   # real 7x7x3 taps (the padded ones are zeros)
+    else:
+        return 0.0
+    Ho = (H + 2 * p - d * (KH - 1) - 1) // s + 1
+    Wo = (W + 2 * p - d * (KW - 1) - 1) // s + 1
+    return 2.0 * N * Ho * Wo * Cout * Cin * KH * KW
+
+
+class ConvProfiler(object):
+    """Wraps sniper_amd.hip.call: brackets every conv-family launch with HIP events recorded on the
+    stream the kernel is launched on (torch's current stream)."""
+    NAMES = ('sn_conv_fwd', 'sn_conv_dgrad', 'sn_conv_wgrad', 'sn_conv_stem_fwd')
+
+    def __init__(self):
+        from sniper_amd import hip
+        self.hip = hip
+        self.orig = hip.call
+        self.records = []
+
+    def __enter__(self):
+        def call(name, *args):
+            if name in self.NAMES:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = self.orig(name, *args)
+                e1.record()
+                self.records.append((name, conv_flops(name, args), e0, e1))
+                return r
+            return self.orig(name, *args)
+        self.hip.call = call
+        import sniper_amd.engine.ops as ops
+        import sniper_amd.engine.executor as ex
+        self._mods = (ops, ex)
+        return self
+
+    def __exit__(self, *exc):
+        self.hip.call = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot_ms, tot_fl, per = 0.0, 0.0, {}
+        for name, fl, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            tot_ms += ms
+            tot_fl += fl
+            d = per.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += ms
+            d[2] += fl
+        return tot_ms, tot_fl, per
+
+
+def cpu_baseline(seconds_target=15.0):
+    """The reference's CPU data path (oracle restatement), Pool(P) over images like MNIteratorE2E does."""
+    import multiprocessing as mp
+    from oracle import build as obuild
+    obuild.build_restatement()
+    P = min(os.cpu_count() or 1, 64)   # TRAIN.NUM_PROCESS = 64 in the reference config
+    n_img = 16 * P
+    t0 = time.time()
+    with mp.get_context('fork').Pool(P) as pool:
+        chips = pool.map(_cpu_image_chips, range(n_img), chunksize=4)
+    dt = time.time() - t0
+    n_chips = int(sum(chips))
+    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'port',
+            'sample': '%d synthetic images -> %d chips: chip_extractor + box_assigner + anchor_worker (oracle/data_path.py, '
+                      'restating lib/data_utils/data_workers.py) under multiprocessing.Pool(%d), %.1f s' % (n_img, n_chips, P, dt)}
+
+
+def _cpu_image_chips(i):
+    from oracle import data_path
+    from sniper_amd import config as cfgmod
+    from sniper_amd.synthetic import make_roidb
+    cfg = cfgmod.res101_e2e()
+    r = make_roidb(1, seed=100000 + i, n_proposals=0)[0]
+    np.random.seed(i)
+    crops = data_path.chip_extractor(r, cfg.TRAIN.SCALES, cfg.TRAIN.VALID_RANGES, 512, 56, None)
+    r['crops'] = crops
+    props = data_path.box_assigner(r, cfg.TRAIN.SCALES, cfg.TRAIN.VALID_RANGES, 512, 56, False, None)[0]
+    at = _cpu_image_chips.at = getattr(_cpu_image_chips, 'at', None) or data_path.AnchorTarget(
+        512, 16, cfg.network.ANCHOR_RATIOS, cfg.network.ANCHOR_SCALES)
+    gtids = np.where(r['max_overlaps'] == 1)[0]
+    for ci, crop in enumerate(crops):
+        at([512, 512, crop[1]], crop[0].copy(), crop[1], props[ci], gtids, r['boxes'][gtids].copy(), r['boxes'].copy(),
+           r['max_classes'][gtids].reshape(-1, 1))
+    return len(crops)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=20, help='chips per GPU (BASELINE C2: 20)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...' %
+                         (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl')   # RCCL over xGMI
+
+    from sniper_amd import hip
+    from sniper_amd.train import Trainer
+    tr = Trainer(batch_images=args.batch, n_images=48, seed=1000 * rank, rank_local=True)
+    # a few distinct chip minibatches, resident in HBM before the timed region; their anchor-labelling inputs
+    # (GT boxes per chip) are kept so that the labelling itself runs inside every step
+    batches = [tr.batch] + [tr.next_batch() for _ in range(3)]
+    import sniper_amd.mx as mx
+    anchors = tr.iter.anchors
+
+    def step(i):
+        b = batches[i % len(batches)]
+        lab = anchors.assign(b.worker_data, seed=i)
+        label = [mx.nd.NDArray(lab['label']), mx.nd.NDArray(lab['bbox_target']), mx.nd.NDArray(lab['bbox_weight']),
+                 mx.nd.NDArray(lab['gt_boxes'])]
+        tr.step(mx.io.DataBatch(data=b.data, label=label, pad=0, index=None, provide_data=b.provide_data,
+                                provide_label=b.provide_label))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    # ---- roofline of the dominant kernel family, live HIP-event timing (untimed extra steps)
+    roof = None
+    if rank == 0:
+        with ConvProfiler() as prof:
+            for i in range(2):
+                step(i)
+            tot_ms, tot_fl, per = prof.summary()
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel / conv_wgrad_kernel (sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad)',
+                'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
+                'traffic': None,
+                'launches_per_step': sum(v[0] for v in per.values()) // 2,
+                'avg_launch_ms': round(tot_ms / max(1, sum(v[0] for v in per.values())), 4),
+                'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
+                'by_entry': {k: {'launches': v[0] // 2, 'ms_per_step': round(v[1] / 2, 3),
+                                 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in per.items()}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:   # the baseline is a report, never a reason to lose the measurement
+            cpu = {'value': None, 'unit': 'chips/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+    if rank == 0:
+        out = {
+            'metric': 'train chips/sec (512x512, R101)', 'value': round(value, 2), 'unit': 'chips/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16 storage / fp32 accumulate', 'data': 'synthetic',
+            'config': {'workload': 'ResNet-101 Faster-RCNN SNIPER 3-scale, batch %d x 512x512 fp16 per GPU (BASELINE configs[1]); '
+                                   'step = GPU anchor labelling + fwd + bwd + grad all-reduce + SGD' % args.batch,
+                       'chips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -55,6 +55,14 @@ int sn_chips_generate_batch(const float *d_boxes, const int32_t *d_box_off, cons
                             const int32_t *d_cand_off, int U, int max_boxes_per_unit, void *d_mask_ws, float *d_out_chips,
                             int32_t *d_out_ids, int32_t *d_out_count, sn_stream_t stream);
 
+/* Box -> chip assignment of chip_worker.box_assigner (lib/data_utils/data_workers.py:516-535, 557-572) for a
+ * ragged batch of U (image, scale) units: d_chips (total_chips,4) f64 + d_chip_off (U+1); d_boxes (total_boxes,4)
+ * f64 + d_box_off (U+1) + d_unit_of_box (total_boxes); d_range (U,2) f64 valid range; d_mode (U) 0 = coarsest
+ * (area >= lo), 1 = area <= hi, 2 = area < hi.  d_out_chip (total_boxes): chip index inside the unit or -1. */
+int sn_assign_boxes_batch(const double *d_chips, const int32_t *d_chip_off, const double *d_boxes, const int32_t *d_box_off,
+                          const double *d_range, const int32_t *d_mode, const int32_t *d_unit_of_box, int U, int total_boxes,
+                          int32_t *d_out_chip, sn_stream_t stream);
+
 /* ------------------------------------------------------------------ RPN anchor labelling ----- */
 /* anchor_worker.worker (lib/data_utils/data_workers.py:164-371) + the dense scatter of
  * MNIteratorE2E._get_batch (lib/iterators/MNIteratorE2E.py:175-194), batched over B chips.
@@ -182,17 +190,17 @@ int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, co
                        sn_stream_t stream);
 
 /* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward. */
-int sn_deform_im2col(const void *data, const float *offset, void *col, int N, int H, int W, int C, int KH, int KW, int stride,
-                     int pad, int dil, int deformable_groups, int offset_pix_stride, sn_stream_t stream);
-int sn_deform_col2im(const void *dcol, const void *data, const float *offset, float *d_data, float *d_offset, int N, int H, int W,
+int sn_deform_im2col(const void *data, const void *offset, void *col, int N, int H, int W, int C, int KH, int KW, int stride,
+                     int pad, int dil, int deformable_groups, int offset_pix_stride, int offset_dtype, sn_stream_t stream);
+int sn_deform_col2im(const void *dcol, const void *data, const void *offset, float *d_data, void *d_offset, int N, int H, int W,
                      int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups, int offset_pix_stride,
-                     sn_stream_t stream);
+                     int offset_dtype, sn_stream_t stream);
 
 /* Multi-precision SGD with momentum (lib/train_utils/utils.py:26-33). */
 int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void *w16, long n, float lr, float wd, float momentum,
                       float rescale, sn_stream_t stream);
-/* fp32 [O][T][I] -> fp16 [I][T][O] (weights for sn_conv_dgrad). */
-int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, sn_stream_t stream);
+/* fp32 [O][T][I] -> fp16 [I][T][O_pad] (weights for sn_conv_dgrad; O_pad = O rounded up to 8, zero filled). */
+int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, int O_pad, sn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -41,8 +41,8 @@ def proposals(cls_prob, bbox_pred, im_info, feat_stride, scales, ratios, pre_nms
         cy = anc[:, 1] + f32(0.5) * (ah - f32(1))
         pcx = d[:, 0] * aw + cx
         pcy = d[:, 1] * ah + cy
-        pw = np.exp(d[:, 2]).astype(f32) * aw
-        ph = np.exp(d[:, 3]).astype(f32) * ah
+        pw = np.exp(d[:, 2].astype(np.float64)).astype(f32) * aw  # exp in double, rounded once
+        ph = np.exp(d[:, 3].astype(np.float64)).astype(f32) * ah
         boxes = np.stack((pcx - f32(0.5) * (pw - f32(1)), pcy - f32(0.5) * (ph - f32(1)),
                           pcx + f32(0.5) * (pw - f32(1)), pcy + f32(0.5) * (ph - f32(1))), 1).astype(f32)
         im_h, im_w, im_s = [f32(v) for v in im_info[b]]

@@ -228,6 +228,59 @@ SN_EXPORT int sn_chips_generate_batch(const float *d_boxes, const int32_t *d_box
 }
 
 // ============================================================================================
+// Box -> chip assignment, chip_worker.box_assigner's inner loops (data_workers.py:516-535 for the
+// positive chips, :557-572 for the negative chips), for a ragged batch of (image, scale) units.
+// One thread per box: arg-max over the unit's chips of intersection / box-area (first maximum, as
+// ignore_overlaps(...).argmax(axis=0)), then the box is accepted iff the clipped intersection is at
+// least one pixel each way and sqrt(|inter area|) is inside the scale's valid range:
+//   mode 0 (coarsest scale): area >= lo;  mode 1: area <= hi (positive pass);  mode 2: area < hi.
+// out_chip[box] = chip index inside the unit, or -1.  All float64 like the reference.
+// ============================================================================================
+__global__ __launch_bounds__(256) void assign_boxes_kernel(const double *__restrict__ chips, const int32_t *__restrict__ chip_off,
+                                                           const double *__restrict__ boxes, const int32_t *__restrict__ box_off,
+                                                           const double *__restrict__ range, const int32_t *__restrict__ mode,
+                                                           const int32_t *__restrict__ unit_of_box, int total_boxes,
+                                                           int32_t *__restrict__ out_chip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total_boxes) return;
+  const int u = unit_of_box[i];
+  const int c0 = chip_off[u], nc = chip_off[u + 1] - c0;
+  const double4 b = reinterpret_cast<const double4 *>(boxes)[i];
+  int best = -1;
+  double bestv = -1.0;
+  for (int c = 0; c < nc; ++c) {
+    const double4 ch = reinterpret_cast<const double4 *>(chips)[c0 + c];
+    const double ov = overlap_f64(ch.x, ch.y, ch.z, ch.w, b.x, b.y, b.z, b.w, 1);
+    if (ov > bestv) { bestv = ov; best = c; }
+  }
+  int res = -1;
+  if (best >= 0) {
+    const double4 ch = reinterpret_cast<const double4 *>(chips)[c0 + best];
+    const double x1 = dmax(ch.x, b.x), x2 = dmin(ch.z, b.z), y1 = dmax(ch.y, b.y), y2 = dmin(ch.w, b.w);
+    const double area = sqrt(fabs((x2 - x1) * (y2 - y1)));
+    const double lo = range[2 * u], hi = range[2 * u + 1];
+    const int m = mode[u];
+    const bool in_range = m == 0 ? (area >= lo) : (m == 1 ? (area <= hi) : (area < hi));
+    if (x2 - x1 >= 1 && y2 - y1 >= 1 && in_range) res = best;
+  }
+  out_chip[i] = res;
+}
+
+SN_EXPORT int sn_assign_boxes_batch(const double *d_chips, const int32_t *d_chip_off, const double *d_boxes,
+                                    const int32_t *d_box_off, const double *d_range, const int32_t *d_mode,
+                                    const int32_t *d_unit_of_box, int U, int total_boxes, int32_t *d_out_chip,
+                                    sn_stream_t stream) {
+  SN_REQUIRE(U >= 0 && total_boxes >= 0, "sn_assign_boxes_batch: bad sizes");
+  if (U == 0 || total_boxes == 0) return SN_OK;
+  SN_REQUIRE(d_chips && d_chip_off && d_boxes && d_box_off && d_range && d_mode && d_unit_of_box && d_out_chip,
+             "sn_assign_boxes_batch: null pointer");
+  hipLaunchKernelGGL(assign_boxes_kernel, dim3(sn_div_up(total_boxes, 256)), dim3(256), 0, sn_stream(stream), d_chips,
+                     d_chip_off, d_boxes, d_box_off, d_range, d_mode, d_unit_of_box, total_boxes, d_out_chip);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ============================================================================================
 // RPN anchor labelling, batched over chips.  Four kernels on one stream:
 //   K1 anchor_prep_kernel     per chip: GT shift/scale/round/clip/filter, valid/invalid split
 //   K2 anchor_gtmax_kernel    per (chip, anchor): IoU vs valid GT, atomic per-GT max (column max)

@@ -623,23 +623,24 @@ SN_EXPORT int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void 
   return SN_OK;
 }
 
-// fp32 [O][T][I] -> fp16 [I][T][O]  (weights for the data-gradient GEMM), and plain fp32->fp16
+// fp32 [O][T][I] -> fp16 [I][T][Opad]  (weights for the data-gradient GEMM; Opad >= O is the
+// 8-aligned contraction length, columns O..Opad-1 are zero so a zero-padded dY is harmless)
 __global__ __launch_bounds__(256) void weight_oti_to_ito_kernel(const float *__restrict__ w, half_t *__restrict__ wt, int O, int T,
-                                                                int I) {
-  const long total = (long)O * T * I;
+                                                                int I, int Opad) {
+  const long total = (long)Opad * T * I;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     // i indexes the destination so that writes are coalesced
-    const int o = (int)(i % O);
-    const long r = i / O;
+    const int o = (int)(i % Opad);
+    const long r = i / Opad;
     const int t = (int)(r % T), ci = (int)(r / T);
-    wt[i] = (half_t)w[((long)o * T + t) * I + ci];
+    wt[i] = o < O ? (half_t)w[((long)o * T + t) * I + ci] : (half_t)0;
   }
 }
 
-SN_EXPORT int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, sn_stream_t stream) {
-  SN_REQUIRE(w_oti && wt_ito_f16 && O > 0 && T > 0 && I > 0, "sn_weight_transpose: bad arguments");
-  hipLaunchKernelGGL(weight_oti_to_ito_kernel, dim3(ew_blocks((long)O * T * I)), dim3(256), 0, sn_stream(stream), w_oti,
-                     (half_t *)wt_ito_f16, O, T, I);
+SN_EXPORT int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, int O_pad, sn_stream_t stream) {
+  SN_REQUIRE(w_oti && wt_ito_f16 && O > 0 && T > 0 && I > 0 && O_pad >= O, "sn_weight_transpose: bad arguments");
+  hipLaunchKernelGGL(weight_oti_to_ito_kernel, dim3(ew_blocks((long)O_pad * T * I)), dim3(256), 0, sn_stream(stream), w_oti,
+                     (half_t *)wt_ito_f16, O, T, I, O_pad);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

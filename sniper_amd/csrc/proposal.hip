@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float *__res
   const float aw = ax2 - ax1 + 1.0f, ah = ay2 - ay1 + 1.0f;
   const float cx = ax1 + 0.5f * (aw - 1.0f), cy = ay1 + 0.5f * (ah - 1.0f);
   const float pcx = dx * aw + cx, pcy = dy * ah + cy;
-  const float pw = expf(dw) * aw, ph = expf(dh) * ah;
+  // exp evaluated in double and rounded once: reproducible across libms (bit-exact RoIs vs the oracle)
+  const float pw = (float)exp((double)dw) * aw, ph = (float)exp((double)dh) * ah;
   float x1 = pcx - 0.5f * (pw - 1.0f), y1 = pcy - 0.5f * (ph - 1.0f);
   float x2 = pcx + 0.5f * (pw - 1.0f), y2 = pcy + 0.5f * (ph - 1.0f);
   const float im_h = im_info[3 * b], im_w = im_info[3 * b + 1], im_s = im_info[3 * b + 2];

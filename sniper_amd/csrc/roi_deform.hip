@@ -224,7 +224,8 @@ __device__ __forceinline__ DeformSample deform_sample(float py, float px, int H,
   return s;
 }
 
-__global__ __launch_bounds__(256) void deform_im2col_kernel(const half_t *__restrict__ data, const float *__restrict__ offset,
+template <typename TO>
+__global__ __launch_bounds__(256) void deform_im2col_kernel(const half_t *__restrict__ data, const TO *__restrict__ offset,
                                                             half_t *__restrict__ col, int N, int H, int W, int C, int Ho, int Wo,
                                                             int KH, int KW, int stride, int pad, int dil, int DG, int off_ps) {
   const int cpr = C >> 3, T = KH * KW, cg = C / DG;
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const half_t *__rest
     const long t2 = m / Wo;
     const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
     const int g = ch / cg, kh = tap / KW, kw = tap - kh * KW;
-    const float *op = offset + m * off_ps + g * 2 * T + 2 * tap;
-    const float py = (float)(oy * stride - pad + kh * dil) + op[0], px = (float)(ox * stride - pad + kw * dil) + op[1];
+    const TO *op = offset + m * off_ps + g * 2 * T + 2 * tap;
+    const float py = (float)(oy * stride - pad + kh * dil) + (float)op[0], px = (float)(ox * stride - pad + kw * dil) + (float)op[1];
     const DeformSample s = deform_sample(py, px, H, W);
     half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
     if (s.ok) {
@@ -261,9 +262,10 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const half_t *__rest
 //   d_data   (N,H,W,C) fp32, atomic scatter (caller zeroes)
 //   d_offset (N,Ho,Wo,2*T*DG) fp32: sum over the group's channels of dcol * d(sample)/d(offset);
 //            each (m, tap, group) is owned by `cg/8` consecutive lanes, reduced with shuffles.
+template <typename TO>
 __global__ __launch_bounds__(256) void deform_col2im_kernel(const half_t *__restrict__ dcol, const half_t *__restrict__ data,
-                                                            const float *__restrict__ offset, float *__restrict__ d_data,
-                                                            float *__restrict__ d_offset, int N, int H, int W, int C, int Ho, int Wo,
+                                                            const TO *__restrict__ offset, float *__restrict__ d_data,
+                                                            TO *__restrict__ d_offset, int N, int H, int W, int C, int Ho, int Wo,
                                                             int KH, int KW, int stride, int pad, int dil, int DG, int off_ps) {
   const int cpr = C >> 3, T = KH * KW, cg = C / DG, lpg = cg >> 3;  // lanes per group (power of two <= 64)
   const long total = (long)N * Ho * Wo * T * cpr;
@@ -278,8 +280,8 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const half_t *__rest
   const long t2 = m / Wo;
   const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
   const int g = ch / cg, kh = tap / KW, kw = tap - kh * KW;
-  const float *op = offset + m * off_ps + g * 2 * T + 2 * tap;
-  const float py = (float)(oy * stride - pad + kh * dil) + op[0], px = (float)(ox * stride - pad + kw * dil) + op[1];
+  const TO *op = offset + m * off_ps + g * 2 * T + 2 * tap;
+  const float py = (float)(oy * stride - pad + kh * dil) + (float)op[0], px = (float)(ox * stride - pad + kw * dil) + (float)op[1];
   const DeformSample s = deform_sample(py, px, H, W);
   float gy = 0.f, gx = 0.f;
   if (active && s.ok) {
@@ -307,37 +309,48 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const half_t *__rest
     gx += __shfl_xor(gx, off, 64);
   }
   if (active && ((ch >> 3) & (lpg - 1)) == 0) {
-    float *dp = d_offset + m * off_ps + g * 2 * T + 2 * tap;
-    dp[0] = gy;
-    dp[1] = gx;
+    TO *dp = d_offset + m * off_ps + g * 2 * T + 2 * tap;
+    dp[0] = (TO)gy;
+    dp[1] = (TO)gx;
   }
 }
 
-SN_EXPORT int sn_deform_im2col(const void *data, const float *offset, void *col, int N, int H, int W, int C, int KH, int KW,
-                               int stride, int pad, int dil, int deformable_groups, int offset_pix_stride, sn_stream_t stream) {
+SN_EXPORT int sn_deform_im2col(const void *data, const void *offset, void *col, int N, int H, int W, int C, int KH, int KW,
+                               int stride, int pad, int dil, int deformable_groups, int offset_pix_stride, int offset_dtype,
+                               sn_stream_t stream) {
   SN_REQUIRE(data && offset && col && C % 8 == 0 && deformable_groups > 0 && (C / deformable_groups) % 8 == 0,
              "sn_deform_im2col: bad arguments");
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   const long total = (long)N * Ho * Wo * KH * KW * (C / 8);
-  hipLaunchKernelGGL(deform_im2col_kernel, dim3((unsigned)blocks_for(total)), dim3(256), 0, sn_stream(stream),
-                     (const half_t *)data, offset, (half_t *)col, N, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups,
-                     offset_pix_stride);
+  if (offset_dtype == 0)
+    hipLaunchKernelGGL((deform_im2col_kernel<half_t>), dim3((unsigned)blocks_for(total)), dim3(256), 0, sn_stream(stream),
+                       (const half_t *)data, (const half_t *)offset, (half_t *)col, N, H, W, C, Ho, Wo, KH, KW, stride, pad, dil,
+                       deformable_groups, offset_pix_stride);
+  else
+    hipLaunchKernelGGL((deform_im2col_kernel<float>), dim3((unsigned)blocks_for(total)), dim3(256), 0, sn_stream(stream),
+                       (const half_t *)data, (const float *)offset, (half_t *)col, N, H, W, C, Ho, Wo, KH, KW, stride, pad, dil,
+                       deformable_groups, offset_pix_stride);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
 
-SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const float *offset, float *d_data, float *d_offset, int N,
+SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *offset, float *d_data, void *d_offset, int N,
                                int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
-                               int offset_pix_stride, sn_stream_t stream) {
+                               int offset_pix_stride, int offset_dtype, sn_stream_t stream) {
   SN_REQUIRE(dcol && data && offset && d_data && d_offset && C % 8 == 0 && deformable_groups > 0, "sn_deform_col2im: bad arguments");
   const int lpg = C / deformable_groups / 8;
   SN_REQUIRE(lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0 && (C / deformable_groups) % 8 == 0,
              "sn_deform_col2im: channels per deformable group / 8 must be a power of two <= 64");
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   const long total = (long)N * Ho * Wo * KH * KW * (C / 8);
-  hipLaunchKernelGGL(deform_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sn_stream(stream),
-                     (const half_t *)dcol, (const half_t *)data, offset, d_data, d_offset, N, H, W, C, Ho, Wo, KH, KW, stride, pad,
-                     dil, deformable_groups, offset_pix_stride);
+  if (offset_dtype == 0)
+    hipLaunchKernelGGL((deform_col2im_kernel<half_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sn_stream(stream),
+                       (const half_t *)dcol, (const half_t *)data, (const half_t *)offset, d_data, (half_t *)d_offset, N, H, W, C, Ho,
+                       Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride);
+  else
+    hipLaunchKernelGGL((deform_col2im_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sn_stream(stream),
+                       (const half_t *)dcol, (const half_t *)data, (const float *)offset, d_data, (float *)d_offset, N, H, W, C, Ho,
+                       Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -1,0 +1,424 @@
+"""Graph executor: lowers a captured symbol graph (sniper_amd.mx.symbol) onto the HIP kernels of
+libsniper_hip.so and runs forward / backward / SGD on one GPU.
+
+This is the replacement for what ``mx.mod.Module`` delegates to in the un-vendored SNIPER-mxnet
+runtime (component 10): executor, operator kernels, optimizer.  Design, MI355X first:
+
+* activations are channels-last fp16 ("act", physical (N,H,W,C)), because the MFMA implicit-GEMM
+  wants the contraction dimension contiguous; loss-side tensors are fp32 in the reference's NCHW
+  order ("f32").  Conversions are inserted only where the graph crosses between the two worlds
+  (RPN heads -> Reshape/softmax/proposal ops, FC logits -> losses).
+* parameters live in flat fp32 arenas (master weights, gradients, momentum) in the kernels' layout
+  [Cout][KH*KW][Cin]; one memset zeroes all gradients, one RCCL all-reduce sums them, a handful of
+  fused SGD launches update them and emit the fp16 compute copies.
+* torch provides device memory, streams and (elsewhere) torch.distributed; every byte of compute
+  goes through the C ABI (sniper_amd.hip.call).  No CPU fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import hip
+from ..mx.symbol import _bool, _tup
+from .shapes import infer_shapes
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class Val(object):
+    """One tensor of the graph.  fmt 'act': fp16 channels-last, t has shape (N,H,W,C) (2-D logical
+    tensors use H=W=1); fmt 'f32': fp32, reference order, t has the logical shape."""
+    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers')
+
+    def __init__(self, name, shape, fmt):
+        self.name, self.shape, self.fmt = name, tuple(shape), fmt
+        self.t = None
+        self.needs_grad = False
+        self.grad = None
+        self.alt = None      # cached other-format copy (forward)
+        self.stem = None     # (src f32 NCHW Val, scale, shift) for a BN-folded image input
+        self.consumers = 0
+
+    def nhwc(self):
+        s = self.shape
+        return (s[0], s[2], s[3], s[1]) if len(s) == 4 else (s[0], 1, 1, int(np.prod(s[1:])))
+
+
+class Param(object):
+    __slots__ = ('name', 'ref_shape', 'kind', 'int_shape', 'trainable', 'lr_mult', 'wd_mult', 'master', 'grad', 'mom',
+                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in')
+
+    def __init__(self, name, ref_shape):
+        self.name, self.ref_shape = name, tuple(ref_shape)
+        self.kind, self.int_shape = 'vec', tuple(ref_shape)
+        self.trainable, self.lr_mult, self.wd_mult = True, 1.0, 1.0
+        self.master = self.grad = self.mom = self.w16 = self.wT16 = None
+        self.need_wT = False
+        self.fc_in = None
+        self.numel = int(np.prod(ref_shape))
+
+    # reference layout <-> kernel layout
+    def to_internal(self, a):
+        a = np.asarray(a, np.float32).reshape(self.ref_shape)
+        if self.kind == 'conv':
+            return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+        if self.kind == 'fc' and self.fc_in is not None:
+            c, h, w = self.fc_in
+            return np.ascontiguousarray(a.reshape(a.shape[0], c, h, w).transpose(0, 2, 3, 1))
+        return a
+
+    def to_reference(self, a):
+        a = np.asarray(a, np.float32)
+        if self.kind == 'conv':
+            o, i, kh, kw = self.ref_shape
+            return np.ascontiguousarray(a.reshape(o, kh, kw, i).transpose(0, 3, 1, 2))
+        if self.kind == 'fc' and self.fc_in is not None:
+            c, h, w = self.fc_in
+            return np.ascontiguousarray(a.reshape(-1, h, w, c).transpose(0, 3, 1, 2)).reshape(self.ref_shape)
+        return a.reshape(self.ref_shape)
+
+
+_F32_CONSUMERS = {'Reshape', 'SoftmaxOutput', 'SoftmaxActivation', 'smooth_l1', 'MakeLoss', 'MultiProposal',
+                  'MultiProposalTarget', 'BlockGrad', '_mul_scalar', '_plus_scalar', '_minus_scalar', 'Flatten', 'Custom'}
+_PRODUCES_ACT = {'Convolution', 'FullyConnected', 'BatchNorm', 'Activation', 'Pooling', 'Concat', 'DeformableConvolution',
+                 'DeformablePSROIPooling', 'clip'}
+
+
+class Executor(object):
+    def __init__(self, symbol, input_shapes, for_training=True, fixed_param_names=(), device=None, data_names=None,
+                 label_names=None, loss_scale_hint=None):
+        self.sym = symbol
+        self.device = device or hip.require_gpu()
+        self.for_training = for_training
+        self.nodes = symbol._topo()
+        self.shapes = infer_shapes(symbol, input_shapes)
+        self.input_names = list(input_shapes.keys())
+        self.fixed = set(fixed_param_names or ())
+        self.arg_names = symbol.list_arguments()
+        self.aux_names = symbol.list_auxiliary_states()
+        self.param_names = [n for n in self.arg_names if n not in input_shapes]
+        self.vals = {}        # (id(node), idx) -> Val
+        self.params = {}      # name -> Param
+        self.aux = {}         # name -> torch fp32 vector
+        self.steps = []       # lowered ops, forward order
+        self.ws = hip.Workspace()
+        self._const = {}
+        self._bn_cache_valid = False
+        self.num_update = 0
+        self._lower()
+        self._alloc_params()
+
+    # ------------------------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        return torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(tuple(int(s) for s in shape), dtype=dtype, device=self.device)
+
+    def const(self, key, fn):
+        if key not in self._const:
+            self._const[key] = fn()
+        return self._const[key]
+
+    def val_of(self, node, idx=0):
+        return self.vals[(id(node), idx)]
+
+    def in_vals(self, node):
+        return [self.vals[(id(n), i)] for n, i in node.inputs]
+
+    # ---- format conversion (forward) ----------------------------------------------------------
+    def as_f32(self, v):
+        """fp32 reference-order view of a Val (converted copy cached per forward)."""
+        if v.fmt == 'f32':
+            return v.t
+        if v.alt is None:
+            n, h, w, c = v.nhwc()
+            out = self.empty(v.shape, F32)
+            if h * w == 1:
+                hip.call('sn_copy2d', v.t, out, n, c, c, c, 0, 1, hip.stream())
+            else:
+                hip.call('sn_transpose_batched', v.t, out, n, h * w, c, h * w * c, c * h * w, c, h * w, 0, 1, hip.stream())
+            v.alt = out
+        return v.alt
+
+    def as_act(self, v):
+        if v.fmt == 'act':
+            return v.t
+        if v.alt is None:
+            n, h, w, c = v.nhwc()
+            out = self.empty((n, h, w, c), F16)
+            if h * w == 1:
+                hip.call('sn_copy2d', v.t, out, n, c, c, c, 1, 0, hip.stream())
+            else:
+                hip.call('sn_transpose_batched', v.t, out, n, c, h * w, c * h * w, h * w * c, h * w, c, 1, 0, hip.stream())
+            v.alt = out
+        return v.alt
+
+    # ---- gradient plumbing -------------------------------------------------------------------
+    def grad_slot(self, v):
+        """-> (tensor in v's own format, accumulate?).  First writer overwrites, later ones add."""
+        if v.grad is None:
+            v.grad = self.empty(v.t.shape, v.t.dtype)
+            return v.grad, False
+        return v.grad, True
+
+    def add_grad(self, v, g, g_fmt):
+        """Accumulate gradient tensor g (format g_fmt: 'act' NHWC fp16 or 'f32' reference order) into v."""
+        if not v.needs_grad:
+            return
+        n, h, w, c = v.nhwc()
+        if g_fmt != v.fmt:
+            if v.fmt == 'act':   # f32 NCHW -> act
+                conv = self.empty((n, h, w, c), F16)
+                if h * w == 1:
+                    hip.call('sn_copy2d', g, conv, n, c, c, c, 1, 0, hip.stream())
+                else:
+                    hip.call('sn_transpose_batched', g, conv, n, c, h * w, c * h * w, h * w * c, h * w, c, 1, 0, hip.stream())
+            else:
+                conv = self.empty(v.shape, F32)
+                if h * w == 1:
+                    hip.call('sn_copy2d', g, conv, n, c, c, c, 0, 1, hip.stream())
+                else:
+                    hip.call('sn_transpose_batched', g, conv, n, h * w, c, h * w * c, c * h * w, c, h * w, 0, 1, hip.stream())
+            g = conv
+        if v.grad is None:
+            v.grad = g
+            return
+        if v.fmt == 'act':
+            out = self.empty(v.grad.shape, F16)
+            hip.call('sn_ew_f16', v.grad, g, None, out, n * h * w, c, c, c, c, c, 1, hip.stream())
+        else:
+            out = self.empty(v.grad.shape, F32)
+            hip.call('sn_ew_f32', v.grad, g, out, v.grad.numel(), 1, 0.0, hip.stream())
+        v.grad = out
+
+    # ------------------------------------------------------------------------------------------
+    # lowering
+    # ------------------------------------------------------------------------------------------
+    def _lower(self):
+        from . import ops
+        # consumer census (for BN+ReLU fusion and f32/act decisions)
+        cons = {}
+        for node in self.nodes:
+            for n, i in node.inputs:
+                cons.setdefault((id(n), i), []).append(node)
+        heads = set((id(n), i) for n, i in self.sym._heads)
+        self.consumers = cons
+        var_is_param = set(self.param_names) | set(self.aux_names)
+        # static format analysis: 'act' (fp16 channels-last) vs 'f32' (reference order)
+        binary = ('_plus', '_minus', '_mul', 'elemwise_add')
+        fmt = {}
+        for node in self.nodes:
+            if node.op is None:
+                fmt[(id(node), 0)] = 'f32'
+            elif node.op in _PRODUCES_ACT:
+                fmt[(id(node), 0)] = 'act'
+            elif node.op == 'Cast':
+                fmt[(id(node), 0)] = fmt[(id(node.inputs[0][0]), node.inputs[0][1])]
+            elif node.op in binary:
+                both = all(fmt[(id(n), i)] == 'act' for n, i in node.inputs)
+                fmt[(id(node), 0)] = 'act' if both and node.op in ('_plus', 'elemwise_add') else 'f32'
+            else:
+                for i in range(node.num_outputs):
+                    fmt[(id(node), i)] = 'f32'
+        for node in self.nodes:
+            if node.op is None:
+                if node.name in var_is_param:
+                    continue
+                shp = self.shapes[('var', node.name)]
+                v = Val(node.name, shp, 'f32')
+                self.vals[(id(node), 0)] = v
+                continue
+            cls = ops.REGISTRY.get(node.op)
+            if cls is None:
+                raise NotImplementedError('no HIP lowering for operator %s (%s)' % (node.op, node.name))
+            wants_f32 = [False] * node.num_outputs
+            for i in range(node.num_outputs):
+                cs = cons.get((id(node), i), [])
+                if (id(node), i) in heads or any(c.op in _F32_CONSUMERS for c in cs):
+                    wants_f32[i] = True
+                for c in cs:   # element-wise ops follow their other operand; rois/trans slots are f32
+                    if c.op in binary and fmt[(id(c), 0)] == 'f32':
+                        wants_f32[i] = True
+                    if c.op == 'DeformablePSROIPooling':
+                        slots = c.extra.get('slots') or []
+                        for s, (n2, i2) in zip(slots, c.inputs):
+                            if n2 is node and i2 == i and s in ('rois', 'trans'):
+                                wants_f32[i] = True
+            step = cls(self, node, wants_f32)
+            self.steps.append(step)
+        # needs_grad propagation is done by the steps at construction (they see their inputs)
+
+    def register_param(self, name, kind='vec', fc_in=None, need_wT=False):
+        shp = self.shapes[('var', name)]
+        p = self.params.get(name)
+        if p is None:
+            p = Param(name, shp)
+            self.params[name] = p
+        p.kind = kind
+        p.fc_in = fc_in
+        p.need_wT = p.need_wT or need_wT
+        if kind == 'conv':
+            o, i, kh, kw = shp
+            p.int_shape = (o, kh * kw, i)
+        elif kind == 'fc':
+            o = shp[0]
+            if fc_in is not None:
+                c, h, w = fc_in
+                p.int_shape = (o, h * w, c)
+            else:
+                p.int_shape = (o, 1, int(np.prod(shp[1:])))
+        else:
+            p.int_shape = tuple(shp)
+        p.trainable = self.for_training and not any(f == name for f in self.fixed)
+        return p
+
+    def register_aux(self, name):
+        if name not in self.aux:
+            self.aux[name] = self.zeros(self.shapes[('var', name)], F32)
+        return self.aux[name]
+
+    def _alloc_params(self):
+        ps = list(self.params.values())
+        # group so that every (lr_mult, wd_mult) class is one contiguous range -> one SGD launch each
+        for p in ps:
+            node = self._var_node(p.name)
+            p.lr_mult = float(node.extra.get('lr_mult', 1.0)) if node is not None else 1.0
+            wd_default = 1.0 if (p.name.endswith('_weight') or p.name.endswith('_gamma')) else 0.0  # mx optimizer rule
+            p.wd_mult = float(node.extra.get('wd_mult', wd_default)) if node is not None else wd_default
+        train = sorted([p for p in ps if p.trainable], key=lambda q: (q.lr_mult, q.wd_mult))
+        total = sum(_pad8(p.numel) for p in train)
+        self.arena_master = self.zeros((max(total, 8),), F32)
+        self.arena_grad = self.zeros((max(total, 8),), F32)
+        self.arena_mom = self.zeros((max(total, 8),), F32)
+        self.arena_w16 = self.zeros((max(total, 8),), F16)
+        off = 0
+        self.groups = []
+        for p in train:
+            n = p.numel
+            p.offset = off
+            p.master = self.arena_master[off:off + n].view(p.int_shape)
+            p.grad = self.arena_grad[off:off + n].view(p.int_shape)
+            p.mom = self.arena_mom[off:off + n].view(p.int_shape)
+            p.w16 = self.arena_w16[off:off + n].view(p.int_shape)
+            key = (p.lr_mult, p.wd_mult)
+            if self.groups and self.groups[-1][0] == key:
+                self.groups[-1][2] = off + _pad8(n)
+            else:
+                self.groups.append([key, off, off + _pad8(n)])
+            off += _pad8(n)
+        for p in ps:
+            if not p.trainable:
+                p.master = self.zeros(p.int_shape, F32)
+                p.w16 = self.zeros(p.int_shape, F16)
+            if p.need_wT and p.kind in ('conv', 'fc'):
+                o, t, i = p.int_shape
+                p.wT16 = self.zeros((i, t, _pad8(o)), F16)
+        self.n_trainable = total
+
+    def _var_node(self, name):
+        for n in self.nodes:
+            if n.op is None and n.name == name:
+                return n
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # parameters in / out (reference layout on the host side)
+    # ------------------------------------------------------------------------------------------
+    def set_params(self, arg_params, aux_params=None, allow_missing=False):
+        for name, p in self.params.items():
+            if name in arg_params:
+                a = arg_params[name]
+                a = a.asnumpy() if hasattr(a, 'asnumpy') else np.asarray(a)
+                if tuple(a.shape) != p.ref_shape:
+                    raise ValueError('parameter %s: shape %s, expected %s' % (name, a.shape, p.ref_shape))
+                t = torch.from_numpy(p.to_internal(a)).to(self.device).view(p.int_shape)
+                p.master.copy_(t)
+            elif not allow_missing:
+                raise KeyError('missing parameter %s' % name)
+        for name, t in self.aux.items():
+            if aux_params and name in aux_params:
+                a = aux_params[name]
+                a = a.asnumpy() if hasattr(a, 'asnumpy') else np.asarray(a)
+                t.copy_(torch.from_numpy(np.asarray(a, np.float32)).to(self.device))
+            elif not allow_missing:
+                raise KeyError('missing auxiliary state %s' % name)
+        self.refresh_compute_copies()
+
+    def get_params(self):
+        arg = {name: p.to_reference(p.master.detach().cpu().numpy()) for name, p in self.params.items()}
+        aux = {name: t.detach().cpu().numpy().copy() for name, t in self.aux.items()}
+        return arg, aux
+
+    def refresh_compute_copies(self, only_trainable=False):
+        """fp16 copies (and transposed dgrad copies) of the fp32 masters."""
+        for p in self.params.values():
+            if only_trainable and not p.trainable:
+                continue
+            if not (only_trainable and p.trainable):  # trainable w16 is written by the SGD kernel
+                hip.call('sn_copy2d', p.master, p.w16, 1, p.numel, p.numel, p.numel, 1, 0, hip.stream())
+            if p.wT16 is not None:
+                o, t, i = p.int_shape
+                hip.call('sn_weight_transpose', p.master, p.wT16, o, t, i, _pad8(o), hip.stream())
+        self._bn_cache_valid = False
+        for s in self.steps:
+            s.params_changed()
+
+    # ------------------------------------------------------------------------------------------
+    # run
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inputs, is_train=None):
+        is_train = self.for_training if is_train is None else is_train
+        self.is_train = is_train
+        for node in self.nodes:
+            if node.op is None and (id(node), 0) in self.vals:
+                v = self.vals[(id(node), 0)]
+                src = inputs[node.name]
+                if hasattr(src, 'asnumpy') and not isinstance(getattr(src, '_data', None), torch.Tensor):
+                    src = src.asnumpy()
+                if isinstance(src, np.ndarray):
+                    src = torch.from_numpy(np.ascontiguousarray(src, np.float32))
+                elif hasattr(src, '_data'):
+                    src = src._data
+                if tuple(src.shape) != v.shape:
+                    raise ValueError('input %s has shape %s, bound shape %s' % (node.name, tuple(src.shape), v.shape))
+                v.t = src.to(self.device, F32, non_blocking=True).contiguous()
+                v.alt = None
+        for v in self.vals.values():
+            v.alt = None
+            v.grad = None
+        for s in self.steps:
+            s.forward()
+        self.outputs = [self.as_f32(self.vals[(id(n), i)]) for n, i in self.sym._heads]
+        return self.outputs
+
+    def zero_grad(self):
+        self.arena_grad.zero_()
+
+    def backward(self):
+        self.zero_grad()
+        for v in self.vals.values():
+            v.grad = None
+        for s in reversed(self.steps):
+            s.backward()
+        for v in self.vals.values():
+            v.grad = None
+
+    def update(self, lr, wd, momentum, rescale_grad=1.0):
+        """SGD with momentum on the fp32 masters (mx 'sgd', multi_precision; utils.py:26-33)."""
+        for (lr_mult, wd_mult), a, b in self.groups:
+            hip.call('sn_sgd_mom_update', self.arena_master[a:], self.arena_grad[a:], self.arena_mom[a:], self.arena_w16[a:],
+                     b - a, float(lr * lr_mult), float(wd * wd_mult), float(momentum), float(rescale_grad), hip.stream())
+        self.num_update += 1
+        self.refresh_compute_copies(only_trainable=True)
+
+    def grad_arena(self):
+        """Flat fp32 gradient buffer (what the data-parallel all-reduce sums)."""
+        return self.arena_grad

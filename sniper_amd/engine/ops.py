@@ -1,0 +1,841 @@
+"""Operator lowerings: one Step class per mx.sym operator the SNIPER graphs use.  Each step
+allocates its outputs at construction (static shapes), launches HIP kernels in forward(), and in
+backward() turns the gradients of its outputs into gradients of its inputs / parameters.
+
+Semantics of the fork-resident operators are documented in DESIGN.md and restated in oracle/nn.py;
+call sites: symbols/faster/resnet_mx_101_e2e.py, mobilenetv2_e2e.py.
+"""
+import numpy as np
+import torch
+
+from .. import hip
+from ..mx.symbol import _bool, _tup
+from .executor import F16, F32, Val, _pad8
+from .shapes import slot_inputs
+
+REGISTRY = {}
+
+
+def register(*names):
+    def deco(cls):
+        for n in names:
+            REGISTRY[n] = cls
+        return cls
+    return deco
+
+
+class Step(object):
+    def __init__(self, ex, node, wants_f32):
+        self.ex, self.node, self.wants_f32 = ex, node, wants_f32
+        self.a = node.attrs
+        self.ins = []
+        for n, i in node.inputs:
+            self.ins.append(ex.vals.get((id(n), i)))   # None for parameters / aux
+        self.slots = slot_inputs(node)
+        self.setup()
+
+    # -- helpers
+    def out_shape(self, i=0):
+        return self.ex.shapes[(id(self.node), i)]
+
+    def new_out(self, fmt, i=0, alloc=True):
+        ex = self.ex
+        v = Val('%s:%d' % (self.node.name, i), self.out_shape(i), fmt)
+        if alloc:
+            v.t = ex.empty(v.nhwc(), F16) if fmt == 'act' else ex.empty(v.shape, F32)
+        ex.vals[(id(self.node), i)] = v
+        return v
+
+    def pname(self, slot):
+        n, _ = self.slots[slot]
+        return n.name
+
+    def data_in(self, slot='data'):
+        n, i = self.slots[slot]
+        return self.ex.vals[(id(n), i)]
+
+    def setup(self):
+        raise NotImplementedError
+
+    def forward(self):
+        raise NotImplementedError
+
+    def backward(self):
+        pass
+
+    def params_changed(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm (+ fused ReLU when the only consumer is Activation(relu))
+# ---------------------------------------------------------------------------------------------
+@register('BatchNorm')
+class BatchNormStep(Step):
+    def setup(self):
+        ex, a = self.ex, self.a
+        self.x = self.data_in()
+        C = self.x.shape[1]
+        self.C = C
+        self.eps = float(a.get('eps', 1e-3))
+        self.momentum = float(a.get('momentum', 0.9))
+        self.fix_gamma = _bool(a.get('fix_gamma', True))
+        self.global_stats = _bool(a.get('use_global_stats', False))
+        self.gamma = ex.register_param(self.pname('gamma'))
+        self.beta = ex.register_param(self.pname('beta'))
+        if self.fix_gamma:
+            self.gamma.trainable = False
+        if self.global_stats:
+            # moving-statistics BN layers carry no gradient here: in every SNIPER config they are frozen
+            # (network.FIXED_PARAMS) -- bn_data's beta, the one exception by name, is frozen too
+            self.gamma.trainable = self.beta.trainable = False
+        self.mean = ex.register_aux(self.pname('moving_mean'))
+        self.var = ex.register_aux(self.pname('moving_var'))
+        ex.aux[self.pname('moving_var')].fill_(1.0)
+        self.scale, self.shift = ex.empty((C,), F32), ex.empty((C,), F32)
+        self.save_mean, self.save_invstd = ex.empty((C,), F32), ex.empty((C,), F32)
+        self.sum64, self.sq64 = ex.zeros((C,), torch.float64), ex.zeros((C,), torch.float64)
+        self.bws = ex.zeros((2 * C,), torch.float64)
+        # image input (C <= 4): folded into the stem convolution's input packing
+        self.is_stem = self.x.fmt == 'f32' and len(self.x.shape) == 4 and C <= 4
+        cons = ex.consumers.get((id(self.node), 0), [])
+        self.relu = (not self.is_stem and len(cons) == 1 and cons[0].op == 'Activation' and
+                     cons[0].attrs.get('act_type') == 'relu')
+        if self.is_stem:
+            self.y = self.new_out('f32', alloc=False)
+            self.y.stem = (self.x, self.scale, self.shift)
+        else:
+            self.y = self.new_out('act')
+        self.y.needs_grad = ex.for_training and (self.x.needs_grad or self.gamma.trainable or self.beta.trainable) \
+            and not self.is_stem
+        self._global_ready = False
+
+    def params_changed(self):
+        self._global_ready = False
+
+    def _use_batch_stats(self):
+        return self.ex.is_train and not self.global_stats
+
+    def forward(self):
+        ex = self.ex
+        g = None if self.fix_gamma else self.gamma.master
+        if not self._use_batch_stats():
+            if not self._global_ready:
+                hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
+                         self.shift, hip.stream())
+                self._global_ready = True
+            if self.is_stem:
+                return
+        if self.is_stem:
+            raise NotImplementedError('batch-statistics BatchNorm on the raw image input')
+        x = ex.as_act(self.x)
+        n, h, w, c = self.x.nhwc()
+        M = n * h * w
+        if self._use_batch_stats():
+            hip.call('sn_bn_stats', x, M, c, c, self.sum64, self.sq64, hip.stream())
+            hip.call('sn_bn_finalize', self.sum64, self.sq64, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
+                     self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
+        hip.call('sn_bn_apply', x, self.y.t, M, c, c, c, self.scale, self.shift, 1 if self.relu else 0, hip.stream())
+
+    def backward(self):
+        ex = self.ex
+        if self.y.grad is None or not self.y.needs_grad:
+            return
+        if not self._use_batch_stats():
+            if self.x.needs_grad or self.gamma.trainable or self.beta.trainable:
+                raise NotImplementedError('gradient through a use_global_stats BatchNorm (%s)' % self.node.name)
+            return
+        n, h, w, c = self.x.nhwc()
+        M = n * h * w
+        x = ex.as_act(self.x)
+        dx, acc = (None, False)
+        if self.x.needs_grad:
+            dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty(x.shape, F16), False)
+        hip.call('sn_bn_backward', self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale, self.shift,
+                 self.save_mean, self.save_invstd, 1 if self.relu else 0, self.bws,
+                 self.gamma.grad if self.gamma.trainable else None, self.beta.grad if self.beta.trainable else None,
+                 hip.stream())
+        if self.x.needs_grad and self.x.fmt != 'act':
+            ex.add_grad(self.x, dx, 'act')
+        self.y.grad = None
+
+
+@register('Activation')
+class ActivationStep(Step):
+    def setup(self):
+        ex = self.ex
+        self.x = self.ins[0]
+        if self.a.get('act_type') != 'relu':
+            raise NotImplementedError('Activation %s' % self.a.get('act_type'))
+        prod = self.node.inputs[0][0]
+        self.fused = (prod.op == 'BatchNorm' and len(ex.consumers.get((id(prod), 0), [])) == 1 and self.x.fmt == 'act')
+        if self.fused:
+            ex.vals[(id(self.node), 0)] = self.x   # alias: the BN kernel already applied the ReLU
+            self.y = self.x
+        else:
+            self.y = self.new_out('act')
+            self.y.needs_grad = self.x.needs_grad
+
+    def forward(self):
+        if self.fused:
+            return
+        x = self.ex.as_act(self.x)
+        n, h, w, c = self.x.nhwc()
+        hip.call('sn_ew_f16', x, None, None, self.y.t, n * h * w, c, c, c, c, c, 0, hip.stream())
+
+    def backward(self):
+        if self.fused or self.y.grad is None or not self.x.needs_grad:
+            return
+        n, h, w, c = self.x.nhwc()
+        if self.x.fmt == 'act':
+            dx, acc = self.ex.grad_slot(self.x)
+            hip.call('sn_ew_f16', self.y.grad, dx if acc else None, self.y.t, dx, n * h * w, c, c, c, c, c, 2, hip.stream())
+        else:
+            tmp = self.ex.empty(self.y.t.shape, F16)
+            hip.call('sn_ew_f16', self.y.grad, None, self.y.t, tmp, n * h * w, c, c, c, c, c, 2, hip.stream())
+            self.ex.add_grad(self.x, tmp, 'act')
+        self.y.grad = None
+
+
+# ---------------------------------------------------------------------------------------------
+# Convolution / FullyConnected on the implicit-GEMM MFMA kernels
+# ---------------------------------------------------------------------------------------------
+class _GemmLike(Step):
+    """Shared by Convolution and FullyConnected.  Sub-classes fill geometry in setup_geom()."""
+
+    def setup(self):
+        ex = self.ex
+        self.x = self.data_in()
+        self.setup_geom()
+        self.w = ex.register_param(self.pname('weight'), self.wkind, self.fc_in, need_wT=False)
+        self.b = ex.register_param(self.pname('bias')) if 'bias' in self.slots else None
+        self.out_f32 = self.wants_f32[0]
+        self.y = self.new_out('f32' if self.out_f32 else 'act')
+        wt = ex.for_training and (self.pname('weight') not in ex.fixed)
+        self.y.needs_grad = ex.for_training and (self.x.needs_grad or wt)
+        if self.x.needs_grad and ex.for_training:
+            self.w.need_wT = True
+        self.tmp_nhwc32 = None
+        if self.out_f32 and self.Ho * self.Wo > 1:
+            self.tmp_nhwc32 = ex.empty((self.N, self.Ho, self.Wo, self.O), F32)
+
+    def forward(self):
+        ex = self.ex
+        x = self.x_tensor()
+        dst = self.tmp_nhwc32 if self.tmp_nhwc32 is not None else self.y.t
+        bias = self.b.master if self.b is not None else None
+        self.launch_fwd(x, dst, bias)
+        if self.tmp_nhwc32 is not None:
+            hw = self.Ho * self.Wo
+            hip.call('sn_transpose_batched', dst, self.y.t, self.N, hw, self.O, hw * self.O, self.O * hw, self.O, hw, 1, 1,
+                     hip.stream())
+
+    def dy_act(self):
+        """incoming gradient as channels-last fp16 with an 8-aligned channel pitch -> (tensor, pitch)"""
+        ex = self.ex
+        g = self.y.grad
+        Op = _pad8(self.O)
+        hw = self.Ho * self.Wo
+        if self.y.fmt == 'act' and Op == self.O:
+            return g, Op
+        dy = ex.zeros((self.N, self.Ho, self.Wo, Op), F16) if Op != self.O else ex.empty((self.N, self.Ho, self.Wo, Op), F16)
+        if self.y.fmt == 'act':
+            hip.call('sn_copy2d', g, dy, self.N * hw, self.O, self.O, Op, 0, 0, hip.stream())
+        elif hw == 1:
+            hip.call('sn_copy2d', g, dy, self.N, self.O, self.O, Op, 1, 0, hip.stream())
+        else:
+            hip.call('sn_transpose_batched', g, dy, self.N, self.O, hw, self.O * hw, hw * Op, hw, Op, 1, 0, hip.stream())
+        return dy, Op
+
+    def backward(self):
+        ex = self.ex
+        if self.y.grad is None or not self.y.needs_grad:
+            return
+        dy, Op = self.dy_act()
+        x = self.x_tensor()
+        if self.w.trainable:
+            self.launch_wgrad(dy, Op, x)
+        if self.b is not None and self.b.trainable:
+            hip.call('sn_bias_grad', dy, self.b.grad, self.N * self.Ho * self.Wo, self.O, Op, 0, hip.stream())
+        if self.x.needs_grad:
+            if self.x.fmt == 'act':
+                dx, acc = ex.grad_slot(self.x)
+                self.launch_dgrad(dy, Op, dx if acc else None, dx)
+            else:
+                dx = ex.empty(self.x_shape_nhwc(), F16)
+                self.launch_dgrad(dy, Op, None, dx)
+                ex.add_grad(self.x, dx, 'act')
+        self.y.grad = None
+
+
+@register('Convolution')
+class ConvolutionStep(_GemmLike):
+    def setup_geom(self):
+        a = self.a
+        self.k = _tup(a['kernel'])
+        self.s = _tup(a.get('stride', (1, 1)))
+        self.p = _tup(a.get('pad', (0, 0)))
+        self.d = _tup(a.get('dilate', (1, 1)))
+        if int(a.get('num_group', 1)) != 1:
+            raise NotImplementedError('grouped / depthwise convolution (%s): next row (MobileNetV2)' % self.node.name)
+        assert self.s[0] == self.s[1] and self.p[0] == self.p[1] and self.d[0] == self.d[1], 'square geometry only'
+        self.N, self.C, self.H, self.W = self.x.shape
+        _, self.O, self.Ho, self.Wo = self.out_shape()
+        self.wkind, self.fc_in = 'conv', None
+        self.is_stem = self.C <= 4
+        if self.is_stem:
+            ex = self.ex
+            kh, kw = self.k
+            self.KWP = (kw + 1) // 2 * 2
+            self.Hp = (self.Ho - 1) * self.s[0] + kh
+            self.Wp = ((self.Wo - 1) * self.s[1] + self.KWP + 1) // 2 * 2
+            self.xp = ex.empty((self.N, self.Hp, self.Wp, 4), F16)
+            self.w_stem = ex.zeros((self.O, kh, self.KWP * 4), F16)
+
+    def params_changed(self):
+        if self.is_stem:
+            o, t, i = self.w.int_shape
+            kh, kw = self.k
+            w = self.w.master.view(o, kh, kw, i)
+            buf = torch.zeros((o, kh, self.KWP, 4), dtype=F16, device=self.ex.device)
+            buf[:, :, :kw, :i] = w.half()
+            self.w_stem.copy_(buf.view(o, kh, self.KWP * 4))
+
+    def x_tensor(self):
+        return None if self.is_stem else self.ex.as_act(self.x)
+
+    def x_shape_nhwc(self):
+        return (self.N, self.H, self.W, self.C)
+
+    def launch_fwd(self, x, dst, bias):
+        ex = self.ex
+        if self.is_stem:
+            src, scale, shift = (self.x.stem if self.x.stem is not None else (self.x, None, None))
+            hip.call('sn_pack_stem_input', src.t, self.xp, self.N, self.C, self.H, self.W, self.Hp, self.Wp, self.p[0], self.p[1],
+                     scale, shift, hip.stream())
+            hip.call('sn_conv_stem_fwd', self.xp, self.w_stem, bias, dst, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O,
+                     self.O, self.k[0], self.KWP, self.s[0], 0, 1 if self.out_f32 else 0, hip.stream())
+            return
+        hip.call('sn_conv_fwd', x, self.w.w16, bias, None, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0,
+                 self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0, 1 if self.out_f32 else 0, hip.stream())
+
+    def launch_dgrad(self, dy, Op, acc, dx):
+        hip.call('sn_conv_dgrad', dy, self.w.wT16, acc, dx, self.N, self.H, self.W, self.C, self.C, Op, Op, self.C,
+                 self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0, hip.stream())
+
+    def launch_wgrad(self, dy, Op, x):
+        if self.is_stem:
+            raise NotImplementedError('weight gradient of the stem convolution (frozen in every SNIPER config)')
+        hip.call('sn_conv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, self.O, Op, self.k[0], self.k[1],
+                 self.s[0], self.p[0], self.d[0], hip.stream())
+
+
+@register('FullyConnected')
+class FullyConnectedStep(_GemmLike):
+    def setup_geom(self):
+        xs = self.x.shape
+        self.N = xs[0]
+        self.H = self.W = self.Ho = self.Wo = 1
+        self.C = int(np.prod(xs[1:]))
+        self.O = int(self.a['num_hidden'])
+        self.wkind = 'fc'
+        # a 4-D channels-last input is consumed in (h, w, c) order: the weight is permuted once instead
+        self.fc_in = (xs[1], xs[2], xs[3]) if len(xs) == 4 and xs[2] * xs[3] > 1 else None
+        self.k, self.s, self.p, self.d = (1, 1), (1, 1), (0, 0), (1, 1)
+        self.is_stem = False
+
+    def x_tensor(self):
+        return self.ex.as_act(self.x)
+
+    def x_shape_nhwc(self):
+        return self.x.nhwc()
+
+    def launch_fwd(self, x, dst, bias):
+        hip.call('sn_conv_fwd', x, self.w.w16, bias, None, dst, self.N, 1, 1, self.C, self.C, self.O, self.O, 0, 1, 1, 1, 0, 1, 0,
+                 1 if self.out_f32 else 0, hip.stream())
+
+    def launch_dgrad(self, dy, Op, acc, dx):
+        hip.call('sn_conv_dgrad', dy, self.w.wT16, acc, dx, self.N, 1, 1, self.C, self.C, Op, Op, self.C, 1, 1, 1, 0, 1, 0,
+                 hip.stream())
+
+    def launch_wgrad(self, dy, Op, x):
+        hip.call('sn_conv_wgrad', dy, x, self.w.grad, self.N, 1, 1, self.C, self.C, self.O, Op, 1, 1, 1, 0, 1, hip.stream())
+
+
+@register('DeformableConvolution')
+class DeformableConvolutionStep(Step):
+    """DCN v1: bilinear gather into a (M, T*C) column buffer + 1x1 GEMM (call site :124-128)."""
+
+    def setup(self):
+        ex, a = self.ex, self.a
+        self.x = self.data_in()
+        self.off = self.data_in('offset')
+        self.k, self.s = _tup(a['kernel']), _tup(a.get('stride', (1, 1)))
+        self.p, self.d = _tup(a.get('pad', (0, 0))), _tup(a.get('dilate', (1, 1)))
+        self.dg = int(a.get('num_deformable_group', 1))
+        self.N, self.C, self.H, self.W = self.x.shape
+        _, self.O, self.Ho, self.Wo = self.out_shape()
+        self.T = self.k[0] * self.k[1]
+        self.w = ex.register_param(self.pname('weight'), 'conv', None, need_wT=ex.for_training)
+        self.b = ex.register_param(self.pname('bias')) if 'bias' in self.slots else None
+        self.y = self.new_out('act')
+        self.y.needs_grad = ex.for_training
+        self.col = ex.empty((self.N * self.Ho * self.Wo, self.T * self.C), F16)
+        self.wT_flat = None
+
+    def params_changed(self):
+        if self.ex.for_training:
+            o = self.O
+            if self.wT_flat is None:
+                self.wT_flat = self.ex.zeros((self.T * self.C, 1, _pad8(o)), F16)
+            hip.call('sn_weight_transpose', self.w.master, self.wT_flat, o, 1, self.T * self.C, _pad8(o), hip.stream())
+
+    def forward(self):
+        ex = self.ex
+        x, off = ex.as_act(self.x), ex.as_act(self.off)
+        oc = self.off.shape[1]
+        hip.call('sn_deform_im2col', x, off, self.col, self.N, self.H, self.W, self.C, self.k[0], self.k[1], self.s[0], self.p[0],
+                 self.d[0], self.dg, oc, 0, hip.stream())
+        M, K = self.col.shape
+        hip.call('sn_conv_fwd', self.col, self.w.w16, self.b.master if self.b is not None else None, None, self.y.t, M, 1, 1, K, K,
+                 self.O, self.O, 0, 1, 1, 1, 0, 1, 0, 0, hip.stream())
+
+    def backward(self):
+        ex = self.ex
+        if self.y.grad is None:
+            return
+        dy = self.y.grad
+        M, K = self.col.shape
+        Op = _pad8(self.O)
+        assert Op == self.O
+        if self.w.trainable:
+            hip.call('sn_conv_wgrad', dy, self.col, self.w.grad, M, 1, 1, K, K, self.O, Op, 1, 1, 1, 0, 1, hip.stream())
+        if self.b is not None and self.b.trainable:
+            hip.call('sn_bias_grad', dy, self.b.grad, M, self.O, Op, 0, hip.stream())
+        if self.x.needs_grad or self.off.needs_grad:
+            dcol = ex.empty((M, K), F16)
+            hip.call('sn_conv_dgrad', dy, self.wT_flat, None, dcol, M, 1, 1, K, K, Op, Op, K, 1, 1, 1, 0, 1, 0, hip.stream())
+            d_data = ex.zeros((self.N, self.H, self.W, self.C), F32)
+            oc = self.off.shape[1]
+            d_off = ex.empty((self.N, self.Ho, self.Wo, oc), F16)
+            hip.call('sn_deform_col2im', dcol, ex.as_act(self.x), ex.as_act(self.off), d_data, d_off, self.N, self.H, self.W,
+                     self.C, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], self.dg, oc, 0, hip.stream())
+            if self.x.needs_grad:
+                d16 = ex.empty((self.N, self.H, self.W, self.C), F16)
+                hip.call('sn_copy2d', d_data, d16, 1, d_data.numel(), d_data.numel(), d_data.numel(), 1, 0, hip.stream())
+                ex.add_grad(self.x, d16, 'act')
+            if self.off.needs_grad:
+                ex.add_grad(self.off, d_off, 'act')
+        self.y.grad = None
+
+
+# ---------------------------------------------------------------------------------------------
+# structure ops
+# ---------------------------------------------------------------------------------------------
+@register('Pooling')
+class PoolingStep(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        a = self.a
+        if a.get('pool_type', 'max') != 'max' or _bool(a.get('global_pool', False)):
+            raise NotImplementedError('Pooling %s (%s)' % (a.get('pool_type'), self.node.name))
+        self.k, self.s, self.p = _tup(a['kernel']), _tup(a.get('stride', (1, 1))), _tup(a.get('pad', (0, 0)))
+        self.y = self.new_out('act')
+        self.y.needs_grad = self.x.needs_grad
+
+    def forward(self):
+        n, h, w, c = self.x.nhwc()
+        hip.call('sn_maxpool_fwd', self.ex.as_act(self.x), self.y.t, n, h, w, c, self.k[0], self.s[0], self.p[0], hip.stream())
+
+    def backward(self):
+        if self.y.grad is not None and self.x.needs_grad:
+            raise NotImplementedError('max-pool backward (the stem is frozen in every SNIPER config)')
+
+
+@register('Cast')
+class CastStep(Step):
+    """fp16 <-> fp32 casts of the reference graph (resnet_mx_101_e2e.py:250-252,405-406) are
+    no-ops here: activations are fp16 channels-last on both sides, consumers convert on demand."""
+
+    def setup(self):
+        self.x = self.ins[0]
+        self.ex.vals[(id(self.node), 0)] = self.x
+
+    def forward(self):
+        pass
+
+
+@register('BlockGrad')
+class BlockGradStep(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        self.y = self.new_out('f32', alloc=False)
+
+    def forward(self):
+        self.y.t = self.ex.as_f32(self.x)
+
+
+@register('Concat')
+class ConcatStep(Step):
+    def setup(self):
+        if int(self.a.get('dim', 1)) != 1:
+            raise NotImplementedError('Concat along dim %s' % self.a.get('dim'))
+        self.y = self.new_out('act')
+        self.y.needs_grad = any(v.needs_grad for v in self.ins)
+
+    def forward(self):
+        n, h, w, ctot = self.y.nhwc()
+        off = 0
+        flat = self.y.t.view(-1)
+        for v in self.ins:
+            c = v.nhwc()[3]
+            hip.call('sn_copy2d', self.ex.as_act(v), flat[off:], n * h * w, c, c, ctot, 0, 0, hip.stream())
+            off += c
+
+    def backward(self):
+        if self.y.grad is None:
+            return
+        n, h, w, ctot = self.y.nhwc()
+        off = 0
+        flat = self.y.grad.view(-1)
+        for v in self.ins:
+            c = v.nhwc()[3]
+            if v.needs_grad:
+                g = self.ex.empty((n, h, w, c), F16)
+                hip.call('sn_copy2d', flat[off:], g, n * h * w, c, ctot, c, 0, 0, hip.stream())
+                self.ex.add_grad(v, g, 'act')
+            off += c
+        self.y.grad = None
+
+
+@register('Reshape', 'Flatten')
+class ReshapeStep(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        self.y = self.new_out('f32', alloc=False)
+        self.y.needs_grad = self.x.needs_grad
+
+    def forward(self):
+        self.y.t = self.ex.as_f32(self.x).view(self.y.shape)
+
+    def backward(self):
+        if self.y.grad is None:
+            return
+        if self.x.needs_grad:
+            self.ex.add_grad(self.x, self.y.grad.view(self.x.shape), 'f32')
+        self.y.grad = None
+
+
+@register('_plus', 'elemwise_add', '_minus', '_mul')
+class BinaryStep(Step):
+    def setup(self):
+        a, b = self.ins
+        self.lhs, self.rhs = a, b
+        self.act = (a.fmt == 'act' and b.fmt == 'act' and not self.wants_f32[0] and self.node.op in ('_plus', 'elemwise_add'))
+        self.y = self.new_out('act' if self.act else 'f32')
+        self.y.needs_grad = a.needs_grad or b.needs_grad
+        if not self.act and a.shape != b.shape:
+            raise NotImplementedError('broadcasting in %s (%s)' % (self.node.op, self.node.name))
+        self.code = {'_plus': 1, 'elemwise_add': 1, '_minus': 0, '_mul': 2}[self.node.op]
+
+    def forward(self):
+        ex = self.ex
+        if self.act:
+            n, h, w, c = self.y.nhwc()
+            hip.call('sn_ew_f16', self.lhs.t, self.rhs.t, None, self.y.t, n * h * w, c, c, c, c, c, 1, hip.stream())
+        else:
+            hip.call('sn_ew_f32', ex.as_f32(self.lhs), ex.as_f32(self.rhs), self.y.t, self.y.t.numel(), self.code, 0.0, hip.stream())
+
+    def backward(self):
+        ex = self.ex
+        g = self.y.grad
+        if g is None:
+            return
+        fmt = self.y.fmt
+        op = self.node.op
+        if op in ('_plus', 'elemwise_add'):
+            ex.add_grad(self.lhs, g, fmt)
+            ex.add_grad(self.rhs, g, fmt)
+        elif op == '_minus':
+            ex.add_grad(self.lhs, g, fmt)
+            if self.rhs.needs_grad:
+                neg = ex.empty(g.shape, F32)
+                hip.call('sn_ew_f32', g, None, neg, g.numel(), 3, -1.0, hip.stream())
+                ex.add_grad(self.rhs, neg, fmt)
+        else:
+            for me, other in ((self.lhs, self.rhs), (self.rhs, self.lhs)):
+                if me.needs_grad:
+                    t = ex.empty(g.shape, F32)
+                    hip.call('sn_ew_f32', g, ex.as_f32(other), t, g.numel(), 2, 0.0, hip.stream())
+                    ex.add_grad(me, t, fmt)
+        self.y.grad = None
+
+
+@register('_mul_scalar', '_plus_scalar', '_minus_scalar')
+class ScalarStep(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        self.y = self.new_out('f32')
+        self.y.needs_grad = self.x.needs_grad
+        self.scalar = float(self.a['scalar'])
+
+    def forward(self):
+        x = self.ex.as_f32(self.x)
+        if self.node.op == '_mul_scalar':
+            hip.call('sn_ew_f32', x, None, self.y.t, x.numel(), 3, self.scalar, hip.stream())
+        else:
+            c = self.ex.const(('fill', x.numel(), self.scalar), lambda: torch.full((x.numel(),), self.scalar, device=x.device))
+            hip.call('sn_ew_f32', x, c, self.y.t, x.numel(), 1 if self.node.op == '_plus_scalar' else 0, 0.0, hip.stream())
+
+    def backward(self):
+        g = self.y.grad
+        if g is None or not self.x.needs_grad:
+            return
+        if self.node.op == '_mul_scalar':
+            t = self.ex.empty(g.shape, F32)
+            hip.call('sn_ew_f32', g, None, t, g.numel(), 3, self.scalar, hip.stream())
+            g = t
+        self.ex.add_grad(self.x, g, 'f32')
+        self.y.grad = None
+
+
+# ---------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------
+@register('SoftmaxOutput')
+class SoftmaxOutputStep(Step):
+    """SoftmaxOutput(multi_output, use_ignore, ignore_label, normalization, grad_scale): forward is
+    the softmax; backward injects grad_scale/valid * (p - onehot) (call sites :279-281, 310-315)."""
+
+    def setup(self):
+        a = self.a
+        self.x, self.label = self.ins[0], self.ins[1]
+        self.multi = _bool(a.get('multi_output', False))
+        self.use_ignore = _bool(a.get('use_ignore', False))
+        self.ignore = float(a.get('ignore_label', -1))
+        self.grad_scale = float(a.get('grad_scale', 1.0))
+        self.norm = a.get('normalization', 'null')
+        xs = self.x.shape
+        if self.multi:
+            self.outer, self.K, self.inner = xs[0], xs[1], int(np.prod(xs[2:]))
+        else:
+            self.outer, self.K, self.inner = int(np.prod(xs[:-1])), xs[-1], 1
+        self.y = self.new_out('f32')
+        self.cnt = self.ex.zeros((4,), torch.int32)
+
+    def forward(self):
+        hip.call('sn_softmax_fwd', self.ex.as_f32(self.x), self.y.t, self.outer, self.K, self.inner, hip.stream())
+
+    def backward(self):
+        ex = self.ex
+        if not self.x.needs_grad:
+            return
+        g = ex.empty(self.x.shape, F32)
+        scale = self.grad_scale
+        if self.norm == 'batch':
+            scale = scale / float(self.outer)
+        hip.call('sn_softmax_output_bwd', self.y.t, ex.as_f32(self.label), g, self.outer, self.K, self.inner, self.ignore,
+                 1 if self.use_ignore else 0, scale, 1 if self.norm == 'valid' else 0, self.cnt, hip.stream())
+        ex.add_grad(self.x, g, 'f32')
+
+
+@register('SoftmaxActivation')
+class SoftmaxActivationStep(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        xs = self.x.shape
+        if self.a.get('mode', 'instance') == 'channel':
+            self.outer, self.K, self.inner = xs[0], xs[1], int(np.prod(xs[2:]))
+        else:
+            self.outer, self.K, self.inner = int(np.prod(xs[:-1])), xs[-1], 1
+        self.y = self.new_out('f32')
+
+    def forward(self):
+        hip.call('sn_softmax_fwd', self.ex.as_f32(self.x), self.y.t, self.outer, self.K, self.inner, hip.stream())
+
+    def backward(self):
+        if self.y.grad is not None and self.x.needs_grad:
+            raise NotImplementedError('SoftmaxActivation backward (inference-only in the reference graphs)')
+
+
+@register('smooth_l1')
+class SmoothL1Step(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        self.sigma = float(self.a.get('scalar', 1.0))
+        self.y = self.new_out('f32')
+        self.y.needs_grad = self.x.needs_grad
+
+    def _consts(self, n, dev):
+        z = self.ex.const(('zeros', n), lambda: torch.zeros((n,), device=dev))
+        o = self.ex.const(('ones', n), lambda: torch.ones((n,), device=dev))
+        return z, o
+
+    def forward(self):
+        x = self.ex.as_f32(self.x)
+        z, o = self._consts(x.numel(), x.device)
+        hip.call('sn_smooth_l1_loss', x, z, o, self.y.t, None, x.numel(), self.sigma, 1.0, hip.stream())
+
+    def backward(self):
+        g = self.y.grad
+        if g is None or not self.x.needs_grad:
+            return
+        x = self.ex.as_f32(self.x)
+        z, _ = self._consts(x.numel(), x.device)
+        dx = self.ex.empty(x.shape, F32)
+        # dpred = grad_scale * weight * f'(x) with weight := incoming gradient
+        hip.call('sn_smooth_l1_loss', x, z, g, None, dx, x.numel(), self.sigma, 1.0, hip.stream())
+        self.ex.add_grad(self.x, dx, 'f32')
+        self.y.grad = None
+
+
+@register('MakeLoss')
+class MakeLossStep(Step):
+    def setup(self):
+        self.x = self.ins[0]
+        self.grad_scale = float(self.a.get('grad_scale', 1.0))
+        self.y = self.new_out('f32', alloc=False)
+
+    def forward(self):
+        self.y.t = self.ex.as_f32(self.x)
+
+    def backward(self):
+        if not self.x.needs_grad:
+            return
+        g = self.ex.empty(self.x.shape, F32)
+        hip.call('sn_ew_f32', None, None, g, g.numel(), 4, self.grad_scale, hip.stream())
+        self.ex.add_grad(self.x, g, 'f32')
+
+
+# ---------------------------------------------------------------------------------------------
+# proposal / RoI operators
+# ---------------------------------------------------------------------------------------------
+def _anchor_attrs(a):
+    scales = a.get('scales', (2, 4, 7, 10, 13, 16, 24))
+    ratios = a.get('ratios', (0.5, 1, 2))
+    if isinstance(scales, str):
+        scales = tuple(float(t) for t in scales.strip('()[] ').split(',') if t.strip())
+    if isinstance(ratios, str):
+        ratios = tuple(float(t) for t in ratios.strip('()[] ').split(',') if t.strip())
+    return tuple(scales), tuple(ratios)
+
+
+class _ProposalBase(Step):
+    def common(self):
+        from ..data.anchors import generate_anchors
+        ex, a = self.ex, self.a
+        self.cls, self.bbox, self.info = self.data_in('cls_prob'), self.data_in('bbox_pred'), self.data_in('im_info')
+        # (B, 2, A*F, F) in the training graph, (B, 2A, F, F) at test time: same memory
+        B, c1, c2, F = self.cls.shape
+        self.B, self.F = B, F
+        self.A = (c1 * c2) // (2 * F)
+        self.stride = int(a.get('feature_stride', 16))
+        scales, ratios = _anchor_attrs(a)
+        if len(scales) * len(ratios) != self.A:
+            raise ValueError('%s: %d anchors per cell in cls_prob but %d scales x %d ratios' % (
+                self.node.name, self.A, len(scales), len(ratios)))
+        base = generate_anchors(self.stride, list(ratios), list(np.array(scales, np.float32))).astype(np.float32)
+        self.base = torch.from_numpy(base).to(ex.device)
+        self.pre = int(a.get('rpn_pre_nms_top_n', 6000))
+        self.post = int(a.get('rpn_post_nms_top_n', 300))
+        self.thresh = float(a.get('threshold', 0.7))
+        self.min_size = float(a.get('rpn_min_size', 0))
+        nbytes = hip.query('sn_proposal_workspace_bytes', B, self.A, F, self.pre, self.post)
+        self.wsbuf = ex.empty((nbytes,), torch.uint8)
+
+
+@register('MultiProposal')
+class MultiProposalStep(_ProposalBase):
+    def setup(self):
+        self.common()
+        self.rois = self.new_out('f32', 0)
+        self.scores = self.new_out('f32', 1)
+
+    def forward(self):
+        ex = self.ex
+        hip.call('sn_multi_proposal', ex.as_f32(self.cls), ex.as_f32(self.bbox), ex.as_f32(self.info), self.base, self.B, self.A,
+                 self.F, self.stride, self.pre, self.post, self.thresh, self.min_size, self.wsbuf, self.rois.t, self.scores.t,
+                 hip.stream())
+
+
+@register('MultiProposalTarget')
+class MultiProposalTargetStep(_ProposalBase):
+    def setup(self):
+        self.common()
+        self.gt, self.vr = self.data_in('gt_boxes'), self.data_in('valid_ranges')
+        self.G = self.gt.shape[1]
+        self.fg = float(self.a.get('fg_thresh', 0.5))
+        self.stds = np.array(self.a.get('bbox_stds', (0.1, 0.1, 0.2, 0.2)), np.float32)
+        self.outs = [self.new_out('f32', i) for i in range(4)]
+
+    def forward(self):
+        ex = self.ex
+        rois, label, tgt, wgt = [o.t for o in self.outs]
+        hip.call('sn_multi_proposal_target', ex.as_f32(self.cls), ex.as_f32(self.bbox), ex.as_f32(self.info), ex.as_f32(self.gt),
+                 ex.as_f32(self.vr), self.base, self.B, self.A, self.F, self.stride, self.G, self.pre, self.post, self.thresh,
+                 self.min_size, self.fg, self.stds.ctypes.data, self.wsbuf, rois, label, tgt, wgt, hip.stream())
+
+
+@register('DeformablePSROIPooling')
+class DPSROIPoolStep(Step):
+    def setup(self):
+        ex, a = self.ex, self.a
+        self.x, self.rois = self.data_in('data'), self.data_in('rois')
+        self.no_trans = _bool(a.get('no_trans', False))
+        self.trans = None if self.no_trans or 'trans' not in self.slots else self.data_in('trans')
+        self.P, self.S = int(a['pooled_size']), int(a.get('sample_per_part', 1))
+        if int(a.get('group_size', 1)) != 1 or int(a.get('part_size', self.P)) != self.P:
+            raise NotImplementedError('DeformablePSROIPooling with group_size != 1 / part_size != pooled_size '
+                                      '(position-sensitive variant of BASELINE config C4: next row)')
+        if int(a['output_dim']) != self.x.shape[1]:
+            raise ValueError('%s: output_dim must equal the channel count when group_size == 1' % self.node.name)
+        self.scale = float(a['spatial_scale'])
+        self.tstd = float(a.get('trans_std', 0.0))
+        self.y = self.new_out('act')
+        self.y.needs_grad = self.x.needs_grad or (self.trans is not None and self.trans.needs_grad)
+
+    def forward(self):
+        ex = self.ex
+        n, h, w, c = self.x.nhwc()
+        R = self.rois.shape[0]
+        hip.call('sn_dpsroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), ex.as_f32(self.trans) if self.trans else None,
+                 self.y.t, R, h, w, c, self.P, self.S, self.scale, self.tstd, hip.stream())
+
+    def backward(self):
+        ex = self.ex
+        if self.y.grad is None:
+            return
+        n, h, w, c = self.x.nhwc()
+        R = self.rois.shape[0]
+        d_data = ex.zeros((n, h, w, c), F32)
+        d_trans = ex.zeros(self.trans.shape, F32) if self.trans is not None else None
+        hip.call('sn_dpsroi_pool_bwd', self.y.grad, ex.as_act(self.x), ex.as_f32(self.rois),
+                 ex.as_f32(self.trans) if self.trans else None, d_data, d_trans, R, h, w, c, self.P, self.S, self.scale, self.tstd,
+                 hip.stream())
+        if self.x.needs_grad:
+            d16 = ex.empty((n, h, w, c), F16)
+            hip.call('sn_copy2d', d_data, d16, 1, d_data.numel(), d_data.numel(), d_data.numel(), 1, 0, hip.stream())
+            ex.add_grad(self.x, d16, 'act')
+        if self.trans is not None and self.trans.needs_grad:
+            ex.add_grad(self.trans, d_trans, 'f32')
+        self.y.grad = None
+
+
+@register('Custom')
+class CustomStep(Step):
+    """mx.operator.CustomOp plugins run on the host (numpy NDArrays), like MXNet's python ops."""
+
+    def setup(self):
+        from ..mx import operator as _operator
+        self.prop = _operator.get_prop(self.a.get('op_type'), self.a)
+        shapes = [v.shape for v in self.ins]
+        self.op = self.prop.create_operator(None, shapes, None)
+        self.outs = [self.new_out('f32', i) for i in range(self.node.num_outputs)]
+
+    def forward(self):
+        from ..mx import ndarray as nd
+        ins = [nd.NDArray(self.ex.as_f32(v).cpu().numpy()) for v in self.ins]
+        outs = [nd.zeros(o.shape) for o in self.outs]
+        self.op.forward(self.ex.is_train, ['write'] * len(outs), ins, outs, [])
+        for o, h in zip(self.outs, outs):
+            o.t.copy_(torch.from_numpy(h.asnumpy()))

@@ -1,0 +1,182 @@
+"""SNIPER end-to-end training iterator on the GPU data path.
+
+Contract of the reference's ``MNIteratorE2E`` (lib/iterators/MNIteratorE2E.py:16-220) +
+``MNIteratorBase`` (MNIteratorBase.py:6-111): same constructor, ``reset()`` builds the epoch chip
+database, every batch is an ``mx.io.DataBatch`` with
+
+    data  = [data (B,3,512,512), valid_ranges (B,2), im_info (B,3) = h, w, im_scale]
+    label = [label (B, A*F*F), bbox_target (B,4A,F,F), bbox_weight (B,4A,F,F), gt_boxes (B,100,5)]
+
+and ``provide_data / provide_label / provide_*_single / batch_size / __len__ / get_batch_size``.
+What differs is where the work happens: chip extraction + box assignment are two ragged GPU launches
+per phase for the whole roidb (chip_worker), and the per-batch anchor labelling of all B chips is one
+``sn_anchor_assign`` call whose outputs stay in HBM -- there is no multiprocessing pool and no pickling
+(the reference's Pool(64).map round trips, :51-63,173).
+
+Image pixels: the reference decodes and resizes JPEGs with OpenCV (im_worker, data_workers.py:80-121).
+OpenCV does not exist here and the benchmark is defined on synthetic chips, so
+pixels come from ``im_source(roidb_entry, crop, flipped) -> (3,H,W) float32``; the default source
+is the seeded N(0, 50^2) generator.
+"""
+import math
+
+import numpy as np
+import torch
+
+import sniper_amd.mx as mx
+
+from .. import hip
+from ..data.anchors import AnchorAssigner
+from ..data.chip_worker import chip_worker
+
+
+def synthetic_im_source(chip_hw):
+    def src(r, crop, flipped, _cache={}):
+        key = (r.get('image'), float(crop[0][0]), float(crop[0][1]), crop[4])
+        rs = np.random.RandomState(abs(hash(key)) % (2 ** 31))
+        return (rs.standard_normal((3, chip_hw[0], chip_hw[1])) * 50.0).astype(np.float32)
+    return src
+
+
+class MNIteratorE2E(mx.io.DataIter):
+    def __init__(self, roidb, config, batch_size=4, threads=8, nGPUs=1, pad_rois_to=400, crop_size=(512, 512),
+                 im_source=None):
+        super(MNIteratorE2E, self).__init__()
+        assert batch_size % nGPUs == 0, 'batch_size should be divisible by number of GPUs'
+        self.roidb, self.cfg = roidb, config
+        self.batch_size, self.crop_size = batch_size, crop_size
+        self.n_per_gpu = batch_size // nGPUs
+        self.data_name = ['data'] if config.TRAIN.ONLY_PROPOSAL else ['data', 'valid_ranges', 'im_info']
+        self.label_name = ['label', 'bbox_target', 'bbox_weight'] if config.TRAIN.ONLY_PROPOSAL else \
+            ['label', 'bbox_target', 'bbox_weight', 'gt_boxes']
+        if config.TRAIN.AUTO_FOCUS:
+            raise NotImplementedError('AUTO_FOCUS training labels (gen_mask) on the GPU: next row')
+        if config.TRAIN.WITH_MASK:
+            raise NotImplementedError('mask branch is out of scope (SURVEY.md 8(f).3)')
+        self.chip_worker = chip_worker(config, crop_size[0])
+        self.anchors = AnchorAssigner(config, crop_size[0])
+        self.im_source = im_source or synthetic_im_source(crop_size)
+        self.epiter = 0
+        self.seed = 0
+        self.batch = None
+        self.reset()
+        self.get_batch()
+
+    # ---- MNIteratorBase contract ---------------------------------------------------------------
+    def get_batch_size(self):
+        return self.batch_size
+
+    def __len__(self):
+        return len(self.inds)
+
+    @property
+    def provide_data(self):
+        return [(k, tuple(v.shape)) for k, v in zip(self.data_name, self.data)]
+
+    @property
+    def provide_label(self):
+        return [(k, tuple(v.shape)) for k, v in zip(self.label_name, self.label)]
+
+    provide_data_single = provide_data
+    provide_label_single = provide_label
+
+    def iter_next(self):
+        return self.get_batch()
+
+    def next(self):
+        if self.iter_next():
+            return self.batch
+        raise StopIteration
+
+    __next__ = next
+
+    def getindex(self):
+        return self.cur_i // self.batch_size
+
+    def getpad(self):
+        return 0
+
+    # ---- epoch chip database (reference :41-103) ------------------------------------------------
+    def reset(self):
+        self.cur_i = 0
+        self.n_neg_per_im = 2
+        self.crop_idx = [0] * len(self.roidb)
+        self.chip_worker.reset()
+        crops = self.chip_worker.extract_batch(self.roidb)
+        for r, cs in zip(self.roidb, crops):
+            r['crops'] = cs
+        assigned = self.chip_worker.assign_batch(self.roidb)
+        for ps, r in zip(assigned, self.roidb):
+            r['props_in_chips'] = list(ps[0])
+            if self.cfg.TRAIN.USE_NEG_CHIPS:
+                r['neg_crops'], r['neg_props_in_chips'] = ps[1], ps[2]
+        chipindex = []
+        for i, r in enumerate(self.roidb):
+            if self.cfg.TRAIN.USE_NEG_CHIPS:
+                cs = r['neg_crops']
+                if len(cs) > 0:
+                    sel = np.arange(len(cs))
+                    if len(cs) > self.n_neg_per_im:
+                        sel = np.random.permutation(sel)[0:self.n_neg_per_im]
+                    for ind in sel:
+                        r['crops'].append(r['neg_crops'][ind])
+                        r['props_in_chips'].append(r['neg_props_in_chips'][ind].astype(np.int32))
+            chipindex.extend([i] * len(r['crops']))
+        chipindex = np.array(chipindex)
+        self.n_chips = len(chipindex)
+        if chipindex.shape[0] % self.batch_size > 0:
+            extra = self.batch_size - (chipindex.shape[0] % self.batch_size)
+            chipindex = np.hstack((chipindex, chipindex[0:extra]))
+        self.inds = np.array(np.random.permutation(chipindex), dtype=int)
+        for r in self.roidb:
+            r['chip_order'] = np.random.permutation(np.arange(len(r['crops'])))
+        self.epiter += 1
+        self.size = len(self.inds)
+
+    # ---- batch assembly (reference :112-220) ----------------------------------------------------
+    def get_batch(self):
+        if self.cur_i >= self.size:
+            return False
+        self.batch = self._get_batch()
+        self.cur_i += self.batch_size
+        return True
+
+    def _get_batch(self):
+        lo, hi = self.cur_i, self.cur_i + self.batch_size
+        ids = [self.inds[i] for i in range(lo, hi)]
+        roidb = [self.roidb[i] for i in ids]
+        cropids = [r['chip_order'][self.crop_idx[i] % len(r['chip_order'])] for i, r in zip(ids, roidb)]
+        for i in ids:
+            self.crop_idx[i] += 1
+        n = len(roidb)
+        srange = np.zeros((n, 2), np.float32)
+        chipinfo = np.zeros((n, 3), np.float32)
+        worker_data = []
+        ims = np.zeros((n, 3, self.crop_size[0], self.crop_size[1]), np.float32)
+        for k, (r, cid) in enumerate(zip(roidb, cropids)):
+            crop = r['crops'][cid]
+            cur_crop, im_scale, height, width, scalei = crop
+            nids = r['props_in_chips'][cid]
+            gtids = np.where(r['max_overlaps'] == 1)[0]
+            vr = self.cfg.TRAIN.VALID_RANGES[scalei]
+            srange[k, 0] = 0 if vr[0] < 0 else vr[0] * im_scale
+            srange[k, 1] = self.crop_size[1] if vr[1] < 0 else vr[1] * im_scale
+            chipinfo[k] = [height, width, im_scale]
+            worker_data.append([[self.crop_size[0], self.crop_size[1], im_scale], cur_crop, im_scale, nids, gtids,
+                                r['boxes'][gtids, :], r['boxes'], r['max_classes'][gtids].reshape(-1, 1)])
+            im = self.im_source(r, crop, r.get('flipped', False))
+            h, w = min(im.shape[1], self.crop_size[0]), min(im.shape[2], self.crop_size[1])
+            ims[k, :, :h, :w] = im[:, :h, :w]
+        out = self.anchors.assign(worker_data, seed=self.seed)
+        self.seed += 1
+        dev = hip.require_gpu()
+        self.data = [mx.nd.NDArray(torch.from_numpy(ims).to(dev))] if self.cfg.TRAIN.ONLY_PROPOSAL else \
+            [mx.nd.NDArray(torch.from_numpy(ims).to(dev)), mx.nd.NDArray(torch.from_numpy(srange).to(dev)),
+             mx.nd.NDArray(torch.from_numpy(chipinfo).to(dev))]
+        self.label = [mx.nd.NDArray(out['label']), mx.nd.NDArray(out['bbox_target']), mx.nd.NDArray(out['bbox_weight'])]
+        if not self.cfg.TRAIN.ONLY_PROPOSAL:
+            self.label.append(mx.nd.NDArray(out['gt_boxes']))
+        batch = mx.io.DataBatch(data=self.data, label=self.label, pad=0, index=self.getindex(),
+                                provide_data=self.provide_data, provide_label=self.provide_label)
+        batch.worker_data = worker_data   # the anchor-labelling inputs (bench.py re-runs the labelling per step)
+        return batch

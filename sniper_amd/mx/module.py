@@ -1,0 +1,236 @@
+"""``mx.mod.Module`` over the HIP executor (main_train.py:89-94,143-146; lib/inference.py:71-74,423-428).
+
+Data parallelism is MI355X-native: one process per GPU.  Under ``torchrun`` (WORLD_SIZE > 1) every
+rank binds its LOCAL_RANK device, consumes its slice ``batch[rank*B:(rank+1)*B]`` of the iterator's
+global batch (the split MNIteratorBase.n_per_gpu implies, lib/iterators/MNIteratorBase.py:21) and the
+gradient arena is summed with one RCCL all-reduce per step -- the only exchange the reference's
+kvstore='device' performs.  A single process asked for several contexts is refused: that is the
+reference's in-process multi-GPU model, which this engine deliberately does not have.
+"""
+import logging
+import os
+import time
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import ndarray as nd
+from .misc import save_checkpoint
+
+BatchEndParam = namedtuple('BatchEndParams', ['epoch', 'nbatch', 'eval_metric', 'locals'])
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist
+    return None
+
+
+def init_distributed():
+    """Join the torchrun rendezvous (RCCL backend) if launched with WORLD_SIZE > 1."""
+    import torch.distributed as dist
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws > 1 and not dist.is_initialized():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group(backend='nccl')
+    return dist if ws > 1 else None
+
+
+class Module(object):
+    def __init__(self, symbol, data_names=('data',), label_names=('softmax_label',), logger=logging, context=None,
+                 work_load_list=None, fixed_param_names=None, state_names=None):
+        self.symbol = symbol
+        self.data_names = list(data_names or [])
+        self.label_names = list(label_names or [])
+        self.logger = logger
+        ctx = context if isinstance(context, (list, tuple)) else [context or nd.gpu(0)]
+        self.contexts = list(ctx)
+        self.fixed_param_names = list(fixed_param_names or [])
+        self.binded = self.params_initialized = self.optimizer_initialized = False
+        self.exe = None
+        self._arg_params = self._aux_params = None
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        # True: the iterator yields the GLOBAL batch and every rank takes its slice (reference behaviour);
+        # False: the iterator is already rank-local (bench.py: each rank owns an independent chip minibatch)
+        self.slice_inputs = True
+
+    # ---- properties the reference reads
+    @property
+    def output_names(self):
+        return self.symbol.list_outputs()
+
+    @property
+    def data_shapes(self):
+        return self._data_shapes
+
+    @property
+    def label_shapes(self):
+        return self._label_shapes
+
+    # ---- bind
+    def _local(self, shape):
+        """per-GPU shape of a batch-major input (global batch split across ranks / contexts)"""
+        n = self.world if (self.world > 1 and self.slice_inputs) else 1
+        if self.world == 1 and len(self.contexts) > 1:
+            raise NotImplementedError(
+                'one process driving %d GPUs is the reference\'s in-process model; launch one process per GPU instead: '
+                'python -m torch.distributed.run --nproc-per-node %d ... (see INTEGRATION.md)' % (len(self.contexts),
+                                                                                                len(self.contexts)))
+        shape = tuple(shape)
+        if n > 1:
+            assert shape[0] % n == 0, 'batch %d not divisible by %d ranks' % (shape[0], n)
+            return (shape[0] // n,) + shape[1:]
+        return shape
+
+    def bind(self, data_shapes, label_shapes=None, for_training=True, inputs_need_grad=False, force_rebind=False,
+             shared_module=None, grad_req='write'):
+        from ..engine.executor import Executor
+        if self.binded and not force_rebind:
+            return
+        if self.world > 1:
+            init_distributed()
+        self.for_training = for_training
+        self._data_shapes = [(d[0], tuple(d[1])) for d in data_shapes]
+        self._label_shapes = [(d[0], tuple(d[1])) for d in (label_shapes or [])]
+        shapes = {}
+        for name, shp in self._data_shapes + self._label_shapes:
+            shapes[name] = self._local(shp)
+        args = set(self.symbol.list_arguments())
+        shapes = {k: v for k, v in shapes.items() if k in args}
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', self.contexts[0].device_id)) if self.world > 1
+                           else self.contexts[0].device_id)
+        torch.cuda.set_device(dev)
+        self.exe = Executor(self.symbol, shapes, for_training=for_training, fixed_param_names=self.fixed_param_names,
+                            device=dev)
+        self.binded = True
+
+    # ---- parameters
+    def init_params(self, initializer=None, arg_params=None, aux_params=None, allow_missing=False, force_init=False,
+                    allow_extra=True):
+        if self.params_initialized and not force_init:
+            return
+        arg = dict(arg_params or {})
+        aux = dict(aux_params or {})
+        rs = np.random.RandomState(0)
+        for name, p in self.exe.params.items():
+            if name not in arg:
+                if not allow_missing and arg_params is not None and initializer is None:
+                    raise RuntimeError('%s is not presented' % name)
+                if name.endswith('_gamma'):
+                    arg[name] = np.ones(p.ref_shape, np.float32)
+                elif name.endswith('_weight') and len(p.ref_shape) > 1:
+                    fan_in = float(np.prod(p.ref_shape[1:]))
+                    arg[name] = (rs.standard_normal(p.ref_shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)  # MSRA
+                else:
+                    arg[name] = np.zeros(p.ref_shape, np.float32)
+        for name, t in self.exe.aux.items():
+            if name not in aux:
+                aux[name] = np.ones(tuple(t.shape), np.float32) if name.endswith('_var') else np.zeros(tuple(t.shape), np.float32)
+        self.exe.set_params(arg, aux)
+        self.params_initialized = True
+
+    def set_params(self, arg_params, aux_params, allow_missing=False, force_init=True, allow_extra=True):
+        self.init_params(None, arg_params, aux_params, allow_missing, force_init)
+
+    def get_params(self):
+        arg, aux = self.exe.get_params()
+        return {k: nd.NDArray(v) for k, v in arg.items()}, {k: nd.NDArray(v) for k, v in aux.items()}
+
+    def save_checkpoint(self, prefix, epoch, save_optimizer_states=False):
+        if self.rank != 0:
+            return
+        arg, aux = self.get_params()
+        save_checkpoint(prefix, epoch, self.symbol, arg, aux)
+        if save_optimizer_states:
+            torch.save({'momentum': self.exe.arena_mom.cpu(), 'num_update': self.exe.num_update}, '%s-%04d.states' % (prefix, epoch))
+
+    # ---- optimizer (mx 'sgd' with multi_precision; lib/train_utils/utils.py:26-33)
+    def init_optimizer(self, kvstore='local', optimizer='sgd', optimizer_params=(('learning_rate', 0.01),), force_init=False):
+        if optimizer != 'sgd':
+            raise NotImplementedError('optimizer %r (the reference trains with sgd)' % (optimizer,))
+        op = dict(optimizer_params)
+        self.opt = {'lr': float(op.get('learning_rate', 0.01)), 'wd': float(op.get('wd', 0.0)),
+                    'momentum': float(op.get('momentum', 0.0)), 'rescale_grad': float(op.get('rescale_grad', 1.0)),
+                    'lr_scheduler': op.get('lr_scheduler')}
+        if self.opt['lr_scheduler'] is not None:
+            self.opt['lr_scheduler'].base_lr = self.opt['lr']
+        self.optimizer_initialized = True
+
+    # ---- compute
+    def _slice(self, a):
+        if self.world > 1 and self.slice_inputs:
+            n = a.shape[0] // self.world
+            return a[self.rank * n:(self.rank + 1) * n]
+        return a
+
+    def forward(self, data_batch, is_train=None):
+        feed = {}
+        for name, arr in zip(self.data_names, data_batch.data):
+            feed[name] = self._slice(arr)
+        if data_batch.label is not None:
+            for name, arr in zip(self.label_names, data_batch.label):
+                feed[name] = self._slice(arr)
+        feed = {k: v for k, v in feed.items() if k in self.exe.input_names}
+        self._labels = [self._slice(a) for a in (data_batch.label or [])]
+        self.exe.forward(feed, is_train=self.for_training if is_train is None else is_train)
+
+    def backward(self, out_grads=None):
+        self.exe.backward()
+
+    def forward_backward(self, data_batch):
+        self.forward(data_batch, is_train=True)
+        self.backward()
+
+    def update(self):
+        dist = _dist()
+        if dist is not None:
+            dist.all_reduce(self.exe.grad_arena())  # sum over ranks == kvstore 'device' push/pull
+        sched = self.opt['lr_scheduler']
+        lr = sched(self.exe.num_update + 1) if sched is not None else self.opt['lr']
+        self.exe.update(lr, self.opt['wd'], self.opt['momentum'], self.opt['rescale_grad'])
+
+    def get_outputs(self, merge_multi_context=True):
+        outs = [nd.NDArray(t) for t in self.exe.outputs]
+        if merge_multi_context:
+            return outs
+        return [[o] for o in outs]
+
+    def update_metric(self, eval_metric, labels):
+        eval_metric.update(labels, self.get_outputs())
+
+    # ---- training loop (main_train.py:143-146)
+    def fit(self, train_data, eval_data=None, eval_metric='acc', epoch_end_callback=None, batch_end_callback=None,
+            kvstore='local', optimizer='sgd', optimizer_params=(('learning_rate', 0.01),), eval_end_callback=None,
+            eval_batch_end_callback=None, initializer=None, arg_params=None, aux_params=None, allow_missing=False,
+            force_rebind=False, force_init=False, begin_epoch=0, num_epoch=None, validation_metric=None, monitor=None):
+        assert num_epoch is not None, 'please specify number of epochs'
+        self.bind(data_shapes=train_data.provide_data, label_shapes=train_data.provide_label, for_training=True,
+                  force_rebind=force_rebind)
+        self.init_params(initializer=initializer, arg_params=arg_params, aux_params=aux_params, allow_missing=allow_missing,
+                         force_init=force_init)
+        self.init_optimizer(kvstore=kvstore, optimizer=optimizer, optimizer_params=optimizer_params)
+        cbs = lambda c: c if isinstance(c, (list, tuple)) else ([c] if c is not None else [])
+        for epoch in range(begin_epoch, num_epoch):
+            tic = time.time()
+            if hasattr(eval_metric, 'reset'):
+                eval_metric.reset()
+            nbatch = 0
+            train_data.reset() if epoch > begin_epoch else None
+            for data_batch in train_data:
+                self.forward_backward(data_batch)
+                self.update()
+                if hasattr(eval_metric, 'update'):
+                    self.update_metric(eval_metric, self._labels)
+                for cb in cbs(batch_end_callback):
+                    cb(BatchEndParam(epoch=epoch, nbatch=nbatch, eval_metric=eval_metric, locals=locals()))
+                nbatch += 1
+            if hasattr(eval_metric, 'get_name_value'):
+                for name, val in eval_metric.get_name_value():
+                    self.logger.info('Epoch[%d] Train-%s=%f', epoch, name, val)
+            self.logger.info('Epoch[%d] Time cost=%.3f', epoch, time.time() - tic)
+            arg, aux = self.get_params()
+            for cb in cbs(epoch_end_callback):
+                cb(epoch, self.symbol, arg, aux)

@@ -1,0 +1,230 @@
+"""``mx.nd`` subset: host arrays are numpy-backed, device arrays wrap a torch
+tensor (torch = memory/stream plumbing).  Only what the reference's iterators, metrics, callbacks and
+weight initialisers call is provided."""
+import numpy as np
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class Context(object):
+    def __init__(self, device_type, device_id=0):
+        self.device_type, self.device_id = device_type, int(device_id)
+
+    def __repr__(self):
+        return '%s(%d)' % (self.device_type, self.device_id)
+
+    def __eq__(self, o):
+        return isinstance(o, Context) and (self.device_type, self.device_id) == (o.device_type, o.device_id)
+
+    def __hash__(self):
+        return hash((self.device_type, self.device_id))
+
+
+def cpu(i=0):
+    return Context('cpu', i)
+
+
+def gpu(i=0):
+    return Context('gpu', i)
+
+
+_DT = {'float32': np.float32, 'float16': np.float16, 'float64': np.float64, 'int32': np.int32, 'uint8': np.uint8,
+       'int64': np.int64}
+
+
+def _dtype(d):
+    if d is None:
+        return np.float32
+    if isinstance(d, str):
+        return _DT[d]
+    return np.dtype(d).type
+
+
+class NDArray(object):
+    """Array handle.  ``_data`` is a numpy array (cpu context) or a torch tensor (gpu context)."""
+    __array_priority__ = 100.0
+
+    def __init__(self, data, ctx=None):
+        self._data = data
+        self.context = ctx or (cpu() if isinstance(data, np.ndarray) else gpu(0))
+
+    # ---- basics
+    @property
+    def shape(self):
+        return tuple(self._data.shape)
+
+    @property
+    def dtype(self):
+        if isinstance(self._data, np.ndarray):
+            return self._data.dtype.type
+        return np.dtype(str(self._data.dtype).replace('torch.', '')).type
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def T(self):
+        return NDArray(self.asnumpy().T.copy())
+
+    def asnumpy(self):
+        if isinstance(self._data, np.ndarray):
+            return self._data
+        return self._data.detach().float().cpu().numpy() if self._data.dtype in (torch.float16, torch.bfloat16) \
+            else self._data.detach().cpu().numpy()
+
+    def asscalar(self):
+        return self.asnumpy().reshape(-1)[0]
+
+    def astype(self, dtype):
+        return NDArray(self.asnumpy().astype(_dtype(dtype)))
+
+    def copy(self):
+        return NDArray(self.asnumpy().copy())
+
+    def copyto(self, other):
+        if isinstance(other, NDArray):
+            other[:] = self
+            return other
+        return self.as_in_context(other)
+
+    def as_in_context(self, ctx):
+        return self  # placement is decided by the executor; host copies stay numpy-backed
+
+    def wait_to_read(self):
+        if not isinstance(self._data, np.ndarray):
+            torch.cuda.synchronize()
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = shape[0]
+        return NDArray(self.asnumpy().reshape(shape))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        return '<NDArray %s @%s>\n%r' % ('x'.join(map(str, self.shape)), self.context, self.asnumpy())
+
+    # ---- indexing (MNIteratorE2E.py:186-194 uses int, slice and fancy-tuple indices)
+    @staticmethod
+    def _idx(i):
+        if isinstance(i, NDArray):
+            return i.asnumpy().astype(np.int64)
+        if isinstance(i, tuple):
+            return tuple(NDArray._idx(j) for j in i)
+        return i
+
+    def __getitem__(self, i):
+        a = self.asnumpy()[self._idx(i)]
+        if isinstance(self._data, np.ndarray) and isinstance(a, np.ndarray) and a.base is not None and not isinstance(
+                self._idx(i), tuple):
+            return NDArray(a)  # a view: writes through, like mx.nd slices of the first axis
+        return NDArray(np.asarray(a))
+
+    def __setitem__(self, i, v):
+        if isinstance(v, NDArray):
+            v = v.asnumpy()
+        if isinstance(self._data, np.ndarray):
+            self._data[self._idx(i)] = v
+        else:
+            t = torch.as_tensor(np.asarray(v), device=self._data.device).to(self._data.dtype)
+            self._data[self._idx(i)] = t
+
+    # ---- arithmetic
+    def _bin(self, o, f):
+        if isinstance(o, NDArray):
+            o = o.asnumpy()
+        return NDArray(np.asarray(f(self.asnumpy(), o)))
+
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._bin(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+    __div__ = __truediv__
+    def __neg__(self): return NDArray(-self.asnumpy())
+
+    def __iadd__(self, o):
+        self[:] = self + o
+        return self
+
+    def __imul__(self, o):
+        self[:] = self * o
+        return self
+
+
+def array(source, ctx=None, dtype=None):
+    if isinstance(source, NDArray):
+        source = source.asnumpy()
+    a = np.array(source, dtype=_dtype(dtype) if dtype is not None else None)
+    if dtype is None and a.dtype != np.float32:
+        a = a.astype(np.float32)  # mx.nd.array defaults to float32
+    return NDArray(a, ctx)
+
+
+def zeros(shape, ctx=None, dtype=None, **kw):
+    return NDArray(np.zeros(shape, dtype=_dtype(dtype)), ctx)
+
+
+def ones(shape, ctx=None, dtype=None, **kw):
+    return NDArray(np.ones(shape, dtype=_dtype(dtype)), ctx)
+
+
+def empty(shape, ctx=None, dtype=None):
+    return zeros(shape, ctx, dtype)
+
+
+def full(shape, val, ctx=None, dtype=None):
+    return NDArray(np.full(shape, val, dtype=_dtype(dtype)), ctx)
+
+
+def sum(a, axis=None, **kw):  # noqa: A001
+    return NDArray(np.asarray(np.sum(a.asnumpy(), axis=axis)))
+
+
+def argmax_channel(a):
+    """mx.ndarray.argmax_channel: argmax over axis 1 (metric.py:59,114)."""
+    return NDArray(np.argmax(a.asnumpy(), axis=1).astype(np.float32))
+
+
+def smooth_l1(data, scalar=1.0):
+    x = data.asnumpy()
+    s2 = scalar * scalar
+    return NDArray(np.where(np.abs(x) < 1.0 / s2, 0.5 * s2 * x * x, np.abs(x) - 0.5 / s2))
+
+
+def SoftmaxActivation(data, mode='instance'):
+    x = data.asnumpy()
+    ax = 1 if mode == 'channel' else -1
+    e = np.exp(x - x.max(axis=ax, keepdims=True))
+    return NDArray(e / e.sum(axis=ax, keepdims=True))
+
+
+def concatenate(arrays, axis=0):
+    return NDArray(np.concatenate([a.asnumpy() for a in arrays], axis=axis))
+
+
+def save(fname, data):
+    """Documented container (MXNet's binary .params format lives in the absent fork):
+    a numpy .npz written under the exact name MXNet would use, keys 'arg:name' / 'aux:name'."""
+    if isinstance(data, dict):
+        arrs = {k: v.asnumpy() for k, v in data.items()}
+    else:
+        arrs = {'%d' % i: v.asnumpy() for i, v in enumerate(data)}
+    with open(fname, 'wb') as fh:
+        np.savez(fh, **arrs)
+
+
+def load(fname):
+    with np.load(fname, allow_pickle=False) as z:
+        return {k: NDArray(z[k]) for k in z.files}

@@ -1,0 +1,57 @@
+"""CPU: the executor's lowering pass (formats, fusions, parameter arenas) without launching kernels."""
+import numpy as np
+import torch
+
+import sniper_amd.mx as mx
+from sniper_amd import config as cfgmod
+from sniper_amd.engine.executor import Executor
+from sniper_amd.symbols.faster import resnet_mx_101_e2e as ours
+from sniper_amd.train import fixed_param_names
+
+
+def test_r101_lowering_plan():
+    B = 2
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    net = ours.resnet_mx_101_e2e(momentum=0.995)
+    sym = net.get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, 21 * 32 * 32),
+                  bbox_target=(B, 84, 32, 32), bbox_weight=(B, 84, 32, 32), gt_boxes=(B, 100, 5))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    kinds = {}
+    for s in ex.steps:
+        kinds[type(s).__name__] = kinds.get(type(s).__name__, 0) + 1
+    assert kinds['ConvolutionStep'] == 33 * 3 + 4 + 1 + 3 + 1 + 3 - 3     # bottleneck convs + shortcuts + stem + rpn + conv_new_1 + offsets, minus the 3 deformable conv2
+    assert kinds['DeformableConvolutionStep'] == 3 and kinds['DPSROIPoolStep'] == 2 and kinds['FullyConnectedStep'] == 5
+    bns = [s for s in ex.steps if type(s).__name__ == 'BatchNormStep']
+    assert sum(1 for s in bns if s.relu) == 100 and sum(1 for s in bns if s.is_stem) == 1
+    # loss-side tensors are fp32, everything else fp16 channels-last
+    f32 = sorted(s.node.name for s in ex.steps if type(s).__name__ in ('ConvolutionStep', 'FullyConnectedStep') and s.y.fmt == 'f32')
+    assert f32 == ['bbox_pred', 'cls_score', 'offset', 'rpn_bbox_pred', 'rpn_cls_score']
+    # frozen stem + stage1: no gradients requested there
+    for s in ex.steps:
+        if type(s).__name__ == 'ConvolutionStep' and (s.node.name == 'conv0' or s.node.name.startswith('stage1')):
+            assert not s.y.needs_grad
+        if type(s).__name__ == 'ConvolutionStep' and s.node.name.startswith('stage3'):
+            assert s.y.needs_grad
+    assert abs(ex.n_trainable / 1e6 - 73.48) < 0.05
+    groups = {g[0]: g[2] - g[1] for g in ex.groups}
+    assert set(groups) == {(0.01, 0.0), (0.01, 1.0), (1.0, 0.0), (1.0, 1.0)}      # offset fc lr_mult .01; bias/beta wd 0
+    assert ex.params['fc_new_1_weight'].int_shape == (1024, 49, 256)
+    assert ex.params['rpn_conv_3x3_weight'].int_shape == (512, 9, 3072)
+    # reference <-> kernel layout round trip
+    p = ex.params['fc_new_1_weight']
+    a = np.random.RandomState(0).standard_normal(p.ref_shape).astype(np.float32)
+    assert np.array_equal(p.to_reference(p.to_internal(a)), a)
+    p = ex.params['stage3_unit1_conv2_weight']
+    a = np.random.RandomState(0).standard_normal(p.ref_shape).astype(np.float32)
+    assert np.array_equal(p.to_reference(p.to_internal(a)), a)
+
+
+def test_test_graph_lowers():
+    cfg = cfgmod.res101_e2e(batch_images=2)
+    net = ours.resnet_mx_101_e2e(test_nbatch=2)
+    sym = net.get_symbol_rcnn(cfg, is_train=False)
+    shapes = dict(data=(2, 3, 512, 512), im_info=(2, 3), im_ids=(2,), chip_ids=(2,))
+    ex = Executor(sym, shapes, False, [], device=torch.device('cpu'))
+    assert any(type(s).__name__ == 'MultiProposalStep' for s in ex.steps)
+    assert ex.n_trainable == 0

@@ -1,0 +1,261 @@
+"""-m gpu: the graph executor (sniper_amd.engine) on small graphs against a torch-CPU fp32 autograd
+reference, then the full R101 SNIPER training step, the chip worker and the iterator."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fnn
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import assert_close, f16r  # noqa: E402
+
+
+def _mini_graph(mx, A=3):
+    """stem (bn_data + 7x7/2 conv + bn0 + relu + maxpool) -> pre-activation bottleneck with projection
+    shortcut -> identity bottleneck -> concat -> RPN head -> SoftmaxOutput + smooth-L1 MakeLoss."""
+    data = mx.sym.Variable('data')
+    label, target, weight = mx.sym.Variable('label'), mx.sym.Variable('bbox_target'), mx.sym.Variable('bbox_weight')
+    x = mx.sym.BatchNorm(data=data, name='bn_data', fix_gamma=True, eps=2e-5, use_global_stats=True)
+    x = mx.sym.Convolution(data=x, name='conv0', num_filter=64, kernel=(7, 7), stride=(2, 2), pad=(3, 3), no_bias=True)
+    x = mx.sym.Cast(data=x, dtype=np.float16)
+    x = mx.sym.BatchNorm(data=x, name='bn0', fix_gamma=False, eps=2e-5, use_global_stats=True)
+    x = mx.sym.Activation(data=x, act_type='relu', name='relu0')
+    x = mx.sym.Pooling(data=x, kernel=(3, 3), stride=(2, 2), pad=(1, 1), pool_type='max')
+
+    def unit(x, nf, stride, match, name):
+        a1 = mx.sym.Activation(data=mx.sym.BatchNorm(data=x, name=name + '_bn1', fix_gamma=False, eps=2e-5, momentum=0.9),
+                               act_type='relu', name=name + '_relu1')
+        c1 = mx.sym.Convolution(data=a1, name=name + '_conv1', num_filter=nf // 4, kernel=(1, 1), no_bias=True)
+        a2 = mx.sym.Activation(data=mx.sym.BatchNorm(data=c1, name=name + '_bn2', fix_gamma=False, eps=2e-5, momentum=0.9),
+                               act_type='relu', name=name + '_relu2')
+        c2 = mx.sym.Convolution(data=a2, name=name + '_conv2', num_filter=nf // 4, kernel=(3, 3), stride=(stride, stride),
+                                pad=(1, 1), no_bias=True)
+        a3 = mx.sym.Activation(data=mx.sym.BatchNorm(data=c2, name=name + '_bn3', fix_gamma=False, eps=2e-5, momentum=0.9),
+                               act_type='relu', name=name + '_relu3')
+        c3 = mx.sym.Convolution(data=a3, name=name + '_conv3', num_filter=nf, kernel=(1, 1), no_bias=True)
+        sc = x if match else mx.sym.Convolution(data=a1, name=name + '_sc', num_filter=nf, kernel=(1, 1),
+                                                stride=(stride, stride), no_bias=True)
+        return c3 + sc
+
+    u1 = unit(x, 128, 2, False, 'stage2_unit1')
+    u2 = unit(u1, 128, 1, True, 'stage2_unit2')
+    cat = mx.sym.Cast(data=mx.sym.Concat(u1, u2, name='cat4'), dtype=np.float32)
+    r = mx.sym.Activation(data=mx.sym.Convolution(data=cat, kernel=(3, 3), pad=(1, 1), num_filter=64, name='rpn_conv_3x3'),
+                          act_type='relu', name='rpn_relu')
+    cls = mx.sym.Convolution(data=r, kernel=(1, 1), num_filter=2 * A, name='rpn_cls_score')
+    box = mx.sym.Convolution(data=r, kernel=(1, 1), num_filter=4 * A, name='rpn_bbox_pred')
+    cls_r = mx.sym.Reshape(data=cls, shape=(0, 2, -1, 0), name='rpn_cls_score_reshape')
+    prob = mx.sym.SoftmaxOutput(data=cls_r, label=label, multi_output=True, normalization='valid', use_ignore=True,
+                                ignore_label=-1, name='rpn_cls_prob', grad_scale=100.0)
+    l1 = weight * mx.sym.smooth_l1(name='rpn_bbox_loss_', scalar=1.0, data=(box - target))
+    loss = mx.sym.MakeLoss(name='rpn_bbox_loss', data=l1, grad_scale=3 * 100.0 / 64.0)
+    return mx.sym.Group([prob, loss])
+
+
+def _torch_reference(P, aux, inp, A=3):
+    """fp32 autograd restatement of _mini_graph (weights/activations are what the device holds in fp16
+    only at the input; tolerance covers the fp16 storage of intermediate activations)."""
+    t = {k: torch.from_numpy(f16r(v) if v.ndim > 1 else v.astype(np.float32)).requires_grad_(True) for k, v in P.items()}
+    x = torch.from_numpy(inp['data'])
+
+    def bn_global(x, name, fix_gamma=False):
+        g = torch.ones_like(t[name + '_beta']) if fix_gamma else t[name + '_gamma']
+        m, v = torch.from_numpy(aux[name + '_moving_mean']), torch.from_numpy(aux[name + '_moving_var'])
+        return (x - m[None, :, None, None]) / torch.sqrt(v + 2e-5)[None, :, None, None] * g[None, :, None, None] + \
+            t[name + '_beta'][None, :, None, None]
+
+    x = bn_global(x, 'bn_data', True)
+    x = Fnn.conv2d(x, t['conv0_weight'], None, 2, 3)
+    x = torch.relu(bn_global(x, 'bn0'))
+    x = Fnn.max_pool2d(x, 3, 2, 1)
+
+    def bn(x, name):
+        return torch.relu(Fnn.batch_norm(x, None, None, t[name + '_gamma'], t[name + '_beta'], True, 0.0, 2e-5))
+
+    def unit(x, stride, match, name):
+        a1 = bn(x, name + '_bn1')
+        c1 = Fnn.conv2d(a1, t[name + '_conv1_weight'])
+        c2 = Fnn.conv2d(bn(c1, name + '_bn2'), t[name + '_conv2_weight'], None, stride, 1)
+        c3 = Fnn.conv2d(bn(c2, name + '_bn3'), t[name + '_conv3_weight'])
+        sc = x if match else Fnn.conv2d(a1, t[name + '_sc_weight'], None, stride)
+        return c3 + sc
+
+    u1 = unit(x, 2, False, 'stage2_unit1')
+    u2 = unit(u1, 1, True, 'stage2_unit2')
+    cat = torch.cat((u1, u2), 1)
+    r = torch.relu(Fnn.conv2d(cat, t['rpn_conv_3x3_weight'], t['rpn_conv_3x3_bias'], 1, 1))
+    cls = Fnn.conv2d(r, t['rpn_cls_score_weight'], t['rpn_cls_score_bias'])
+    box = Fnn.conv2d(r, t['rpn_bbox_pred_weight'], t['rpn_bbox_pred_bias'])
+    B, _, F, _ = cls.shape
+    cls_r = cls.reshape(B, 2, A * F, F)
+    prob = torch.softmax(cls_r, 1)
+    lab = torch.from_numpy(inp['label']).reshape(B, A * F, F)
+    valid = lab != -1
+    logp = torch.log_softmax(cls_r, 1)
+    picked = torch.gather(logp, 1, lab.clamp(min=0).long()[:, None])[:, 0]
+    ce = -(picked * valid).sum() / max(1, int(valid.sum())) * 100.0
+    d = box - torch.from_numpy(inp['bbox_target'])
+    sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5) * torch.from_numpy(inp['bbox_weight'])
+    total = ce + sl1.sum() * (3 * 100.0 / 64.0)
+    total.backward()
+    return prob.detach().numpy(), sl1.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else None) for k, v in t.items()}
+
+
+def test_executor_small_graph_vs_torch_autograd():
+    import sniper_amd.mx as mx
+    from sniper_amd.engine.executor import Executor
+    A, B, S = 3, 2, 64
+    sym = _mini_graph(mx, A)
+    F = S // 8
+    shapes = dict(data=(B, 3, S, S), label=(B, A * F * F), bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F))
+    fixed = [n for n in sym.list_arguments() if any(p in n for p in ('conv0', 'bn0', 'bn_data'))]
+    ex = Executor(sym, shapes, True, fixed)
+    rs = np.random.RandomState(0)
+    args, _, auxs = sym.infer_shape(**shapes)
+    P, AUX = {}, {}
+    for name, shp in zip(sym.list_arguments(), args):
+        if name in shapes:
+            continue
+        if name.endswith('_gamma'):
+            P[name] = rs.uniform(0.5, 1.5, shp).astype(np.float32)
+        elif name.endswith('_beta') or name.endswith('_bias'):
+            P[name] = (rs.standard_normal(shp) * 0.1).astype(np.float32)
+        else:
+            P[name] = (rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))).astype(np.float32)
+    for name, shp in zip(sym.list_auxiliary_states(), auxs):
+        AUX[name] = rs.uniform(0.5, 1.5, shp).astype(np.float32) if name.endswith('_var') else \
+            (rs.standard_normal(shp) * 0.1).astype(np.float32)
+    P['bn_data_gamma'][:] = 1.0
+    ex.set_params(P, AUX)
+    inp = dict(data=(rs.standard_normal((B, 3, S, S)) * 2).astype(np.float32),
+               label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.5, 0.3, 0.2]).astype(np.float32),
+               bbox_target=rs.standard_normal((B, 4 * A, F, F)).astype(np.float32),
+               bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.2).astype(np.float32))
+    outs = ex.forward(inp, is_train=True)
+    ex.backward()
+    torch.cuda.synchronize()
+    want_prob, want_l1, want_g = _torch_reference(P, AUX, inp, A)
+    assert_close(outs[0].cpu().numpy(), want_prob, 2e-2, 2e-2, 'rpn_cls_prob')
+    assert_close(outs[1].cpu().numpy(), want_l1, 3e-2, 3e-2 * np.abs(want_l1).max(), 'rpn_bbox_loss')
+    checked = 0
+    for name, p in ex.params.items():
+        if not p.trainable:
+            continue
+        got = p.to_reference(p.grad.detach().cpu().numpy())
+        want = want_g[name]
+        assert want is not None, name
+        # fp16 activations/gradients through 10 layers: 5% of the tensor's scale
+        assert_close(got, want, 5e-2, 5e-2 * np.abs(want).max() + 1e-6, 'grad %s' % name)
+        checked += 1
+    assert checked >= 20
+    # frozen parameters receive nothing, one SGD step moves the trainable ones and refreshes the fp16 copies
+    before = {k: p.master.clone() for k, p in ex.params.items()}
+    ex.update(lr=1e-3, wd=1e-2, momentum=0.9)
+    for k, p in ex.params.items():
+        moved = not torch.equal(before[k], p.master)
+        assert moved == p.trainable, k
+        assert torch.equal(p.w16.float(), p.master.half().float())
+
+
+def test_chip_worker_mirror_golden():
+    """sniper_amd.data.chip_worker (GPU, batched) reproduces the reference's chip_extractor / box_assigner
+    outputs recorded in the golden fixture, when fed the recorded candidate permutations."""
+    import oracle
+    from golden_util import golden_images, ref_cfg
+    from sniper_amd.data.chip_worker import chip_worker
+    cfg = ref_cfg()
+    imgs = golden_images()
+    state = {}
+
+    def perm_fn(key, n):
+        ii, phase, scale = key
+        seed = (7000 if phase == 'pos' else 9000) + ii
+        first = (ii, phase) not in state
+        state[(ii, phase)] = True
+        return oracle.shuffle_perm(n, seed if first else -1)
+
+    cw = chip_worker(cfg, 512, perm_fn=perm_fn)
+    cw.chip_stride = 56
+    roidb = [copy.deepcopy(im['r']) for im in imgs]
+    crops = cw.extract_batch(roidb)
+    for got, im in zip(crops, imgs):
+        assert len(got) == len(im['crops'])
+        for a, b in zip(got, im['crops']):
+            assert np.array_equal(a[0], b[0]) and list(a[1:]) == list(b[1:])
+    for r, c in zip(roidb, crops):
+        r['crops'] = c
+    res = cw.assign_batch(roidb)
+    for (p, nc, npp), im in zip(res, imgs):
+        assert len(p) == len(im['props']) and all(np.array_equal(a, b) for a, b in zip(p, im['props']))
+        assert len(nc) == len(im['neg'])
+        for a, b in zip(nc, im['neg']):
+            assert np.array_equal(a[0], b[0]) and list(a[1:]) == list(b[1:])
+        assert all(np.array_equal(a, b) for a, b in zip(npp, im['negprops']))
+
+
+def test_r101_training_steps():
+    """BASELINE C2 network at 2 chips: the step runs, everything is finite, gradients reach every
+    trainable tensor, frozen tensors stay put and the RPN loss goes down on a repeated batch."""
+    from sniper_amd.train import Trainer
+    tr = Trainer(batch_images=2, n_images=4, seed=0)
+    ex = tr.mod.exe
+    assert abs(ex.n_trainable / 1e6 - 73.5) < 0.3
+    b = tr.batch
+
+    def rpn_ce(outs):
+        p = outs[0].asnumpy()
+        lab = b.label[0].asnumpy().reshape(p.shape[0], -1)
+        p = p.reshape(p.shape[0], 2, -1)
+        m = lab != -1
+        sel = np.where(lab == 1, p[:, 1], p[:, 0])
+        return float(-np.log(sel[m] + 1e-12).mean())
+
+    tr.mod.forward(b, is_train=True)
+    l0 = rpn_ce(tr.mod.get_outputs())
+    tr.mod.backward()
+    torch.cuda.synchronize()
+    g = ex.arena_grad
+    assert torch.isfinite(g).all()
+    nz = 0
+    for name, p in ex.params.items():
+        if p.trainable:
+            assert torch.isfinite(p.grad).all(), name
+            nz += int(float(p.grad.abs().sum()) > 0)
+    assert nz > 0.9 * sum(1 for p in ex.params.values() if p.trainable), nz
+    outs = tr.mod.get_outputs()
+    assert [tuple(o.shape) for o in outs] == [(2, 2, 672, 32), (2, 84, 32, 32), (2, 300, 81), (2, 300, 4), (600,)]
+    for o in outs:
+        assert np.isfinite(o.asnumpy()).all()
+    frozen = {k: p.master.clone() for k, p in ex.params.items() if not p.trainable}
+    tr.cfg.TRAIN.lr = 0.01
+    tr.mod.init_optimizer(optimizer='sgd', optimizer_params={'learning_rate': 1e-4, 'momentum': 0.9, 'wd': 0.01})
+    for _ in range(6):
+        outs = tr.step(b)
+    l1 = rpn_ce(outs)
+    assert np.isfinite(l1) and l1 < l0, (l0, l1)
+    for k, v in frozen.items():
+        assert torch.equal(v, ex.params[k].master), k
+
+
+def test_iterator_contract():
+    import sniper_amd.mx as mx
+    from sniper_amd import config as cfgmod
+    from sniper_amd.iterators import MNIteratorE2E
+    from sniper_amd.synthetic import make_roidb
+    cfg = cfgmod.res101_e2e(batch_images=4)
+    np.random.seed(3)
+    it = MNIteratorE2E(make_roidb(12, seed=3, n_proposals=300), cfg, batch_size=4, nGPUs=1)
+    assert [k for k, _ in it.provide_data] == ['data', 'valid_ranges', 'im_info']
+    assert dict(it.provide_label)['label'] == (4, 21 * 32 * 32) and dict(it.provide_label)['gt_boxes'] == (4, 100, 5)
+    assert len(it) % 4 == 0 and len(it) >= it.n_chips
+    n = 0
+    for batch in it:
+        lab = batch.label[0].asnumpy()
+        assert set(np.unique(lab)).issubset({-1.0, 0.0, 1.0})
+        assert ((lab == 1).sum(1) <= 128).all() and ((lab >= 0).sum(1) <= 256).all()
+        n += 1
+        if n >= 3:
+            break
+    assert n == 3

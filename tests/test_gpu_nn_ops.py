@@ -123,23 +123,26 @@ def test_conv_dgrad_wgrad(case):
     y.backward(torch.from_numpy(f16r(dy)))
     want_dx, want_dw = xt.grad.numpy(), wt.grad.numpy()
     Ho, Wo = y.shape[2], y.shape[3]
-    d_dy = to_nhwc_f16(dy)
+    # the contraction length of dgrad (Cout) must be 8-aligned: dY and W^T are zero padded (RPN heads: 42 -> 48)
+    Op = (O + 7) // 8 * 8
+    d_dy = torch.zeros((N, Ho, Wo, Op), dtype=torch.float16, device=dev())
+    d_dy[..., :O] = to_nhwc_f16(dy)
     # dgrad: weights as [Cin][taps][Cout]
     w_otI = torch.from_numpy(w_to_otI(w)).to(dev())
-    wT = torch.empty((C, K * K, O), dtype=torch.float16, device=dev())
-    hip.call('sn_weight_transpose', w_otI, wT, O, K * K, C, hip.stream())
+    wT = torch.empty((C, K * K, Op), dtype=torch.float16, device=dev())
+    hip.call('sn_weight_transpose', w_otI, wT, O, K * K, C, Op, hip.stream())
     dx = torch.empty((N, H, W, C), dtype=torch.float16, device=dev())
-    hip.call('sn_conv_dgrad', d_dy, wT, None, dx, N, H, W, C, C, O, O, C, K, K, s, p, d, 0, hip.stream())
+    hip.call('sn_conv_dgrad', d_dy, wT, None, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, d, 0, hip.stream())
     torch.cuda.synchronize()
     assert_close(from_nhwc(dx), want_dx, 1e-2, 1e-2 * np.abs(want_dx).max(), 'dgrad %s' % (case,))
     # accumulate form: dx2 = dgrad + dx
     dx2 = dx.clone()
-    hip.call('sn_conv_dgrad', d_dy, wT, dx2, dx2, N, H, W, C, C, O, O, C, K, K, s, p, d, 0, hip.stream())
+    hip.call('sn_conv_dgrad', d_dy, wT, dx2, dx2, N, H, W, C, C, Op, Op, C, K, K, s, p, d, 0, hip.stream())
     torch.cuda.synchronize()
     assert_close(from_nhwc(dx2), 2 * want_dx, 2e-2, 2e-2 * np.abs(want_dx).max(), 'dgrad accumulate')
     # wgrad (+= into zeroed fp32)
     dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=dev())
-    hip.call('sn_conv_wgrad', d_dy, to_nhwc_f16(x), dw, N, H, W, C, C, O, O, K, K, s, p, d, hip.stream())
+    hip.call('sn_conv_wgrad', d_dy, to_nhwc_f16(x), dw, N, H, W, C, C, O, Op, K, K, s, p, d, hip.stream())
     torch.cuda.synchronize()
     got_dw = dw.cpu().numpy().reshape(O, K, K, C).transpose(0, 3, 1, 2)
     assert_close(got_dw, want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'wgrad %s' % (case,))
@@ -309,14 +312,17 @@ def test_sgd_and_weight_transpose():
     w16 = torch.empty(n, dtype=torch.float16, device=dev())
     hip.call('sn_sgd_mom_update', wd, gd, md, w16, n, 0.01, 0.001, 0.9, 1.0, hip.stream())
     nm = 0.9 * m - 0.01 * (g + 0.001 * w)
-    assert_close(md.cpu().numpy(), nm, 1e-6, 1e-7, 'sgd mom')
-    assert_close(wd.cpu().numpy(), w + nm, 1e-6, 1e-7, 'sgd w')
+    assert_close(md.cpu().numpy(), nm, 1e-5, 1e-6, 'sgd mom')
+    assert_close(wd.cpu().numpy(), w + nm, 1e-5, 1e-6, 'sgd w')
     assert torch.equal(w16, wd.half())
     O, T, I = 40, 9, 24
     ww = rs.standard_normal((O, T, I)).astype(np.float32)
     wt = torch.empty((I, T, O), dtype=torch.float16, device=dev())
-    hip.call('sn_weight_transpose', td(ww), wt, O, T, I, hip.stream())
+    hip.call('sn_weight_transpose', td(ww), wt, O, T, I, O, hip.stream())
     assert_close(wt.float().cpu().numpy(), f16r(ww.transpose(2, 1, 0)), 0, 0, 'weight transpose')
+    wp = torch.empty((I, T, 48), dtype=torch.float16, device=dev())
+    hip.call('sn_weight_transpose', td(ww), wp, O, T, I, 48, hip.stream())
+    assert torch.equal(wp[..., :O], wt) and float(wp[..., O:].abs().sum()) == 0
 
 
 def test_multi_proposal_target_vs_oracle():
@@ -414,19 +420,19 @@ def test_deformable_sampling_vs_oracle():
     dd = to_nhwc_f16(data)
     offd = torch.from_numpy(np.ascontiguousarray(off.transpose(0, 2, 3, 1))).to(dev())
     col = torch.empty((N * H * W, T, C), dtype=torch.float16, device=dev())
-    hip.call('sn_deform_im2col', dd, offd, col, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, hip.stream())
+    hip.call('sn_deform_im2col', dd, offd, col, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, hip.stream())
     want = onn.deform_im2col(f16r(data).astype(np.float64), off.astype(np.float64), KH, KW, 1, 2, 2, DG)
     assert_close(col.float().cpu().numpy().reshape(N, H, W, T, C), want, 1e-2, 1e-2, 'deform im2col')
     # zero offsets == plain dilated im2col
     col0 = torch.empty_like(col)
-    hip.call('sn_deform_im2col', dd, torch.zeros_like(offd), col0, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, hip.stream())
+    hip.call('sn_deform_im2col', dd, torch.zeros_like(offd).half(), col0, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 0, hip.stream())
     unf = Fnn.unfold(torch.from_numpy(f16r(data)), 3, dilation=2, padding=2).numpy().reshape(N, C, T, H, W)
     assert_close(col0.float().cpu().numpy().reshape(N, H, W, T, C), unf.transpose(0, 3, 4, 2, 1), 1e-3, 1e-3, 'deform zero offset')
     dcol = rs.standard_normal((N, H, W, T, C)).astype(np.float32)
     d_data = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev())
     d_off = torch.zeros((N, H, W, 2 * T * DG), dtype=torch.float32, device=dev())
     hip.call('sn_deform_col2im', torch.from_numpy(dcol).to(dev()).half(), dd, offd, d_data, d_off, N, H, W, C, KH, KW, 1, 2, 2, DG,
-             2 * T * DG, hip.stream())
+             2 * T * DG, 1, hip.stream())
     wdata, woff = onn.deform_col2im(f16r(dcol).astype(np.float64), f16r(data).astype(np.float64), off.astype(np.float64), KH, KW, 1, 2, 2, DG)
     assert_close(d_data.cpu().numpy().transpose(0, 3, 1, 2), wdata, 1e-3, 1e-3 * np.abs(wdata).max(), 'deform d_data')
     assert_close(d_off.cpu().numpy().transpose(0, 3, 1, 2), woff, 1e-3, 1e-3 * np.abs(woff).max(), 'deform d_offset')

@@ -1,0 +1,100 @@
+"""Graph-level checks (CPU): our network definitions build on the mx shim, infer the BASELINE shapes,
+and -- where the reference checkout is present -- have exactly the arguments / auxiliary states /
+outputs / shapes that the reference's own symbol file produces when run over the same shim."""
+import sys
+
+import numpy as np
+import pytest
+
+from sniper_amd import config as cfgmod
+from sniper_amd.symbols.faster import resnet_mx_101_e2e as ours
+
+
+def _shapes(B, A=21, F=32, train=True):
+    if train:
+        return dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                    bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5))
+    return dict(data=(B, 3, 512, 512), im_info=(B, 3), im_ids=(B,), chip_ids=(B,))
+
+
+def _cfg(B):
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    cfg.TRAIN.ENABLE_OHEM = False
+    return cfg
+
+
+def test_r101_train_graph_shapes():
+    B = 2
+    cfg = _cfg(B)
+    net = ours.resnet_mx_101_e2e(n_proposals=400, momentum=0.995)
+    sym = net.get_symbol_rcnn(cfg)
+    assert sym.list_outputs() == ['rpn_cls_prob_output', 'rpn_bbox_loss_output', 'cls_prob_reshape_output',
+                                  'bbox_loss_reshape_output', 'blockgrad0_output']
+    net.infer_shape(_shapes(B))
+    assert net.out_shape_dict['rpn_cls_prob_output'] == (B, 2, 21 * 32, 32)
+    assert net.out_shape_dict['cls_prob_reshape_output'] == (B, 300, 81)
+    assert net.arg_shape_dict['conv0_weight'] == (64, 3, 7, 7)
+    assert net.arg_shape_dict['rpn_conv_3x3_weight'] == (512, 3072, 3, 3)
+    assert net.arg_shape_dict['fc_new_1_weight'] == (1024, 256 * 49)
+    assert net.arg_shape_dict['stage4_unit1_offset_weight'] == (72, 512, 3, 3)
+    n = sum(int(np.prod(s)) for k, s in net.arg_shape_dict.items() if k not in _shapes(B))
+    assert abs(n / 1e6 - 73.7) < 0.1          # 73.5 M trainable + frozen stem
+    params, aux = {}, {}
+    net.init_weight_rcnn(cfg, params, aux)
+    assert float(np.abs(params['offset_weight'].asnumpy()).sum()) == 0 and params['fc_new_1_weight'].shape == (1024, 12544)
+
+
+def test_r101_test_and_rpn_graphs():
+    cfg = _cfg(2)
+    net = ours.resnet_mx_101_e2e(test_nbatch=2)
+    sym = net.get_symbol_rcnn(cfg, is_train=False)
+    assert sym.list_outputs() == ['rois_output', 'cls_prob_reshape_output', 'bbox_pred_reshape_output', 'im_ids', 'im_info',
+                                  'chip_ids']
+    net.infer_shape(_shapes(2, train=False))
+    assert net.out_shape_dict['rois_output'] == (600, 5) and net.out_shape_dict['cls_prob_reshape_output'] == (2, 300, 81)
+    cfg.TEST.AUTO_FOCUS = True
+    sym = net.get_symbol_rcnn(cfg, is_train=False)
+    assert 'scale_prob_output' in sym.list_outputs()
+    rpn = net.get_symbol_rpn(_cfg(2))
+    assert rpn.list_outputs() == ['rpn_cls_prob_output', 'rpn_bbox_loss_output']
+
+
+@pytest.mark.ref
+def test_same_graph_as_reference_symbol_file():
+    import sniper_amd.mx as mx
+    mx.alias_as('mxnet')
+    for p in ('/root/reference', '/root/reference/lib', '/root/reference/symbols/faster'):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import importlib
+    sys.dont_write_bytecode = True
+    refmod = importlib.import_module('resnet_mx_101_e2e')
+    B = 2
+    for train in (True, False):
+        cfg = _cfg(B)
+        a = refmod.resnet_mx_101_e2e(n_proposals=400, momentum=0.995, test_nbatch=B)
+        b = ours.resnet_mx_101_e2e(n_proposals=400, momentum=0.995, test_nbatch=B)
+        from sniper_amd.mx import symbol as _symmod
+        _symmod._counter().clear()          # auto-names (blockgrad0, _plus0, pooling0 ...) count per graph build
+        sa = a.get_symbol_rcnn(cfg, is_train=train)
+        _symmod._counter().clear()
+        sb = b.get_symbol_rcnn(cfg, is_train=train)
+        assert sa.list_outputs() == sb.list_outputs()
+        assert sorted(sa.list_arguments()) == sorted(sb.list_arguments())
+        assert sorted(sa.list_auxiliary_states()) == sorted(sb.list_auxiliary_states())
+        a.infer_shape(_shapes(B, train=train))
+        b.infer_shape(_shapes(B, train=train))
+        assert a.arg_shape_dict == b.arg_shape_dict and a.out_shape_dict == b.out_shape_dict
+        assert a.aux_shape_dict == b.aux_shape_dict
+        # node-for-node: same operators with the same attributes in the same topological order
+        dflt = {'dilate': '(1, 1)', 'stride': '(1, 1)', 'pad': '(0, 0)'}
+
+        def norm(n):
+            kv = [(k, str(tuple(v)) if isinstance(v, (list, tuple)) else str(v)) for k, v in n.attrs.items()
+                  if k not in ('workspace', 'cudnn_off')]
+            return (n.op, n.name, sorted((k, v) for k, v in kv if dflt.get(k) != v))
+
+        na = [norm(n) for n in sa._topo() if n.op]
+        nb = [norm(n) for n in sb._topo() if n.op]
+        assert len(na) == len(nb)
+        assert sorted(na) == sorted(nb)

@@ -1,18 +1,36 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, micro-benchmarks, rocprof stats.  Everything lands in gpurun_out/.
+# One GPU-box visit: parity tests, smoke, bench, rocprof stats.  Everything lands in gpurun_out/.
+# usage: tools/gpu_session.sh [tests|bench|micro|all]   (default all)
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 ROOT=$(pwd)
+WHAT=${1:-all}
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.txt
 nproc >> gpurun_out/device.txt
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -n 1 --timeout 600 > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
-tail -40 gpurun_out/pytest_gpu.log
-timeout 600 python tools/microbench.py > gpurun_out/microbench.log 2>&1
-echo "microbench exit $?" >> gpurun_out/microbench.log
-cat gpurun_out/microbench.log
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/prof_micro" -o micro -- python "$ROOT/tools/microbench.py" --quick > "$ROOT/gpurun_out/rocprof_micro.log" 2>&1
-echo "rocprof exit $?"
-find "$ROOT/gpurun_out/prof_micro" -name "*stats*" | head
+if [[ $WHAT == all || $WHAT == tests ]]; then
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -n 1 --timeout 900 > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+  tail -60 gpurun_out/pytest_gpu.log
+  timeout 900 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
+  echo "smoke exit $?" >> gpurun_out/smoke.log
+  tail -5 gpurun_out/smoke.log
+fi
+if [[ $WHAT == all || $WHAT == micro ]]; then
+  timeout 600 python tools/microbench.py > gpurun_out/microbench.log 2>&1
+  echo "microbench exit $?" >> gpurun_out/microbench.log
+  cat gpurun_out/microbench.log
+fi
+if [[ $WHAT == all || $WHAT == bench ]]; then
+  timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
+  echo "bench exit $?" >> gpurun_out/bench.log
+  tail -5 gpurun_out/bench.log
+  cd /tmp && export TMPDIR=/tmp
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_bench" -o bench -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$ROOT/gpurun_out/rocprof_bench.log" 2>&1
+  echo "rocprof exit $?"
+  find "$ROOT/gpurun_out/prof_bench" -name "*stats*" | head
+  F=$(find "$ROOT/gpurun_out/prof_bench" -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && head -40 "$F"
+  # the raw kernel trace is large; keep only the stats
+  find "$ROOT/gpurun_out/prof_bench" -name "*kernel_trace.csv" -size +20M -delete
+fi
