@@ -182,19 +182,22 @@ int sn_multi_proposal_target(const float *cls_prob, const float *bbox_pred, cons
                              float *bbox_weight, sn_stream_t stream);
 
 /* DeformablePSROIPooling, group_size 1 (:286-293).  data (B,H,W,C) fp16, rois (R,5), trans (R,2,P,P) or NULL,
- * out (R,P,P,C) fp16.  Backward scatters into zeroed fp32 d_data / d_trans. */
+ * out (R,P,P,C) fp16.  Backward: d_data (B,H,W,C) fp16 (d_data_f32 = 0) or fp32 and d_trans (R,2,P,P) fp32 are
+ * OVERWRITTEN (every element written exactly once, no atomics); ws = sn_dpsroi_bwd_workspace_bytes(R). */
 int sn_dpsroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int C, int pooled,
                        int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream);
-int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, float *d_data, float *d_trans,
-                       int R, int H, int W, int C, int pooled, int sample_per_part, float spatial_scale, float trans_std,
-                       sn_stream_t stream);
+size_t sn_dpsroi_bwd_workspace_bytes(int R);
+int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data, int d_data_f32,
+                       float *d_trans, int R, int B, int H, int W, int C, int pooled, int sample_per_part, float spatial_scale,
+                       float trans_std, void *ws, sn_stream_t stream);
 
-/* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward. */
+/* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward:
+ * d_data (N,H,W,C) fp16/fp32 and d_offset (same layout/dtype as offset) are OVERWRITTEN; either may be NULL. */
 int sn_deform_im2col(const void *data, const void *offset, void *col, int N, int H, int W, int C, int KH, int KW, int stride,
                      int pad, int dil, int deformable_groups, int offset_pix_stride, int offset_dtype, sn_stream_t stream);
-int sn_deform_col2im(const void *dcol, const void *data, const void *offset, float *d_data, void *d_offset, int N, int H, int W,
-                     int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups, int offset_pix_stride,
-                     int offset_dtype, sn_stream_t stream);
+int sn_deform_col2im(const void *dcol, const void *data, const void *offset, void *d_data, int d_data_f32, void *d_offset, int N,
+                     int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                     int offset_pix_stride, int offset_dtype, sn_stream_t stream);
 
 /* Multi-precision SGD with momentum (lib/train_utils/utils.py:26-33). */
 int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void *w16, long n, float lr, float wd, float momentum,

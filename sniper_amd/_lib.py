@@ -62,6 +62,11 @@ class _Lib(object):
         if not os.path.exists(LIB_PATH):
             raise ImportError("libsniper_hip.so not built (%s); run `python -m sniper_amd.build` -- there is no "
                               "CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 (same sonames as /opt/rocm's).  Whichever is
+        # mapped first serves the whole process; two different runtimes in one process leave the second without a
+        # device ("no ROCm-capable device is detected").  torch owns device memory and streams here, so its runtime
+        # must be the one: load it before the kernel library resolves its DT_NEEDED entries.
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         missing = []

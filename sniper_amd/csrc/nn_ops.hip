@@ -52,50 +52,93 @@ SN_EXPORT int sn_pack_stem_input(const float *x_nchw, void *out, int N, int C, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// BatchNorm.  x is (M pixels, C channels) fp16 with pixel stride ps; C/8 must divide 256.
-// Thread t owns the 8-channel chunk t % (C/8) and walks rows t / (C/8), +256/(C/8), ...
-//   bn_stats    : per-channel sum and sum of squares -> fp64 accumulators (atomic, caller zeroes)
+// BatchNorm.  x is (M pixels, C channels) fp16 with pixel stride ps, C % 8 == 0.
+// Row-walking kernels (stats, backward reduce, backward dx) share one mapping: a block covers up to 256 8-channel
+// chunks (blockIdx.y selects the slab when C > 2048); thread t owns chunk t % CB for its whole life -- per-channel
+// coefficients live in registers -- and walks rows t / CB, + rpp, ... of the block's row range with 4 independent
+// 16-byte loads in flight (HBM-bound: bytes in flight per CU decide the rate, guide section "memory").
+//   bn_stats    : per-channel sum and sum of squares -> fp64 accumulators (one atomic per block and channel)
 //   bn_finalize : mean/var -> scale = gamma*invstd, shift = beta - mean*scale; running stats
 //   bn_apply    : y = relu?(x*scale + shift)
 //   bn_bwd_reduce / bn_bwd_dx : gradients through (ReLU o BN) in training mode
 // BatchNorm(fix_gamma=False, eps=2e-5, momentum) call sites: resnet_mx_101_e2e.py:38-58.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBnThreads = 256;
+constexpr int kBnUnroll = 4;
+
+struct BnMap {
+  int cb, rpp, chunk, rl;
+  bool on;
+};
+__device__ __forceinline__ BnMap bn_map(int C) {
+  const int cpr = C >> 3;
+  BnMap m;
+  m.cb = cpr < kBnThreads ? cpr : kBnThreads;
+  m.rpp = kBnThreads / m.cb;
+  m.rl = threadIdx.x / m.cb;
+  m.chunk = blockIdx.y * kBnThreads + (int)(threadIdx.x - m.rl * m.cb);
+  m.on = m.rl < m.rpp && m.chunk < cpr;
+  return m;
+}
+
+// block-level reduction of 16 per-thread partials over the row lanes, then `emit(channel, j, value)`
+template <typename F>
+__device__ __forceinline__ void bn_block_reduce(const BnMap &m, int C, const float s[8], const float q[8], F emit) {
+  __shared__ float red[kBnThreads][17];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[threadIdx.x][j] = m.on ? s[j] : 0.f;
+    red[threadIdx.x][8 + j] = m.on ? q[j] : 0.f;
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  for (int w = threadIdx.x; w < m.cb * 16; w += kBnThreads) {
+    const int ch = w >> 4, j = w & 15;
+    if (blockIdx.y * kBnThreads + ch >= cpr) continue;
+    float a = 0.f;
+    for (int k = 0; k < m.rpp; ++k) a += red[k * m.cb + ch][j];
+    emit((blockIdx.y * kBnThreads + ch) * 8 + (j & 7), j, a);
+  }
+}
 
 __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const half_t *__restrict__ x, int M, int C, int ps,
                                                               int rows_per_block, double *__restrict__ sum,
                                                               double *__restrict__ sumsq) {
-  const int cpr = C >> 3, rpp = kBnThreads / cpr;
-  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const BnMap m = bn_map(C);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-  for (int r = r0 + rl; r < r1; r += rpp) {
-    const half8 v = *reinterpret_cast<const half8 *>(x + (size_t)r * ps + chunk * 8);
+  if (m.on) {
+    const half_t *px = x + m.chunk * 8;
+    int r = r0 + m.rl;
+    for (; r + (kBnUnroll - 1) * m.rpp < r1; r += kBnUnroll * m.rpp) {
+      half8 v[kBnUnroll];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = (float)v[j];
-      s[j] += f;
-      q[j] += f * f;
+      for (int u = 0; u < kBnUnroll; ++u) v[u] = *reinterpret_cast<const half8 *>(px + (size_t)(r + u * m.rpp) * ps);
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[u][j];
+          s[j] += f;
+          q[j] += f * f;
+        }
+    }
+    for (; r < r1; r += m.rpp) {
+      const half8 v = *reinterpret_cast<const half8 *>(px + (size_t)r * ps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        s[j] += f;
+        q[j] += f * f;
+      }
     }
   }
-  __shared__ float red[kBnThreads][17];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    red[threadIdx.x][j] = s[j];
-    red[threadIdx.x][8 + j] = q[j];
-  }
-  __syncthreads();
-  // thread (chunk, j) for j < 16 sums over row-lanes: cpr*16 <= 4096 work items over 256 threads
-  for (int w = threadIdx.x; w < cpr * 16; w += kBnThreads) {
-    const int ch = w >> 4, j = w & 15;
-    float a = 0.f;
-    for (int k = 0; k < rpp; ++k) a += red[k * cpr + ch][j];
-    const int c = ch * 8 + (j & 7);
+  bn_block_reduce(m, C, s, q, [&](int c, int j, float a) {
     if (j < 8) atomicAdd(&sum[c], (double)a);
     else atomicAdd(&sumsq[c], (double)a);
-  }
+  });
 }
 
 __global__ void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq, int M, int C, float eps,
@@ -160,76 +203,101 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
                                                                    const float *__restrict__ mean,
                                                                    const float *__restrict__ invstd, int relu,
                                                                    double *__restrict__ dgamma, double *__restrict__ dbeta) {
-  const int cpr = C >> 3, rpp = kBnThreads / cpr;
-  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const BnMap m = bn_map(C);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float sc[8], sh[8], mu[8], is[8], s[8], q[8];
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  if (m.on) {
+    float sc[8], sh[8], mu[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = m.chunk * 8 + j;
+      sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c];
+    }
+    const half_t *pg = dy + m.chunk * 8, *px = x + m.chunk * 8;
+    auto body = [&](const half8 &g, const half8 &v) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xf = (float)v[j];
+        float gf = (float)g[j];
+        if (relu && !(xf * sc[j] + sh[j] > 0.f)) gf = 0.f;
+        s[j] += gf;
+        q[j] += gf * (xf - mu[j]);
+      }
+    };
+    int r = r0 + m.rl;
+    for (; r + (kBnUnroll - 1) * m.rpp < r1; r += kBnUnroll * m.rpp) {
+      half8 g[kBnUnroll], v[kBnUnroll];
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) {
+        g[u] = *reinterpret_cast<const half8 *>(pg + (size_t)(r + u * m.rpp) * ps_dy);
+        v[u] = *reinterpret_cast<const half8 *>(px + (size_t)(r + u * m.rpp) * ps_x);
+      }
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) body(g[u], v[u]);
+    }
+    for (; r < r1; r += m.rpp)
+      body(*reinterpret_cast<const half8 *>(pg + (size_t)r * ps_dy), *reinterpret_cast<const half8 *>(px + (size_t)r * ps_x));
+  }
+  bn_block_reduce(m, C, s, q, [&](int c, int j, float a) {
+    if (j < 8) atomicAdd(&dbeta[c], (double)a);
+    else atomicAdd(&dgamma[c], (double)(a * invstd[c]));
+  });
+}
+
+// dx = scale * (g - dbeta/M - xhat*dgamma/M) [+ acc] = ka*g + kb*x + kd with three per-channel registers
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__restrict__ dy, const half_t *__restrict__ x,
+                                                               const half_t *__restrict__ acc, half_t *__restrict__ dx, int M,
+                                                               int C, int ps_dy, int ps_x, int ps_acc, int ps_dx,
+                                                               int rows_per_block, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, const float *__restrict__ mean,
+                                                               const float *__restrict__ invstd,
+                                                               const double *__restrict__ dgamma,
+                                                               const double *__restrict__ dbeta, int relu) {
+  const BnMap m = bn_map(C);
+  if (!m.on) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  const float invM = 1.f / (float)M;
+  float sc[8], sh[8], kb[8], kd[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = chunk * 8 + j;
-    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
-    s[j] = q[j] = 0.f;
+    const int c = m.chunk * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c];
+    const float t = invstd[c] * (float)dgamma[c] * invM;   // xhat coefficient / scale
+    kb[j] = -sc[j] * t;
+    kd[j] = sc[j] * (mean[c] * t - (float)dbeta[c] * invM);
   }
-  for (int r = r0 + rl; r < r1; r += rpp) {
-    const half8 g = *reinterpret_cast<const half8 *>(dy + (size_t)r * ps_dy + chunk * 8);
-    const half8 v = *reinterpret_cast<const half8 *>(x + (size_t)r * ps_x + chunk * 8);
+  const half_t *pg = dy + m.chunk * 8, *px = x + m.chunk * 8, *pa = acc ? acc + m.chunk * 8 : nullptr;
+  half_t *po = dx + m.chunk * 8;
+  auto body = [&](const half8 &g, const half8 &v, const half8 &a, size_t r) {
+    half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xf = (float)v[j];
       float gf = (float)g[j];
       if (relu && !(xf * sc[j] + sh[j] > 0.f)) gf = 0.f;
-      s[j] += gf;
-      q[j] += gf * (xf - mu[j]) * is[j];
+      o[j] = (half_t)(sc[j] * gf + kb[j] * xf + kd[j] + (float)a[j]);
     }
-  }
-  __shared__ float red[kBnThreads][17];
+    *reinterpret_cast<half8 *>(po + r * ps_dx) = o;
+  };
+  const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  int r = r0 + m.rl;
+  for (; r + (kBnUnroll - 1) * m.rpp < r1; r += kBnUnroll * m.rpp) {
+    half8 g[kBnUnroll], v[kBnUnroll], a[kBnUnroll];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    red[threadIdx.x][j] = s[j];
-    red[threadIdx.x][8 + j] = q[j];
-  }
-  __syncthreads();
-  for (int w = threadIdx.x; w < cpr * 16; w += kBnThreads) {
-    const int ch = w >> 4, j = w & 15;
-    float a = 0.f;
-    for (int k = 0; k < rpp; ++k) a += red[k * cpr + ch][j];
-    const int c = ch * 8 + (j & 7);
-    if (j < 8) atomicAdd(&dbeta[c], (double)a);
-    else atomicAdd(&dgamma[c], (double)a);
-  }
-}
-
-// dx = scale * (g - dbeta/M - xhat*dgamma/M) [+ acc]; also emits fp32 dgamma/dbeta for the optimizer
-__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const half_t *__restrict__ dy, const half_t *__restrict__ x,
-                                                        const half_t *__restrict__ acc, half_t *__restrict__ dx, int M, int C,
-                                                        int ps_dy, int ps_x, int ps_acc, int ps_dx,
-                                                        const float *__restrict__ scale, const float *__restrict__ shift,
-                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                        const double *__restrict__ dgamma, const double *__restrict__ dbeta,
-                                                        int relu) {
-  const int cpr = C >> 3;
-  const long total = (long)M * cpr;
-  const float invM = 1.f / (float)M;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int chunk = (int)(i % cpr);
-    const long r = i / cpr;
-    const half8 g = *reinterpret_cast<const half8 *>(dy + r * ps_dy + chunk * 8);
-    const half8 v = *reinterpret_cast<const half8 *>(x + r * ps_x + chunk * 8);
-    half8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (acc) a = *reinterpret_cast<const half8 *>(acc + r * ps_acc + chunk * 8);
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = chunk * 8 + j;
-      const float xf = (float)v[j];
-      float gf = (float)g[j];
-      if (relu && !(xf * scale[c] + shift[c] > 0.f)) gf = 0.f;
-      const float xhat = (xf - mean[c]) * invstd[c];
-      const float d = scale[c] * (gf - (float)dbeta[c] * invM - xhat * (float)dgamma[c] * invM);
-      o[j] = (half_t)(d + (float)a[j]);
+    for (int u = 0; u < kBnUnroll; ++u) {
+      const size_t rr = (size_t)(r + u * m.rpp);
+      g[u] = *reinterpret_cast<const half8 *>(pg + rr * ps_dy);
+      v[u] = *reinterpret_cast<const half8 *>(px + rr * ps_x);
+      a[u] = pa ? *reinterpret_cast<const half8 *>(pa + rr * ps_acc) : zero;
     }
-    *reinterpret_cast<half8 *>(dx + r * ps_dx + chunk * 8) = o;
+#pragma unroll
+    for (int u = 0; u < kBnUnroll; ++u) body(g[u], v[u], a[u], (size_t)(r + u * m.rpp));
   }
+  for (; r < r1; r += m.rpp)
+    body(*reinterpret_cast<const half8 *>(pg + (size_t)r * ps_dy), *reinterpret_cast<const half8 *>(px + (size_t)r * ps_x),
+         pa ? *reinterpret_cast<const half8 *>(pa + (size_t)r * ps_acc) : zero, (size_t)r);
 }
 
 __global__ void f64_to_f32_accum_kernel(const double *__restrict__ a, float *__restrict__ out, int n, float mul) {
@@ -237,24 +305,29 @@ __global__ void f64_to_f32_accum_kernel(const double *__restrict__ a, float *__r
   if (i < n) out[i] += (float)a[i] * mul;
 }
 
-static int bn_shape_ok(int C) { return C >= 64 && C % 8 == 0 && (256 % (C / 8)) == 0; }
+static int bn_shape_ok(int C) { return C >= 8 && C % 8 == 0; }
+// grid of the row-walking BN kernels: x = row blocks (>= kBnUnroll*2 rows per thread, at most `cap` blocks so that the
+// per-block fp64 atomics stay few), y = 256-chunk slabs
+static dim3 bn_grid(int M, int C, int cap, int *rows_per_block) {
+  const int cpr = C / 8, cb = cpr < kBnThreads ? cpr : kBnThreads, rpp = kBnThreads / cb;
+  int blocks = sn_div_up(M, rpp * kBnUnroll * 2);
+  if (blocks > cap) blocks = cap;
+  *rows_per_block = sn_div_up(sn_div_up(M, blocks), rpp) * rpp;
+  return dim3(sn_div_up(M, *rows_per_block), sn_div_up(cpr, kBnThreads));
+}
 static int ew_blocks(long total) {
   long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
 SN_EXPORT int sn_bn_stats(const void *x, int M, int C, int ps, double *sum, double *sumsq, sn_stream_t stream) {
-  SN_REQUIRE(x && sum && sumsq && M > 0 && bn_shape_ok(C), "sn_bn_stats: C=%d unsupported (C/8 must divide 256)", C);
+  SN_REQUIRE(x && sum && sumsq && M > 0 && bn_shape_ok(C), "sn_bn_stats: C=%d unsupported (C %% 8 != 0)", C);
   hipStream_t s = sn_stream(stream);
   SN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * C, s));
   SN_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * C, s));
-  const int rpp = kBnThreads / (C / 8);
-  int blocks = sn_div_up(M, rpp * 8);  // >= 8 rows per thread
-  if (blocks > 2048) blocks = 2048;
-  const int rows_per_block = sn_div_up(M, blocks);
-  blocks = sn_div_up(M, rows_per_block);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(kBnThreads), 0, s, (const half_t *)x, M, C, ps, rows_per_block, sum,
-                     sumsq);
+  int rows_per_block;
+  const dim3 grid = bn_grid(M, C, 1024, &rows_per_block);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)x, M, C, ps, rows_per_block, sum, sumsq);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
@@ -297,18 +370,16 @@ SN_EXPORT int sn_bn_backward(const void *dy, const void *x, const void *accumula
              "sn_bn_backward: bad arguments (C=%d)", C);
   hipStream_t s = sn_stream(stream);
   SN_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s));
-  const int rpp = kBnThreads / (C / 8);
-  int blocks = sn_div_up(M, rpp * 8);
-  if (blocks > 2048) blocks = 2048;
-  const int rows_per_block = sn_div_up(M, blocks);
-  blocks = sn_div_up(M, rows_per_block);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x, M, C,
-                     ps_dy, ps_x, rows_per_block, scale, shift, mean, invstd, relu, ws, ws + C);
+  int rows_per_block;
+  dim3 grid = bn_grid(M, C, 1024, &rows_per_block);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x, M, C, ps_dy,
+                     ps_x, rows_per_block, scale, shift, mean, invstd, relu, ws, ws + C);
   SN_CHECK_LAUNCH();
   if (dx) {
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks((long)M * (C / 8))), dim3(256), 0, s, (const half_t *)dy,
-                       (const half_t *)x, (const half_t *)accumulate, (half_t *)dx, M, C, ps_dy, ps_x, ps_acc, ps_dx, scale,
-                       shift, mean, invstd, ws, ws + C, relu);
+    grid = bn_grid(M, C, 8192, &rows_per_block);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x,
+                       (const half_t *)accumulate, (half_t *)dx, M, C, ps_dy, ps_x, ps_acc, ps_dx, rows_per_block, scale, shift,
+                       mean, invstd, ws, ws + C, relu);
     SN_CHECK_LAUNCH();
   }
   if (dgamma) {

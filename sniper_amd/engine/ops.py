@@ -415,14 +415,12 @@ class DeformableConvolutionStep(Step):
         if self.x.needs_grad or self.off.needs_grad:
             dcol = ex.empty((M, K), F16)
             hip.call('sn_conv_dgrad', dy, self.wT_flat, None, dcol, M, 1, 1, K, K, Op, Op, K, 1, 1, 1, 0, 1, 0, hip.stream())
-            d_data = ex.zeros((self.N, self.H, self.W, self.C), F32)
             oc = self.off.shape[1]
-            d_off = ex.empty((self.N, self.Ho, self.Wo, oc), F16)
-            hip.call('sn_deform_col2im', dcol, ex.as_act(self.x), ex.as_act(self.off), d_data, d_off, self.N, self.H, self.W,
+            d16 = ex.empty((self.N, self.H, self.W, self.C), F16) if self.x.needs_grad else None
+            d_off = ex.empty((self.N, self.Ho, self.Wo, oc), F16) if self.off.needs_grad else None
+            hip.call('sn_deform_col2im', dcol, ex.as_act(self.x), ex.as_act(self.off), d16, 0, d_off, self.N, self.H, self.W,
                      self.C, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], self.dg, oc, 0, hip.stream())
             if self.x.needs_grad:
-                d16 = ex.empty((self.N, self.H, self.W, self.C), F16)
-                hip.call('sn_copy2d', d_data, d16, 1, d_data.numel(), d_data.numel(), d_data.numel(), 1, 0, hip.stream())
                 ex.add_grad(self.x, d16, 'act')
             if self.off.needs_grad:
                 ex.add_grad(self.off, d_off, 'act')
@@ -793,6 +791,7 @@ class DPSROIPoolStep(Step):
         self.tstd = float(a.get('trans_std', 0.0))
         self.y = self.new_out('act')
         self.y.needs_grad = self.x.needs_grad or (self.trans is not None and self.trans.needs_grad)
+        self.ws = None
 
     def forward(self):
         ex = self.ex
@@ -807,14 +806,14 @@ class DPSROIPoolStep(Step):
             return
         n, h, w, c = self.x.nhwc()
         R = self.rois.shape[0]
-        d_data = ex.zeros((n, h, w, c), F32)
-        d_trans = ex.zeros(self.trans.shape, F32) if self.trans is not None else None
+        d16 = ex.empty((n, h, w, c), F16)
+        d_trans = ex.empty(self.trans.shape, F32) if self.trans is not None else None
+        if self.ws is None:
+            self.ws = ex.empty((hip.query('sn_dpsroi_bwd_workspace_bytes', R),), torch.uint8)
         hip.call('sn_dpsroi_pool_bwd', self.y.grad, ex.as_act(self.x), ex.as_f32(self.rois),
-                 ex.as_f32(self.trans) if self.trans else None, d_data, d_trans, R, h, w, c, self.P, self.S, self.scale, self.tstd,
-                 hip.stream())
+                 ex.as_f32(self.trans) if self.trans else None, d16, 0, d_trans, R, n, h, w, c, self.P, self.S, self.scale,
+                 self.tstd, self.ws, hip.stream())
         if self.x.needs_grad:
-            d16 = ex.empty((n, h, w, c), F16)
-            hip.call('sn_copy2d', d_data, d16, 1, d_data.numel(), d_data.numel(), d_data.numel(), 1, 0, hip.stream())
             ex.add_grad(self.x, d16, 'act')
         if self.trans is not None and self.trans.needs_grad:
             ex.add_grad(self.trans, d_trans, 'f32')

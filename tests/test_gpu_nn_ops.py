@@ -178,7 +178,9 @@ def test_fc_as_conv_and_bias_grad():
 def test_batchnorm_train_fwd_bwd():
     hip = _hip()
     rs = np.random.RandomState(3)
-    for (N, C, H, W, relu) in ((4, 256, 16, 16, 1), (2, 64, 9, 7, 0), (3, 2048, 4, 4, 1)):
+    # C/8 = 32, 8, 256 (one slab), 4, 3, 12 (MobileNetV2 widths: not divisors of 256), 320 (two slabs), many rows
+    for (N, C, H, W, relu) in ((4, 256, 16, 16, 1), (2, 64, 9, 7, 0), (3, 2048, 4, 4, 1), (2, 32, 5, 6, 1), (2, 24, 7, 3, 0),
+                               (1, 96, 11, 5, 1), (2, 2560, 3, 3, 1), (8, 128, 40, 40, 1)):
         x = (rs.standard_normal((N, C, H, W)) * 2 + 0.5).astype(np.float32)
         gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), rs.standard_normal(C).astype(np.float32) * 0.1
         dy = rs.standard_normal((N, C, H, W)).astype(np.float32)
@@ -378,45 +380,58 @@ def test_multi_proposal_target_vs_oracle():
     assert (sc.view(B, post)[:, :-1] >= sc.view(B, post)[:, 1:]).float().mean() > 0.95
 
 
-def test_dpsroi_pool_fwd_bwd_vs_oracle():
+@pytest.mark.parametrize('B,C,H,W,R', [(2, 64, 12, 12, 9), (3, 256, 10, 14, 40)])
+def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R):
     hip = _hip()
     rs = np.random.RandomState(9)
-    B, C, H, W, R, P, S = 2, 64, 12, 12, 9, 7, 4
+    P, S = 7, 4
     data = rs.standard_normal((B, C, H, W)).astype(np.float32)
     rois = np.zeros((R, 5), np.float32)
     rois[:, 0] = rs.randint(0, B, R)
-    c = rs.uniform(20, 170, (R, 2))
-    wh = rs.uniform(10, 120, (R, 2))
+    c = rs.uniform(20, 16 * min(H, W) - 20, (R, 2))
+    wh = rs.uniform(4, 120, (R, 2))
     rois[:, 1:3], rois[:, 3:5] = c - wh / 2, c + wh / 2
     rois[0, 1:] = [-30, -20, 40, 50]   # partly outside
+    rois[1, 1:] = [0, 0, 16 * W - 1, 16 * H - 1]   # whole map
+    rois[2, 1:] = [33, 47, 34, 48]   # tiny: every sample of a bin in one cell
     trans = (rs.standard_normal((R, 2, P, P)) * 0.5).astype(np.float32)
     dd = to_nhwc_f16(data)
     td = lambda z: torch.from_numpy(z).to(dev())
+    ws = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=dev())
     for tr, tstd in ((None, 0.0), (trans, 0.1)):
         out = torch.empty((R, P, P, C), dtype=torch.float16, device=dev())
         hip.call('sn_dpsroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, C, P, S, 1 / 16., tstd, hip.stream())
         want = onn.dpsroi_pool(f16r(data).astype(np.float64), rois, tr, P, S, 1 / 16., tstd)
         assert_close(out.float().cpu().numpy().transpose(0, 3, 1, 2), want, 1e-2, 1e-2, 'dpsroi fwd')
         dout = rs.standard_normal((R, C, P, P)).astype(np.float32)
-        d_data = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev())
-        d_trans = torch.zeros((R, 2, P, P), dtype=torch.float32, device=dev())
         dod = torch.from_numpy(np.ascontiguousarray(dout.transpose(0, 2, 3, 1))).to(dev()).half()
-        hip.call('sn_dpsroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d_data, d_trans if tr is not None else None,
-                 R, H, W, C, P, S, 1 / 16., tstd, hip.stream())
         wd, wtr = onn.dpsroi_pool_backward(f16r(dout).astype(np.float64), f16r(data).astype(np.float64), rois, tr, P, S, 1 / 16., tstd)
-        assert_close(d_data.cpu().numpy().transpose(0, 3, 1, 2), wd, 1e-3, 1e-3 * np.abs(wd).max(), 'dpsroi d_data')
-        if tr is not None:
-            assert_close(d_trans.cpu().numpy(), wtr, 1e-3, 1e-3 * np.abs(wtr).max(), 'dpsroi d_trans')
+        for f32 in (1, 0):
+            # poisoned outputs: the kernels must overwrite every element (no zeroing contract)
+            d_data = torch.full((B, H, W, C), 7.0, dtype=torch.float32 if f32 else torch.float16, device=dev())
+            d_trans = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
+            hip.call('sn_dpsroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d_data, f32,
+                     d_trans if tr is not None else None, R, B, H, W, C, P, S, 1 / 16., tstd, ws, hip.stream())
+            tol = 1e-3 if f32 else 1e-2
+            assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, tol, tol * np.abs(wd).max(), 'dpsroi d_data')
+            if tr is not None:
+                assert_close(d_trans.cpu().numpy(), wtr, 1e-3, 1e-3 * np.abs(wtr).max(), 'dpsroi d_trans')
+        # the tile kernel sums in a fixed order: bit-reproducible
+        d2 = torch.empty_like(d_data)
+        hip.call('sn_dpsroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d2, 0,
+                 d_trans if tr is not None else None, R, B, H, W, C, P, S, 1 / 16., tstd, ws, hip.stream())
+        assert torch.equal(d2, d_data)
 
 
-def test_deformable_sampling_vs_oracle():
+@pytest.mark.parametrize('N,C,H,W,DG', [(2, 64, 7, 6, 4), (2, 512, 9, 11, 4), (1, 72, 5, 5, 1)])
+def test_deformable_sampling_vs_oracle(N, C, H, W, DG):
     hip = _hip()
     rs = np.random.RandomState(10)
-    N, C, H, W, DG = 2, 64, 7, 6, 4
     KH = KW = 3
     T = 9
     data = rs.standard_normal((N, C, H, W)).astype(np.float32)
     off = (rs.standard_normal((N, 2 * T * DG, H, W)) * 1.5).astype(np.float32)
+    off[0, :, 0, 0] = 40.0   # far outside: contributes nothing
     dd = to_nhwc_f16(data)
     offd = torch.from_numpy(np.ascontiguousarray(off.transpose(0, 2, 3, 1))).to(dev())
     col = torch.empty((N * H * W, T, C), dtype=torch.float16, device=dev())
@@ -429,10 +444,12 @@ def test_deformable_sampling_vs_oracle():
     unf = Fnn.unfold(torch.from_numpy(f16r(data)), 3, dilation=2, padding=2).numpy().reshape(N, C, T, H, W)
     assert_close(col0.float().cpu().numpy().reshape(N, H, W, T, C), unf.transpose(0, 3, 4, 2, 1), 1e-3, 1e-3, 'deform zero offset')
     dcol = rs.standard_normal((N, H, W, T, C)).astype(np.float32)
-    d_data = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev())
-    d_off = torch.zeros((N, H, W, 2 * T * DG), dtype=torch.float32, device=dev())
-    hip.call('sn_deform_col2im', torch.from_numpy(dcol).to(dev()).half(), dd, offd, d_data, d_off, N, H, W, C, KH, KW, 1, 2, 2, DG,
-             2 * T * DG, 1, hip.stream())
     wdata, woff = onn.deform_col2im(f16r(dcol).astype(np.float64), f16r(data).astype(np.float64), off.astype(np.float64), KH, KW, 1, 2, 2, DG)
-    assert_close(d_data.cpu().numpy().transpose(0, 3, 1, 2), wdata, 1e-3, 1e-3 * np.abs(wdata).max(), 'deform d_data')
-    assert_close(d_off.cpu().numpy().transpose(0, 3, 1, 2), woff, 1e-3, 1e-3 * np.abs(woff).max(), 'deform d_offset')
+    dcd = torch.from_numpy(dcol).to(dev()).half()
+    for f32 in (1, 0):
+        d_data = torch.full((N, H, W, C), 7.0, dtype=torch.float32 if f32 else torch.float16, device=dev())
+        d_off = torch.full((N, H, W, 2 * T * DG), 7.0, dtype=torch.float32, device=dev())
+        hip.call('sn_deform_col2im', dcd, dd, offd, d_data, f32, d_off, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, hip.stream())
+        tol = 1e-3 if f32 else 1e-2
+        assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wdata, tol, tol * np.abs(wdata).max(), 'deform d_data')
+        assert_close(d_off.cpu().numpy().transpose(0, 3, 1, 2), woff, 1e-3, 1e-3 * np.abs(woff).max(), 'deform d_offset')

@@ -124,10 +124,27 @@ def main():
     out = torch.empty((R, 7, 7, C), dtype=torch.float16, device=d)
     ms = timeit(lambda: hip.call('sn_dpsroi_pool_fwd', data, rois, None, out, R, 32, 32, C, 7, 4, 1 / 16., 0.0, hip.stream()), it)
     print('dpsroi fwd R=%d               %8.3f ms %8.1f GB/s (output bytes)' % (R, ms, R * 49 * C * 2 / ms / 1e6), flush=True)
-    dda = torch.zeros((B, 32, 32, C), device=d)
-    ms = timeit(lambda: hip.call('sn_dpsroi_pool_bwd', out, data, rois, None, dda, None, R, 32, 32, C, 7, 4, 1 / 16., 0.0, hip.stream()), it)
-    print('dpsroi bwd R=%d               %8.3f ms' % (R, ms), flush=True)
-
+    dda = torch.empty((B, 32, 32, C), dtype=torch.float16, device=d)
+    wsb = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=d)
+    ms = timeit(lambda: hip.call('sn_dpsroi_pool_bwd', out, data, rois, None, dda, 0, None, R, B, 32, 32, C, 7, 4, 1 / 16., 0.0, wsb,
+                                 hip.stream()), it)
+    print('dpsroi bwd R=%d (no trans)    %8.3f ms %8.1f GB/s (dout bytes)' % (R, ms, R * 49 * C * 2 / ms / 1e6), flush=True)
+    trans = torch.randn(R, 2, 7, 7, device=d) * 0.3
+    dtr = torch.empty_like(trans)
+    ms = timeit(lambda: hip.call('sn_dpsroi_pool_bwd', out, data, rois, trans, dda, 0, dtr, R, B, 32, 32, C, 7, 4, 1 / 16., 0.1, wsb,
+                                 hip.stream()), it)
+    print('dpsroi bwd R=%d (trans)       %8.3f ms' % (R, ms), flush=True)
+    # deformable conv sampling (res5: 512 ch, 3x3 dil 2, 4 groups)
+    C5, DG = 512, 4
+    x5 = h(B, 32, 32, C5)
+    off = (torch.randn(B, 32, 32, 72, device=d) * 0.5).half()
+    col = torch.empty((B * 1024, 9 * C5), dtype=torch.float16, device=d)
+    ms = timeit(lambda: hip.call('sn_deform_im2col', x5, off, col, B, 32, 32, C5, 3, 3, 1, 2, 2, DG, 72, 0, hip.stream()), it)
+    print('deform im2col B=%d            %8.3f ms %8.1f GB/s (col bytes)' % (B, ms, col.numel() * 2 / ms / 1e6), flush=True)
+    dx5 = torch.empty_like(x5)
+    doff = torch.empty_like(off)
+    ms = timeit(lambda: hip.call('sn_deform_col2im', col, x5, off, dx5, 0, doff, B, 32, 32, C5, 3, 3, 1, 2, 2, DG, 72, 0, hip.stream()), it)
+    print('deform col2im B=%d            %8.3f ms %8.1f GB/s (col bytes)' % (B, ms, col.numel() * 2 / ms / 1e6), flush=True)
 
 if __name__ == '__main__':
     main()
