@@ -19,3 +19,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "ref" in item.keywords and not have_ref:
             item.add_marker(skip_ref)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_symbol_names():
+    """mx.sym auto-names (`blockgrad0`, ...) come from a per-thread counter like MXNet's NameManager; start every
+    test from zero so that assertions on generated names do not depend on test order."""
+    from sniper_amd.mx import symbol
+    symbol._counter().clear()
+    yield

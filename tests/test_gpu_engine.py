@@ -146,8 +146,17 @@ def test_executor_small_graph_vs_torch_autograd():
         got = p.to_reference(p.grad.detach().cpu().numpy())
         want = want_g[name]
         assert want is not None, name
-        # fp16 activations/gradients through 10 layers: 5% of the tensor's scale
-        assert_close(got, want, 5e-2, 5e-2 * np.abs(want).max() + 1e-6, 'grad %s' % name)
+        # fp16 activations/gradients through 10 layers: 5% of the tensor's scale.  A ReLU whose pre-activation is
+        # within fp16 rounding of zero flips its mask against the fp32 reference and moves one channel's sum by one
+        # element's gradient, so a few isolated elements may sit further out: bound those at 20% and the whole
+        # tensor in the L2 sense.
+        scale = np.abs(want).max() + 1e-6
+        err = np.abs(got.astype(np.float64) - want)
+        tol = 5e-2 * np.abs(want) + 5e-2 * scale
+        assert (err > tol).mean() <= 0.05, 'grad %s: %.1f%% of the elements outside 5%%' % (name, 100 * (err > tol).mean())
+        assert_close(got, want, 2e-1, 2e-1 * scale, 'grad %s (outliers)' % name)
+        assert np.linalg.norm(err) <= 0.1 * np.linalg.norm(want) + 1e-6, 'grad %s: relative L2 error %.3f' % (
+            name, np.linalg.norm(err) / np.linalg.norm(want))
         checked += 1
     assert checked >= 20
     # frozen parameters receive nothing, one SGD step moves the trainable ones and refreshes the fp16 copies
