@@ -262,10 +262,10 @@ SN_EXPORT int sn_conv_dgrad(const void *dy, const void *wt, const void *accumula
 //
 // GEMM with M' = Cout, N' = Cin, K' = pixels: the contraction index is the slow dimension of both
 // operands, so each MFMA fragment (8 consecutive k for one row/column) is a strided gather.
-// Version 1 gathers the fragments straight from global memory with 2-byte loads (every 16-lane
-// group reads 32 contiguous bytes, the lines stay in L1/L2 for the next 7 k), no LDS, no barriers:
-// each wave owns a 64x64 (co x ci) tile.  Version 2 (conv_wgrad_tr_kernel) stages natural-layout
-// tiles in LDS and transposes with ds_read_b64_tr_b16.
+// Version 1 (conv_wgrad_kernel, kept for operands that are not 16-byte addressable) gathers the fragments straight
+// from global memory with 2-byte loads (every 16-lane group reads 32 contiguous bytes, the lines stay in L1/L2
+// for the next 7 k), no LDS, no barriers: each wave owns a 64x64 (co x ci) tile.  Version 2
+// (conv_wgrad_tr_kernel, below) stages natural-layout tiles in LDS and transposes with ds_read_b64_tr_b16.
 // K' is split over (tap, row-range) blocks that accumulate with fp32 atomics into the zeroed dW.
 // Pixels are walked row by row (img, oy) in chunks of 32 consecutive ox so that the source row and
 // validity are scalar per step; 1x1/stride-1 layers and FCs pass the whole tensor as one long row.
@@ -356,6 +356,141 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---- version 2: natural-layout LDS tiles + ds_read_b64_tr_b16 ---------------------------------
+// Both operands are staged exactly as they lie in HBM -- [k = pixel][m = channel], 16-byte channel runs, fully
+// coalesced 256-byte rows -- and the transpose happens in the LDS read: ds_read_b64_tr_b16 hands lane (c, g) of a
+// 16-lane group the column c of the 4x16 block whose rows the group's lanes point at (4 lanes x 8 B per row;
+// semantics pinned on the hardware by tools/probes/tr16_probe.hip).  Two reads (rows g*4.., 16+g*4..) make one
+// 8-deep MFMA fragment; the k order inside a fragment is therefore permuted (k = {4g..4g+3, 16+4g..16+4g+3}) but
+// identically for A and B, and a contraction does not care.
+// LDS image: 32 rows (pixels) x 256 B (128 channels); the 32-byte segment index is XORed with (row & 7) so that the
+// 8 rows a 32-lane service group touches fall on 8 distinct bank octets (reads) and the 8 lanes of a
+// ds_write_b128 group on 8 distinct 16-byte slots (writes).
+// Tile 128 (co) x 128 (ci) x 32 (pixels) per 256-thread workgroup, waves 2x2, register-staged double buffer.
+typedef short short4v __attribute__((vector_size(8)));
+
+__device__ __forceinline__ half8 tr_frag(const half_t *lds_tile, int off) {
+  typedef __attribute__((address_space(3))) short4v *lds_v4;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_tile + off));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_tile + off + 16 * 128));
+  union { short4v s[2]; half8 h; } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.h;
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p) {
+  constexpr int MI = 4, NI = 4, TILE = 32 * 128;
+  __shared__ __attribute__((aligned(16))) half_t sA[2][TILE];
+  __shared__ __attribute__((aligned(16))) half_t sB[2][TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 128;
+  const int taps = p.KH * p.KW;
+  const int tap = blockIdx.z % taps, split = blockIdx.z / taps;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int cpr = (p.Wo + 31) / 32;  // 32-pixel units per (img, oy) row
+  const int nunits = p.N * p.Ho * cpr;
+  const int u_begin = split * p.units_per_split, u_end = min(nunits, u_begin + p.units_per_split);
+
+  // loader: rows lr, lr+16 of the unit; 16-byte chunk `chunk` of the 128 channels
+  const int lr = tid >> 4, chunk = tid & 15;
+  const int a_c = co0 + chunk * 8, b_c = ci0 + chunk * 8;
+  const bool a_cok = a_c < p.Cout, b_cok = b_c < p.Cin;
+  int st_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = lr + 16 * i;
+    st_off[i] = row * 128 + ((((chunk >> 1) ^ (row & 7)) << 4) | ((chunk & 1) << 3));
+  }
+  // fragment reads: lane (fr, fq) points at row fq*4 + fr/4, 8-byte piece fr%4 of the fragment's 32-byte segment
+  const int row0 = fq * 4 + (fr >> 2), r7 = row0 & 7;
+  int a_off[MI], b_off[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_off[i] = row0 * 128 + ((((wm * 4 + i) ^ r7) << 4) | ((fr & 3) << 2));
+#pragma unroll
+  for (int j = 0; j < NI; ++j) b_off[j] = row0 * 128 + ((((wn * 4 + j) ^ r7) << 4) | ((fr & 3) << 2));
+
+  auto next_valid = [&](int u) {  // skip units whose whole source row is padding
+    for (; u < u_end; ++u) {
+      const int r = u / cpr, oy = r % p.Ho;
+      const int sy = oy * p.stride - p.pad + kh * p.dil;
+      if ((unsigned)sy < (unsigned)p.H) break;
+    }
+    return u;
+  };
+  half8 ra[2], rb[2];
+  auto gload = [&](int u) {
+    const int r = u / cpr, ox0 = (u - r * cpr) * 32;
+    const int img = r / p.Ho, oy = r - img * p.Ho;
+    const int sy = oy * p.stride - p.pad + kh * p.dil;
+    const half_t *dyr = p.dy + (size_t)r * p.Wo * p.dy_ps + a_c;
+    const half_t *xr = p.x + ((size_t)img * p.H + sy) * p.W * (size_t)p.x_ps + b_c;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ox = ox0 + lr + 16 * i, sx = ox * p.stride - p.pad + kw * p.dil;
+      half8 va = {0, 0, 0, 0, 0, 0, 0, 0}, vb = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ox < p.Wo && a_cok) va = *reinterpret_cast<const half8 *>(dyr + (size_t)ox * p.dy_ps);
+      if (ox < p.Wo && b_cok && (unsigned)sx < (unsigned)p.W) vb = *reinterpret_cast<const half8 *>(xr + (size_t)sx * p.x_ps);
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<half8 *>(&sA[buf][st_off[i]]) = ra[i];
+      *reinterpret_cast<half8 *>(&sB[buf][st_off[i]]) = rb[i];
+    }
+  };
+
+  floatx4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  int u = next_valid(u_begin);
+  if (u >= u_end) return;  // block-uniform
+  gload(u);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  while (true) {
+    const int un = next_valid(u + 1);
+    const bool more = un < u_end;
+    if (more) gload(un);
+    half8 fa[MI], fb[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = tr_frag(sA[cur], a_off[i]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) fb[j] = tr_frag(sB[cur], b_off[j]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    if (!more) break;
+    u = un;
+    cur ^= 1;
+  }
+  // D: row = co (A operand), col = ci (B operand)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int co = co0 + wm * 64 + i * 16 + fq * 4 + rr;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int ci = ci0 + wn * 64 + j * 16 + fr;
+        if (ci < p.Cin) atomicAdd(p.dw + ((size_t)co * taps + tap) * p.Cin + ci, acc[i][j][rr]);
+      }
+    }
+}
+
 SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride,
                             int Cout, int dy_pix_stride, int KH, int KW, int stride, int pad, int dil,
                             sn_stream_t stream) {
@@ -374,14 +509,20 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
   }
   const int taps = KH * KW;
   const int gx = sn_div_up(Cout, 128), gy = sn_div_up(Cin, 128);
-  // enough K-splits to fill the chip (~4 workgroups per CU)
   const int nunits = p.N * p.Ho * sn_div_up(p.Wo, 32);
-  int splits = sn_div_up(1024, gx * gy * taps);
+  // 16-byte channel runs: pixel strides multiples of 8 that cover the last (possibly partial) chunk, aligned bases
+  const bool vec_ok = dy_pix_stride % 8 == 0 && x_pix_stride % 8 == 0 && dy_pix_stride >= sn_div_up(Cout, 8) * 8 &&
+                      x_pix_stride >= sn_div_up(Cin, 8) * 8 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0;
+  // K-splits: ~3 workgroups per CU (LDS 32 KB, ~128 VGPR); every split adds a 128x128 atomic epilogue
+  int splits = sn_div_up(vec_ok ? 768 : 1024, gx * gy * taps);
   if (splits > nunits) splits = nunits;
   if (splits < 1) splits = 1;
   p.units_per_split = sn_div_up(nunits, splits);
   splits = sn_div_up(nunits, p.units_per_split);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
+  if (vec_ok)
+    hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -66,6 +66,9 @@ CONV_CASES = [
     (2, 24, 10, 10, 72, 3, 1, 1, 1, True, False, 1),     # Cin not a multiple of 32
     (1, 256, 32, 32, 128, 1, 2, 0, 1, False, False, 0),  # stride-2 1x1 shortcut
     (2, 8, 9, 9, 16, 3, 1, 1, 1, False, False, 0),
+    (2, 320, 20, 24, 136, 3, 1, 1, 1, False, False, 0),  # partial 128-tiles in both channel dims, Wo < 32
+    (2, 256, 32, 32, 256, 3, 1, 1, 1, False, False, 0),  # several K-splits of the weight gradient
+    (1, 128, 40, 72, 64, 3, 2, 1, 1, False, False, 0),   # Wo = 36: two 32-pixel units per row, stride 2
 ]
 
 
@@ -109,7 +112,7 @@ def test_conv_stem_packed_7x7():
     assert_close(got, want, 1e-2, 1e-2 * np.abs(want).max(), 'stem conv')
 
 
-@pytest.mark.parametrize('case', CONV_CASES[:7])
+@pytest.mark.parametrize('case', CONV_CASES[:7] + CONV_CASES[8:])
 def test_conv_dgrad_wgrad(case):
     hip = _hip()
     N, C, H, W, O, K, s, p, d, _, _, _ = case
