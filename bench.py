@@ -97,17 +97,35 @@ class ConvProfiler(object):
         return tot_ms, tot_fl, per
 
 
+def pmc_traffic():
+    """HBM bytes per conv-family launch from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_traffic.py -> profiles/pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
+    as MI355X_MICROARCH.md section HBM prescribes for gfx950).  None when no such profile has been collected."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return d.get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_target=15.0):
     """The reference's CPU data path (oracle restatement), Pool(P) over images like MNIteratorE2E does."""
     import multiprocessing as mp
     from oracle import build as obuild
     obuild.build_restatement()
     P = min(os.cpu_count() or 1, 64)   # TRAIN.NUM_PROCESS = 64 in the reference config
-    n_img = 16 * P
-    t0 = time.time()
     with mp.get_context('fork').Pool(P) as pool:
-        chips = pool.map(_cpu_image_chips, range(n_img), chunksize=4)
-    dt = time.time() - t0
+        pool.map(_cpu_image_chips, range(P), chunksize=1)          # warm the workers (imports, anchor tables)
+        # bounded sample: a pilot batch sizes the timed batch to about `seconds_target` of wall time
+        t0 = time.time()
+        pool.map(_cpu_image_chips, range(8 * P), chunksize=4)
+        pilot = max(time.time() - t0, 1e-3)
+        n_img = int(min(max(8 * P * seconds_target / pilot, 8 * P), 4096 * P))
+        t0 = time.time()
+        chips = pool.map(_cpu_image_chips, range(10 ** 6, 10 ** 6 + n_img), chunksize=4)
+        dt = time.time() - t0
     n_chips = int(sum(chips))
     return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'port',
             'sample': '%d synthetic images -> %d chips: chip_extractor + box_assigner + anchor_worker (oracle/data_path.py, '
@@ -182,6 +200,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    host_dt = time.perf_counter() - t0     # host enqueue time: all launches issued, nothing waited for yet
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -201,7 +220,7 @@ def main():
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel / conv_wgrad_kernel (sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad)',
                 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
-                'traffic': None,
+                'traffic': pmc_traffic(),
                 'launches_per_step': sum(v[0] for v in per.values()) // 2,
                 'avg_launch_ms': round(tot_ms / max(1, sum(v[0] for v in per.values())), 4),
                 'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
@@ -217,9 +236,11 @@ def main():
         out = {
             'metric': 'train chips/sec (512x512, R101)', 'value': round(value, 2), 'unit': 'chips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16 storage / fp32 accumulate', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 3),
             'config': {'workload': 'ResNet-101 Faster-RCNN SNIPER 3-scale, batch %d x 512x512 fp16 per GPU (BASELINE configs[1]); '
-                                   'step = GPU anchor labelling + fwd + bwd + grad all-reduce + SGD' % args.batch,
+                                   'step = GPU anchor labelling + fwd + bwd + grad all-reduce + SGD; f16 MFMA operands, f32 '
+                                   'accumulation / losses / master weights' % args.batch,
                        'chips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
             'roofline': roof, 'cpu_baseline': cpu,
         }

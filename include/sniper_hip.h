@@ -136,17 +136,21 @@ int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype,
 int sn_pack_stem_input(const float *x_nchw, void *out, int N, int C, int H, int W, int Hp, int Wp, int pad_t, int pad_l,
                        const float *scale, const float *shift, sn_stream_t stream);
 
-/* BatchNorm (eps, momentum; :38-58).  sum/sumsq/ws are fp64 scratch of C (2C for ws) elements. */
-int sn_bn_stats(const void *x, int M, int C, int ps, double *sum, double *sumsq, sn_stream_t stream);
-int sn_bn_finalize(const double *sum, const double *sumsq, int M, int C, float eps, float momentum, const float *gamma,
-                   const float *beta, float *run_mean, float *run_var, float *scale, float *shift, float *save_mean,
-                   float *save_invstd, sn_stream_t stream);
+/* BatchNorm (eps, momentum; :38-58).  Training statistics: sn_bn_stats writes fp32 per-row-block partials into ws
+ * (sn_bn_workspace_bytes(M, C), no atomics, fixed summation order), sn_bn_finalize reduces them in double to
+ * scale = gamma*invstd, shift = beta - mean*scale, the saved batch statistics and the moving averages.
+ * sn_bn_backward: gradients through relu?(BN_train(x)); dgamma/dbeta are accumulated (+=); same ws size. */
+size_t sn_bn_workspace_bytes(int M, int C);
+int sn_bn_stats(const void *x, int M, int C, int ps, void *ws, sn_stream_t stream);
+int sn_bn_finalize(const void *ws, int M, int C, float eps, float momentum, const float *gamma, const float *beta,
+                   float *run_mean, float *run_var, float *scale, float *shift, float *save_mean, float *save_invstd,
+                   sn_stream_t stream);
 int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int C, float eps,
                              float *scale, float *shift, sn_stream_t stream);
 int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, const float *scale, const float *shift, int relu,
                 sn_stream_t stream);
 int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy, int ps_x, int ps_acc,
-                   int ps_dx, const float *scale, const float *shift, const float *mean, const float *invstd, int relu, double *ws,
+                   int ps_dx, const float *scale, const float *shift, const float *mean, const float *invstd, int relu, void *ws,
                    float *dgamma, float *dbeta, sn_stream_t stream);
 
 /* fp16 channels-last element-wise: mode 0 relu(a), 1 a+b, 2 relu-backward (ref>0 ? a : 0) [+ b]. */

@@ -102,8 +102,7 @@ __device__ __forceinline__ void bn_block_reduce(const BnMap &m, int C, const flo
 }
 
 __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const half_t *__restrict__ x, int M, int C, int ps,
-                                                              int rows_per_block, double *__restrict__ sum,
-                                                              double *__restrict__ sumsq) {
+                                                              int rows_per_block, float *__restrict__ part) {
   const BnMap m = bn_map(C);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s[8], q[8];
@@ -135,21 +134,44 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const half_t *__re
       }
     }
   }
-  bn_block_reduce(m, C, s, q, [&](int c, int j, float a) {
-    if (j < 8) atomicAdd(&sum[c], (double)a);
-    else atomicAdd(&sumsq[c], (double)a);
-  });
+  float *po = part + (size_t)blockIdx.x * 2 * C;  // [row block][sum | sumsq][C]
+  bn_block_reduce(m, C, s, q, [&](int c, int j, float a) { po[(j < 8 ? 0 : C) + c] = a; });
 }
 
-__global__ void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq, int M, int C, float eps,
-                                   float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                   float *__restrict__ run_mean, float *__restrict__ run_var, float *__restrict__ scale,
-                                   float *__restrict__ shift, float *__restrict__ save_mean,
-                                   float *__restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = sum[c] / M;
-  double var = sumsq[c] / M - mean * mean;  // biased
+// sums the per-row-block partials [nblk][2][C] in double: 32 channels x 8 partial lanes per block
+__device__ __forceinline__ void bn_sum_partials(const float *__restrict__ part, int nblk, int C, double &a, double &b, int &c) {
+  __shared__ double red[2][8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  c = blockIdx.x * 32 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int k = rl; k < nblk; k += 8) {
+      s0 += (double)part[(size_t)k * 2 * C + c];
+      s1 += (double)part[(size_t)k * 2 * C + C + c];
+    }
+  red[0][rl][cl] = s0;
+  red[1][rl][cl] = s1;
+  __syncthreads();
+  a = b = 0.0;
+  if (rl == 0)
+    for (int k = 0; k < 8; ++k) {
+      a += red[0][k][cl];
+      b += red[1][k][cl];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nblk, int M, int C, float eps,
+                                                          float momentum, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ run_mean,
+                                                          float *__restrict__ run_var, float *__restrict__ scale,
+                                                          float *__restrict__ shift, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_invstd) {
+  double sum, sumsq;
+  int c;
+  bn_sum_partials(part, nblk, C, sum, sumsq, c);
+  if (threadIdx.x >= 32 || c >= C) return;
+  const double mean = sum / M;
+  double var = sumsq / M - mean * mean;  // biased
   if (var < 0) var = 0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f;
@@ -201,8 +223,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
                                                                    const float *__restrict__ scale,
                                                                    const float *__restrict__ shift,
                                                                    const float *__restrict__ mean,
-                                                                   const float *__restrict__ invstd, int relu,
-                                                                   double *__restrict__ dgamma, double *__restrict__ dbeta) {
+                                                                   int relu, float *__restrict__ part) {
   const BnMap m = bn_map(C);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s[8], q[8];
@@ -240,10 +261,23 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
     for (; r < r1; r += m.rpp)
       body(*reinterpret_cast<const half8 *>(pg + (size_t)r * ps_dy), *reinterpret_cast<const half8 *>(px + (size_t)r * ps_x));
   }
-  bn_block_reduce(m, C, s, q, [&](int c, int j, float a) {
-    if (j < 8) atomicAdd(&dbeta[c], (double)a);
-    else atomicAdd(&dgamma[c], (double)(a * invstd[c]));
-  });
+  float *po = part + (size_t)blockIdx.x * 2 * C;  // [row block][sum g | sum g*(x-mean)][C]
+  bn_block_reduce(m, C, s, q, [&](int c, int j, float a) { po[(j < 8 ? 0 : C) + c] = a; });
+}
+
+// partials -> fin[0..C) = dbeta, fin[C..2C) = dgamma (fp32, read by the dx kernel) and += into the gradient arena
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C,
+                                                              const float *__restrict__ invstd, float *__restrict__ fin,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  double sg, sgx;
+  int c;
+  bn_sum_partials(part, nblk, C, sg, sgx, c);
+  if (threadIdx.x >= 32 || c >= C) return;
+  const float db = (float)sg, dg = (float)(sgx * (double)invstd[c]);
+  fin[c] = db;
+  fin[C + c] = dg;
+  if (dbeta) dbeta[c] += db;
+  if (dgamma) dgamma[c] += dg;
 }
 
 // dx = scale * (g - dbeta/M - xhat*dgamma/M) [+ acc] = ka*g + kb*x + kd with three per-channel registers
@@ -253,8 +287,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
                                                                int rows_per_block, const float *__restrict__ scale,
                                                                const float *__restrict__ shift, const float *__restrict__ mean,
                                                                const float *__restrict__ invstd,
-                                                               const double *__restrict__ dgamma,
-                                                               const double *__restrict__ dbeta, int relu) {
+                                                               const float *__restrict__ dgamma,
+                                                               const float *__restrict__ dbeta, int relu) {
   const BnMap m = bn_map(C);
   if (!m.on) return;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -264,9 +298,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
   for (int j = 0; j < 8; ++j) {
     const int c = m.chunk * 8 + j;
     sc[j] = scale[c]; sh[j] = shift[c];
-    const float t = invstd[c] * (float)dgamma[c] * invM;   // xhat coefficient / scale
+    const float t = invstd[c] * dgamma[c] * invM;   // xhat coefficient / scale
     kb[j] = -sc[j] * t;
-    kd[j] = sc[j] * (mean[c] * t - (float)dbeta[c] * invM);
+    kd[j] = sc[j] * (mean[c] * t - dbeta[c] * invM);
   }
   const half_t *pg = dy + m.chunk * 8, *px = x + m.chunk * 8, *pa = acc ? acc + m.chunk * 8 : nullptr;
   half_t *po = dx + m.chunk * 8;
@@ -300,14 +334,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
          pa ? *reinterpret_cast<const half8 *>(pa + (size_t)r * ps_acc) : zero, (size_t)r);
 }
 
-__global__ void f64_to_f32_accum_kernel(const double *__restrict__ a, float *__restrict__ out, int n, float mul) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] += (float)a[i] * mul;
-}
-
 static int bn_shape_ok(int C) { return C >= 8 && C % 8 == 0; }
-// grid of the row-walking BN kernels: x = row blocks (>= kBnUnroll*2 rows per thread, at most `cap` blocks so that the
-// per-block fp64 atomics stay few), y = 256-chunk slabs
+static int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+// grid of the row-walking BN kernels: x = row blocks (>= kBnUnroll*2 rows per thread, at most `cap`), y = 256-chunk slabs
 static dim3 bn_grid(int M, int C, int cap, int *rows_per_block) {
   const int cpr = C / 8, cb = cpr < kBnThreads ? cpr : kBnThreads, rpp = kBnThreads / cb;
   int blocks = sn_div_up(M, rpp * kBnUnroll * 2);
@@ -315,29 +347,37 @@ static dim3 bn_grid(int M, int C, int cap, int *rows_per_block) {
   *rows_per_block = sn_div_up(sn_div_up(M, blocks), rpp) * rpp;
   return dim3(sn_div_up(M, *rows_per_block), sn_div_up(cpr, kBnThreads));
 }
-static int ew_blocks(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+// row blocks of the two reduction kernels: their fp32 partials [blocks][2][C] stay <= 4 MB
+static int bn_reduce_cap(int C) {
+  int cap = (1 << 22) / (8 * C);
+  return cap < 256 ? 256 : (cap > 2048 ? 2048 : cap);
 }
 
-SN_EXPORT int sn_bn_stats(const void *x, int M, int C, int ps, double *sum, double *sumsq, sn_stream_t stream) {
-  SN_REQUIRE(x && sum && sumsq && M > 0 && bn_shape_ok(C), "sn_bn_stats: C=%d unsupported (C %% 8 != 0)", C);
-  hipStream_t s = sn_stream(stream);
-  SN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * C, s));
-  SN_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * C, s));
+SN_EXPORT size_t sn_bn_workspace_bytes(int M, int C) {
+  if (M <= 0 || !bn_shape_ok(C)) return 0;
+  int rpb;
+  const dim3 g = bn_grid(M, C, bn_reduce_cap(C), &rpb);
+  return sn_align(sizeof(float) * 2 * (size_t)C * (g.x + 1));
+}
+
+SN_EXPORT int sn_bn_stats(const void *x, int M, int C, int ps, void *ws, sn_stream_t stream) {
+  SN_REQUIRE(x && ws && M > 0 && bn_shape_ok(C), "sn_bn_stats: bad arguments (C=%d must be a multiple of 8)", C);
   int rows_per_block;
-  const dim3 grid = bn_grid(M, C, 1024, &rows_per_block);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)x, M, C, ps, rows_per_block, sum, sumsq);
+  const dim3 grid = bn_grid(M, C, bn_reduce_cap(C), &rows_per_block);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, sn_stream(stream), (const half_t *)x, M, C, ps, rows_per_block,
+                     (float *)ws + 2 * C);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
 
-SN_EXPORT int sn_bn_finalize(const double *sum, const double *sumsq, int M, int C, float eps, float momentum,
-                             const float *gamma, const float *beta, float *run_mean, float *run_var, float *scale,
-                             float *shift, float *save_mean, float *save_invstd, sn_stream_t stream) {
-  SN_REQUIRE(sum && sumsq && beta && scale && shift && save_mean && save_invstd, "sn_bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, sn_stream(stream), sum, sumsq, M, C, eps,
-                     momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean, save_invstd);
+SN_EXPORT int sn_bn_finalize(const void *ws, int M, int C, float eps, float momentum, const float *gamma, const float *beta,
+                             float *run_mean, float *run_var, float *scale, float *shift, float *save_mean, float *save_invstd,
+                             sn_stream_t stream) {
+  SN_REQUIRE(ws && beta && scale && shift && save_mean && save_invstd && M > 0 && bn_shape_ok(C), "sn_bn_finalize: bad arguments");
+  int rows_per_block;
+  const dim3 grid = bn_grid(M, C, bn_reduce_cap(C), &rows_per_block);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(256), 0, sn_stream(stream), (const float *)ws + 2 * C,
+                     (int)grid.x, M, C, eps, momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean, save_invstd);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
@@ -360,34 +400,29 @@ SN_EXPORT int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int p
   return SN_OK;
 }
 
-// Backward of y = relu?(BN_train(x)).  dgamma/dbeta (fp32, length C) are ACCUMULATED into
-// (+=, the optimizer's gradient arena is zeroed once per step); ws = 2*C doubles.
+// Backward of y = relu?(BN_train(x)).  dgamma/dbeta (fp32, length C) are ACCUMULATED into (+=, the optimizer's
+// gradient arena is zeroed once per step); ws = sn_bn_workspace_bytes(M, C).  Three launches, no atomics, no memset:
+// partial reduce -> finalize -> dx.
 SN_EXPORT int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy,
                              int ps_x, int ps_acc, int ps_dx, const float *scale, const float *shift, const float *mean,
-                             const float *invstd, int relu, double *ws, float *dgamma, float *dbeta,
-                             sn_stream_t stream) {
+                             const float *invstd, int relu, void *ws, float *dgamma, float *dbeta, sn_stream_t stream) {
   SN_REQUIRE(dy && x && scale && shift && mean && invstd && ws && bn_shape_ok(C) && M > 0,
              "sn_bn_backward: bad arguments (C=%d)", C);
   hipStream_t s = sn_stream(stream);
-  SN_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s));
+  float *fin = (float *)ws, *part = fin + 2 * C;
   int rows_per_block;
-  dim3 grid = bn_grid(M, C, 1024, &rows_per_block);
+  dim3 grid = bn_grid(M, C, bn_reduce_cap(C), &rows_per_block);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x, M, C, ps_dy,
-                     ps_x, rows_per_block, scale, shift, mean, invstd, relu, ws, ws + C);
+                     ps_x, rows_per_block, scale, shift, mean, relu, part);
+  SN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(256), 0, s, (const float *)part, (int)grid.x, C,
+                     invstd, fin, dgamma, dbeta);
   SN_CHECK_LAUNCH();
   if (dx) {
     grid = bn_grid(M, C, 8192, &rows_per_block);
     hipLaunchKernelGGL(bn_bwd_dx_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x,
                        (const half_t *)accumulate, (half_t *)dx, M, C, ps_dy, ps_x, ps_acc, ps_dx, rows_per_block, scale, shift,
-                       mean, invstd, ws, ws + C, relu);
-    SN_CHECK_LAUNCH();
-  }
-  if (dgamma) {
-    hipLaunchKernelGGL(f64_to_f32_accum_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, s, ws, dgamma, C, 1.f);
-    SN_CHECK_LAUNCH();
-  }
-  if (dbeta) {
-    hipLaunchKernelGGL(f64_to_f32_accum_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, s, ws + C, dbeta, C, 1.f);
+                       mean, invstd, (const float *)fin + C, (const float *)fin, relu);
     SN_CHECK_LAUNCH();
   }
   return SN_OK;

@@ -94,8 +94,7 @@ class BatchNormStep(Step):
         ex.aux[self.pname('moving_var')].fill_(1.0)
         self.scale, self.shift = ex.empty((C,), F32), ex.empty((C,), F32)
         self.save_mean, self.save_invstd = ex.empty((C,), F32), ex.empty((C,), F32)
-        self.sum64, self.sq64 = ex.zeros((C,), torch.float64), ex.zeros((C,), torch.float64)
-        self.bws = ex.zeros((2 * C,), torch.float64)
+        self.bws = None
         # image input (C <= 4): folded into the stem convolution's input packing
         self.is_stem = self.x.fmt == 'f32' and len(self.x.shape) == 4 and C <= 4
         cons = ex.consumers.get((id(self.node), 0), [])
@@ -132,8 +131,10 @@ class BatchNormStep(Step):
         n, h, w, c = self.x.nhwc()
         M = n * h * w
         if self._use_batch_stats():
-            hip.call('sn_bn_stats', x, M, c, c, self.sum64, self.sq64, hip.stream())
-            hip.call('sn_bn_finalize', self.sum64, self.sq64, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
+            if self.bws is None:
+                self.bws = ex.empty((hip.query('sn_bn_workspace_bytes', M, c),), torch.uint8)
+            hip.call('sn_bn_stats', x, M, c, c, self.bws, hip.stream())
+            hip.call('sn_bn_finalize', self.bws, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
                      self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
         hip.call('sn_bn_apply', x, self.y.t, M, c, c, c, self.scale, self.shift, 1 if self.relu else 0, hip.stream())
 

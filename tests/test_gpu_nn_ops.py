@@ -190,12 +190,12 @@ def test_batchnorm_train_fwd_bwd():
         M = N * H * W
         xd, dyd = to_nhwc_f16(x), to_nhwc_f16(dy)
         f = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev())
-        s64, q64 = f(C, torch.float64), f(C, torch.float64)
+        ws = torch.empty(hip.query('sn_bn_workspace_bytes', M, C), dtype=torch.uint8, device=dev())
         scale, shift, mean, invstd = f(C), f(C), f(C), f(C)
         rm, rv = f(C), torch.ones(C, device=dev())
         g_d, b_d = torch.from_numpy(gamma).to(dev()), torch.from_numpy(beta).to(dev())
-        hip.call('sn_bn_stats', xd, M, C, C, s64, q64, hip.stream())
-        hip.call('sn_bn_finalize', s64, q64, M, C, 2e-5, 0.9, g_d, b_d, rm, rv, scale, shift, mean, invstd, hip.stream())
+        hip.call('sn_bn_stats', xd, M, C, C, ws, hip.stream())
+        hip.call('sn_bn_finalize', ws, M, C, 2e-5, 0.9, g_d, b_d, rm, rv, scale, shift, mean, invstd, hip.stream())
         y = torch.empty_like(xd)
         hip.call('sn_bn_apply', xd, y, M, C, C, C, scale, shift, relu, hip.stream())
         xt = torch.from_numpy(f16r(x)).requires_grad_(True)
@@ -208,7 +208,6 @@ def test_batchnorm_train_fwd_bwd():
         xm = f16r(x).transpose(1, 0, 2, 3).reshape(C, -1)
         assert_close(rm.cpu().numpy(), 0.1 * xm.mean(1), 1e-3, 1e-4, 'running mean')
         assert_close(rv.cpu().numpy(), 0.9 + 0.1 * xm.var(1), 1e-3, 1e-4, 'running var')
-        ws = f(2 * C, torch.float64)
         dx, dg, db = torch.empty_like(xd), f(C), f(C)
         hip.call('sn_bn_backward', dyd, xd, None, dx, M, C, C, C, C, C, scale, shift, mean, invstd, relu, ws, dg, db, hip.stream())
         torch.cuda.synchronize()

@@ -34,3 +34,13 @@ if [[ $WHAT == all || $WHAT == bench ]]; then
   # the raw kernel trace is large; keep only the stats
   find "$ROOT/gpurun_out/prof_bench" -name "*kernel_trace.csv" -size +20M -delete
 fi
+if [[ $WHAT == pmc ]]; then
+  # HBM traffic of the conv family: FETCH_SIZE and WRITE_SIZE need separate passes (TCC has 4 slots: 3 + 2)
+  cd /tmp && export TMPDIR=/tmp
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 1200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/gpurun_out/pmc_$C" -o pmc -- python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$ROOT/gpurun_out/rocprof_pmc_$C.log" 2>&1
+    echo "pmc $C exit $?"
+  done
+  cd "$ROOT" && python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json
+  find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete
+fi

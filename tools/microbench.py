@@ -70,14 +70,13 @@ def main():
     for (H, C) in ((64, 512), (32, 1024)):
         Mr = B * H * H
         x, y = h(Mr, C), torch.empty((Mr, C), dtype=torch.float16, device=d)
-        s64, q64 = torch.zeros(C, dtype=torch.float64, device=d), torch.zeros(C, dtype=torch.float64, device=d)
+        ws = torch.empty(hip.query('sn_bn_workspace_bytes', Mr, C), dtype=torch.uint8, device=d)
         f = lambda: torch.ones(C, device=d)
         sc, sh, mu, iv, g, bt = f(), f(), f(), f(), f(), f()
-        ms = timeit(lambda: hip.call('sn_bn_stats', x, Mr, C, C, s64, q64, hip.stream()), it)
+        ms = timeit(lambda: hip.call('sn_bn_stats', x, Mr, C, C, ws, hip.stream()), it)
         print('bn_stats  %dx%d %8.3f ms %8.1f GB/s' % (Mr, C, ms, Mr * C * 2 / ms / 1e6), flush=True)
         ms = timeit(lambda: hip.call('sn_bn_apply', x, y, Mr, C, C, C, sc, sh, 1, hip.stream()), it)
         print('bn_apply  %dx%d %8.3f ms %8.1f GB/s' % (Mr, C, ms, Mr * C * 4 / ms / 1e6), flush=True)
-        ws = torch.zeros(2 * C, dtype=torch.float64, device=d)
         dg, db = f(), f()
         ms = timeit(lambda: hip.call('sn_bn_backward', y, x, None, y, Mr, C, C, C, C, C, sc, sh, mu, iv, 1, ws, dg, db, hip.stream()), it)
         print('bn_bwd    %dx%d %8.3f ms %8.1f GB/s (10 B/elt)' % (Mr, C, ms, Mr * C * 10 / ms / 1e6), flush=True)
