@@ -206,6 +206,10 @@ int sn_deform_col2im(const void *dcol, const void *data, const void *offset, voi
 /* Multi-precision SGD with momentum (lib/train_utils/utils.py:26-33). */
 int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void *w16, long n, float lr, float wd, float momentum,
                       float rescale, sn_stream_t stream);
+/* Same, with lr/wd/momentum/rescale read from device memory d_hyper[4] (for launches captured in a hipGraph):
+ * lr = d_hyper[0]*lr_mult, wd = d_hyper[1]*wd_mult. */
+int sn_sgd_mom_update_dev(float *w32, const float *grad, float *mom, void *w16, long n, const float *d_hyper, float lr_mult,
+                          float wd_mult, sn_stream_t stream);
 /* fp32 [O][T][I] -> fp16 [I][T][O_pad] (weights for sn_conv_dgrad; O_pad = O rounded up to 8, zero filled). */
 int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, int O_pad, sn_stream_t stream);
 

@@ -138,29 +138,33 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const half_t *__re
   bn_block_reduce(m, C, s, q, [&](int c, int j, float a) { po[(j < 8 ? 0 : C) + c] = a; });
 }
 
-// sums the per-row-block partials [nblk][2][C] in double: 32 channels x 8 partial lanes per block
+// sums the per-row-block partials [nblk][2][C] in double: 32 channels x 32 partial lanes per 1024-thread block
+// (nblk <= 512: at most 16 independent loads per thread and statistic -- the chain is latency, not bandwidth)
+constexpr int kBnFinThreads = 1024;
 __device__ __forceinline__ void bn_sum_partials(const float *__restrict__ part, int nblk, int C, double &a, double &b, int &c) {
-  __shared__ double red[2][8][33];
+  __shared__ double red[2][32][33];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   c = blockIdx.x * 32 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (int k = rl; k < nblk; k += 8) {
+  if (c < C) {
+#pragma unroll 4
+    for (int k = rl; k < nblk; k += 32) {
       s0 += (double)part[(size_t)k * 2 * C + c];
       s1 += (double)part[(size_t)k * 2 * C + C + c];
     }
+  }
   red[0][rl][cl] = s0;
   red[1][rl][cl] = s1;
   __syncthreads();
   a = b = 0.0;
   if (rl == 0)
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 32; ++k) {
       a += red[0][k][cl];
       b += red[1][k][cl];
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nblk, int M, int C, float eps,
+__global__ __launch_bounds__(kBnFinThreads) void bn_finalize_kernel(const float *__restrict__ part, int nblk, int M, int C, float eps,
                                                           float momentum, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ run_mean,
                                                           float *__restrict__ run_var, float *__restrict__ scale,
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
 }
 
 // partials -> fin[0..C) = dbeta, fin[C..2C) = dgamma (fp32, read by the dx kernel) and += into the gradient arena
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C,
+__global__ __launch_bounds__(kBnFinThreads) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C,
                                                               const float *__restrict__ invstd, float *__restrict__ fin,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
   double sg, sgx;
@@ -347,10 +351,11 @@ static dim3 bn_grid(int M, int C, int cap, int *rows_per_block) {
   *rows_per_block = sn_div_up(sn_div_up(M, blocks), rpp) * rpp;
   return dim3(sn_div_up(M, *rows_per_block), sn_div_up(cpr, kBnThreads));
 }
-// row blocks of the two reduction kernels: their fp32 partials [blocks][2][C] stay <= 4 MB
+// row blocks of the two reduction kernels: their fp32 partials [blocks][2][C] stay <= 4 MB and the finalize
+// kernels' per-thread chains short
 static int bn_reduce_cap(int C) {
   int cap = (1 << 22) / (8 * C);
-  return cap < 256 ? 256 : (cap > 2048 ? 2048 : cap);
+  return cap < 256 ? 256 : (cap > 512 ? 512 : cap);
 }
 
 SN_EXPORT size_t sn_bn_workspace_bytes(int M, int C) {
@@ -376,7 +381,7 @@ SN_EXPORT int sn_bn_finalize(const void *ws, int M, int C, float eps, float mome
   SN_REQUIRE(ws && beta && scale && shift && save_mean && save_invstd && M > 0 && bn_shape_ok(C), "sn_bn_finalize: bad arguments");
   int rows_per_block;
   const dim3 grid = bn_grid(M, C, bn_reduce_cap(C), &rows_per_block);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(256), 0, sn_stream(stream), (const float *)ws + 2 * C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(kBnFinThreads), 0, sn_stream(stream), (const float *)ws + 2 * C,
                      (int)grid.x, M, C, eps, momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean, save_invstd);
   SN_CHECK_LAUNCH();
   return SN_OK;
@@ -415,7 +420,7 @@ SN_EXPORT int sn_bn_backward(const void *dy, const void *x, const void *accumula
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x, M, C, ps_dy,
                      ps_x, rows_per_block, scale, shift, mean, relu, part);
   SN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(256), 0, s, (const float *)part, (int)grid.x, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(kBnFinThreads), 0, s, (const float *)part, (int)grid.x, C,
                      invstd, fin, dgamma, dbeta);
   SN_CHECK_LAUNCH();
   if (dx) {
@@ -725,6 +730,33 @@ SN_EXPORT int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void 
   if (n == 0) return SN_OK;
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, sn_stream(stream), w32, grad, mom, (half_t *)w16, n, lr, wd,
                      momentum, rescale);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// Same update with the per-step hyper-parameters read from device memory (d_hyper = [lr, wd, momentum, rescale]):
+// a launch captured in a hipGraph must not bake the scheduled learning rate into its arguments.
+__global__ __launch_bounds__(256) void sgd_dev_kernel(float *__restrict__ w32, const float *__restrict__ grad,
+                                                      float *__restrict__ mom, half_t *__restrict__ w16, long n,
+                                                      const float *__restrict__ hyper, float lr_mult, float wd_mult) {
+  const float lr = hyper[0] * lr_mult, wd = hyper[1] * wd_mult, momentum = hyper[2], rescale = hyper[3];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float w = w32[i];
+    const float g = rescale * grad[i] + wd * w;
+    const float m = momentum * mom[i] - lr * g;
+    mom[i] = m;
+    const float nw = w + m;
+    w32[i] = nw;
+    if (w16) w16[i] = (half_t)nw;
+  }
+}
+
+SN_EXPORT int sn_sgd_mom_update_dev(float *w32, const float *grad, float *mom, void *w16, long n, const float *d_hyper,
+                                    float lr_mult, float wd_mult, sn_stream_t stream) {
+  SN_REQUIRE(w32 && grad && mom && d_hyper && n >= 0, "sn_sgd_mom_update_dev: bad arguments");
+  if (n == 0) return SN_OK;
+  hipLaunchKernelGGL(sgd_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, sn_stream(stream), w32, grad, mom, (half_t *)w16, n,
+                     d_hyper, lr_mult, wd_mult);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

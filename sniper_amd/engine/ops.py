@@ -63,7 +63,7 @@ class Step(object):
     def backward(self):
         pass
 
-    def params_changed(self):
+    def params_changed(self, only_trainable=False):
         pass
 
 
@@ -109,8 +109,11 @@ class BatchNormStep(Step):
             and not self.is_stem
         self._global_ready = False
 
-    def params_changed(self):
-        self._global_ready = False
+    def params_changed(self, only_trainable=False):
+        # after an optimizer step only trainable parameters moved; a moving-statistics layer with frozen
+        # gamma/beta keeps its folded scale/shift
+        if not (only_trainable and self.global_stats and not self.gamma.trainable and not self.beta.trainable):
+            self._global_ready = False
 
     def _use_batch_stats(self):
         return self.ex.is_train and not self.global_stats
@@ -293,8 +296,8 @@ class ConvolutionStep(_GemmLike):
             self.xp = ex.empty((self.N, self.Hp, self.Wp, 4), F16)
             self.w_stem = ex.zeros((self.O, kh, self.KWP * 4), F16)
 
-    def params_changed(self):
-        if self.is_stem:
+    def params_changed(self, only_trainable=False):
+        if self.is_stem and not (only_trainable and not self.w.trainable):
             o, t, i = self.w.int_shape
             kh, kw = self.k
             w = self.w.master.view(o, kh, kw, i)
@@ -384,7 +387,7 @@ class DeformableConvolutionStep(Step):
         self.col = ex.empty((self.N * self.Ho * self.Wo, self.T * self.C), F16)
         self.wT_flat = None
 
-    def params_changed(self):
+    def params_changed(self, only_trainable=False):
         if self.ex.for_training:
             o = self.O
             if self.wT_flat is None:

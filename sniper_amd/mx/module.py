@@ -166,23 +166,25 @@ class Module(object):
             return a[self.rank * n:(self.rank + 1) * n]
         return a
 
-    def forward(self, data_batch, is_train=None):
+    def _feed(self, data_batch):
         feed = {}
         for name, arr in zip(self.data_names, data_batch.data):
             feed[name] = self._slice(arr)
         if data_batch.label is not None:
             for name, arr in zip(self.label_names, data_batch.label):
                 feed[name] = self._slice(arr)
-        feed = {k: v for k, v in feed.items() if k in self.exe.input_names}
         self._labels = [self._slice(a) for a in (data_batch.label or [])]
-        self.exe.forward(feed, is_train=self.for_training if is_train is None else is_train)
+        return {k: v for k, v in feed.items() if k in self.exe.input_names}
+
+    def forward(self, data_batch, is_train=None):
+        self.exe.forward(self._feed(data_batch), is_train=self.for_training if is_train is None else is_train)
 
     def backward(self, out_grads=None):
         self.exe.backward()
 
     def forward_backward(self, data_batch):
-        self.forward(data_batch, is_train=True)
-        self.backward()
+        """The training step's compute: one hipGraph replay once the executor has captured it."""
+        self.exe.forward_backward(self._feed(data_batch))
 
     def update(self):
         dist = _dist()

@@ -268,3 +268,50 @@ def test_iterator_contract():
         if n >= 3:
             break
     assert n == 3
+
+
+def test_hip_graph_replay_matches_eager(monkeypatch):
+    """The captured forward+backward / optimizer graphs must compute what the eager step computes: two executors,
+    same parameters and inputs, five steps each (two eager warm-up steps, capture on the third, replays after)."""
+    import sniper_amd.mx as mx
+    from sniper_amd.engine.executor import Executor
+    A, B, S = 3, 2, 64
+    F = S // 8
+    shapes = dict(data=(B, 3, S, S), label=(B, A * F * F), bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F))
+    rs = np.random.RandomState(5)
+    results = []
+    for graphs in ('0', '1'):
+        monkeypatch.setenv('SNIPER_HIP_GRAPHS', graphs)
+        sym = _mini_graph(mx, A)
+        fixed = [n for n in sym.list_arguments() if any(p in n for p in ('conv0', 'bn0', 'bn_data'))]
+        ex = Executor(sym, shapes, True, fixed)
+        assert ex.use_graphs == (graphs == '1')
+        if not results:
+            args, _, auxs = sym.infer_shape(**shapes)
+            P, AUX = {}, {}
+            for name, shp in zip(sym.list_arguments(), args):
+                if name not in shapes:
+                    P[name] = rs.uniform(0.5, 1.5, shp).astype(np.float32) if name.endswith('_gamma') else \
+                        (rs.standard_normal(shp) * (0.1 if len(shp) == 1 else np.sqrt(2.0 / np.prod(shp[1:])))).astype(np.float32)
+            for name, shp in zip(sym.list_auxiliary_states(), auxs):
+                AUX[name] = rs.uniform(0.5, 1.5, shp).astype(np.float32)
+            feeds = [dict(data=(rs.standard_normal((B, 3, S, S)) * 2).astype(np.float32),
+                          label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.5, 0.3, 0.2]).astype(np.float32),
+                          bbox_target=rs.standard_normal((B, 4 * A, F, F)).astype(np.float32),
+                          bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.2).astype(np.float32)) for _ in range(5)]
+        ex.set_params(P, AUX)
+        outs = []
+        for i, feed in enumerate(feeds):
+            o = ex.forward_backward(feed)
+            outs.append([t.clone() for t in o])
+            ex.update(lr=1e-4 * (i + 1), wd=1e-3, momentum=0.9)     # a changing learning rate must reach the replayed graph
+        torch.cuda.synchronize()
+        if graphs == '1':
+            assert ex._graph_fb is not None and ex._graph_up is not None, 'hipGraph capture did not happen'
+        results.append((outs, {k: p.master.clone() for k, p in ex.params.items()}))
+    (oe, pe), (og, pg) = results
+    for a, b in zip(oe, og):
+        for x, y in zip(a, b):
+            assert_close(y.cpu().numpy(), x.cpu().numpy(), 2e-2, 2e-2 * float(x.abs().max()) + 1e-6, 'graph vs eager outputs')
+    for k in pe:
+        assert_close(pg[k].cpu().numpy(), pe[k].cpu().numpy(), 2e-2, 2e-2 * float(pe[k].abs().max()) + 1e-6, 'graph vs eager ' + k)
