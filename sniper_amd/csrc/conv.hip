@@ -25,6 +25,8 @@
 // the slow dimension of both dY and X); see conv_wgrad_kernel below.
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -177,6 +179,198 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
 }
 
+// ---- pipelined variant: BK = 64, two register sets in flight ------------------------------------
+// The BK = 32 kernel above hides one K-step (~0.1 us of MFMA) of global-load latency; measured, a K-step costs
+// ~1 us even with 2.5 workgroups per CU (rpn 3x3: 612 TFLOP/s).  A 128x128 fp16 tile needs ~150 GB/s per CU at the
+// MFMA rate, i.e. ~100 KB in flight per CU at ~1 us of loaded latency.  This variant keeps TWO tiles (2 x 32 KB per
+// workgroup) in flight in registers ahead of the one being multiplied and halves the barriers per FLOP:
+//   step t:  ds_write tile t+1 (set (t+1)&1, issued two steps ago) -> LDS[(t+1)&1]
+//            issue global loads of tile t+3 into that set
+//            16 ds_read_b128 + 32 MFMA on LDS[t&1]
+//            barrier
+// LDS rows are 128 B (64 channels); 16-byte chunk c of row r sits at c ^ (r & 7): conflict-free for the 8-lane
+// ds_write_b128 groups (8 chunks of one row) and the 16-lane ds_read_b128 groups (16 rows, chunk q / q+1).
+// Workgroup -> tile mapping is XCD-aware: the Nout/128 column tiles that share one 128-row A panel run back to back
+// on the SAME XCD (linear id % 8 = XCD), so the panel is fetched into one L2 once instead of once per column tile.
+template <bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams p, int mtiles, int ntiles) {
+  constexpr int BM = 128, BN = 128, BK = 64;
+  constexpr int MI = 4, NI = 4, AR = 4, BR = 4;   // 16-byte chunks per thread per tile: 128 rows x 8 chunks / 256
+  __shared__ __attribute__((aligned(16))) half_t sA[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) half_t sB[2][BN * BK];
+
+  const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
+  const int nt = j % ntiles, mt = (j / ntiles) * 8 + xcd;
+  if (mt >= mtiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int chunk = tid & 7, lrow = tid >> 3;   // rows lrow + 32*i
+
+  int a_base[AR], a_h[AR], a_w[AR];
+  bool a_ok[AR];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int img = mm / HoWo, rem = mm - img * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    a_base[i] = img * p.H * p.W;
+    if (DGRAD) { a_h[i] = oy + p.pad; a_w[i] = ox + p.pad; }
+    else { a_h[i] = oy * p.stride - p.pad; a_w[i] = ox * p.stride - p.pad; }
+  }
+  const int taps = p.KH * p.KW;
+  const int kpt = p.Cin / BK;          // host guarantees Cin % 64 == 0
+  const int nk = taps * kpt;
+  const unsigned wrow_bytes = (unsigned)(taps * p.Cin) * 2u;
+  // rows lrow + 32*i share (row & 7): one swizzled LDS store address, the others are immediates (+32 rows = 4 KB)
+  const int st_off = (lrow * 8 + (chunk ^ (lrow & 7))) * 8;
+  // weight rows n0 + lrow + 32*i: byte offset of row i = w_off0 + i * 32 * wrow_bytes (zero-filled beyond Nout)
+  const unsigned w_off0 = (unsigned)(n0 + lrow) * wrow_bytes + (unsigned)chunk * 16u;
+  const char *xb = reinterpret_cast<const char *>(p.x), *wb = reinterpret_cast<const char *>(p.w);
+  const unsigned in_ps_bytes = (unsigned)p.in_ps * 2u;
+
+  // Loads are unconditional (a padded tap / a row beyond M or Nout reads a harmless valid address) and the zero
+  // fill is applied from a bit mask when the set is written to LDS: no divergent branch around any load.
+  unsigned b_mask = 0;
+#pragma unroll
+  for (int i = 0; i < BR; ++i) b_mask |= (n0 + lrow + 32 * i < p.Nout ? 1u : 0u) << i;
+  auto gload = [&](int kt, half8 (&ra)[AR], half8 (&rb)[BR], unsigned &mask) {
+    const int tap = kt / kpt, cb = (kt - tap * kpt) * (BK * 2) + chunk * 16;   // byte offset of this thread's channels
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    mask = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int sy, sx;
+      bool ok = a_ok[i];
+      if (DGRAD) {
+        const int ty = a_h[i] - kh * p.dil, tx = a_w[i] - kw * p.dil;
+        sy = ty / p.stride; sx = tx / p.stride;
+        ok = ok && ty >= 0 && tx >= 0 && (sy * p.stride == ty) && (sx * p.stride == tx) && sy < p.H && sx < p.W;
+      } else {
+        sy = a_h[i] + kh * p.dil; sx = a_w[i] + kw * p.dil;
+        ok = ok && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+      }
+      const unsigned off = ok ? (unsigned)(a_base[i] + sy * p.W + sx) * in_ps_bytes + (unsigned)cb : 0u;
+      ra[i] = *reinterpret_cast<const half8 *>(xb + off);
+      mask |= (ok ? 1u : 0u) << i;
+    }
+    const unsigned wo = w_off0 + (unsigned)(tap * p.Cin) * 2u + (unsigned)(cb - chunk * 16);
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      rb[i] = *reinterpret_cast<const half8 *>(wb + (((b_mask >> i) & 1u) ? wo + (unsigned)i * 32u * wrow_bytes : 0u));
+  };
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto lstore = [&](int buf, const half8 (&ra)[AR], const half8 (&rb)[BR], unsigned mask) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<half8 *>(&sA[buf][st_off + i * 32 * BK]) = ((mask >> i) & 1u) ? ra[i] : zero8;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<half8 *>(&sB[buf][st_off + i * 32 * BK]) = ((b_mask >> i) & 1u) ? rb[i] : zero8;
+  };
+
+  floatx4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment rows wm*64 + i*16 + fr all share (row & 7) = fr & 7: one base per k-substep, rows by immediates
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = fq ^ (fr & 7);
+  const int a_rd = (wm * 64 + fr) * BK, b_rd = (wn * 64 + fr) * BK;
+  // The product is formed TRANSPOSED (weights as the MFMA A operand): D^T[n][m] puts 4 consecutive output channels
+  // n = fq*4 + r of one pixel m = fr into each lane, so the epilogue stores 8 bytes per (i, jn) instead of 4 x 2.
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int co = (sw ^ (ks * 4)) * 8;
+      half8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const half8 *>(&sA[buf][a_rd + i * 16 * BK + co]);
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) fb[jn] = *reinterpret_cast<const half8 *>(&sB[buf][b_rd + jn * 16 * BK + co]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);
+    }
+  };
+
+  half8 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
+  unsigned mk0 = 0, mk1 = 0;
+  gload(0, ra0, rb0, mk0);
+  if (nk > 1) gload(1, ra1, rb1, mk1);
+  lstore(0, ra0, rb0, mk0);
+  if (nk > 2) gload(2, ra0, rb0, mk0);
+  __syncthreads();
+  for (int t = 0; t < nk; t += 2) {
+    // even step t: tile t+1 lives in set 1, tile t+2 in set 0
+    if (t + 1 < nk) lstore(1, ra1, rb1, mk1);
+    if (t + 3 < nk) gload(t + 3, ra1, rb1, mk1);
+    compute(0);
+    __syncthreads();
+    if (t + 1 >= nk) break;
+    // odd step t+1: tile t+2 lives in set 0, tile t+3 in set 1
+    if (t + 2 < nk) lstore(0, ra0, rb0, mk0);
+    if (t + 4 < nk) gload(t + 4, ra0, rb0, mk0);
+    compute(1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (fr, fq) holds, for each (i, jn), pixel m = ..+fr and channels n = ..+fq*4 .. +3
+  const bool vec = (p.out_ps % 4 == 0) && (p.Nout % 4 == 0) && (!p.res || p.res_ps % 4 == 0);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      const int n = n0 + wn * 64 + jn * 16 + fq * 4;
+      if (n >= p.Nout) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][jn][r];
+      if (vec) {
+        if (p.bias) {
+          const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (p.res) {
+          const half4 rv = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.res_ps + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.out_f32) {
+          *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.y) + (size_t)m * p.out_ps + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          half4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+          *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + n) = o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.Nout) continue;
+          float x = v[r];
+          if (p.bias) x += p.bias[n + r];
+          if (p.res) x += (float)p.res[(size_t)m * p.res_ps + n + r];
+          if (p.relu) x = x > 0.f ? x : 0.f;
+          if (p.out_f32) reinterpret_cast<float *>(p.y)[(size_t)m * p.out_ps + n + r] = x;
+          else reinterpret_cast<half_t *>(p.y)[(size_t)m * p.out_ps + n + r] = (half_t)x;
+        }
+      }
+    }
+  }
+}
+
 static int conv_check(const ConvParams &p, const char *who) {
   SN_REQUIRE(p.x && p.w && p.y, "%s: null pointer", who);
   SN_REQUIRE(p.N > 0 && p.H > 0 && p.W > 0 && p.Ho > 0 && p.Wo > 0 && p.Nout > 0, "%s: bad dims", who);
@@ -193,8 +387,12 @@ static int conv_check(const ConvParams &p, const char *who) {
 
 template <bool DGRAD>
 static int conv_launch(const ConvParams &p, hipStream_t s) {
-  // BN = 64 when the output is narrow (stage1 / RPN heads), 128 otherwise; BM = 128 always.
-  if (p.Nout <= 64) {
+  // BN = 64 when the output is narrow (stage1 / RPN heads), 128 otherwise; BM = 128 always.  Layers whose taps are
+  // whole 64-channel K-steps and 16-byte addressable take the pipelined kernel.
+  if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && !getenv("SNIPER_CONV_V1")) {
+    const int mtiles = sn_div_up(p.M, 128), ntiles = sn_div_up(p.Nout, 128);
+    hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, p, mtiles, ntiles);
+  } else if (p.Nout <= 64) {
     dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 64));
     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, DGRAD>), grid, dim3(256), 0, s, p);
   } else {

@@ -69,6 +69,8 @@ CONV_CASES = [
     (2, 320, 20, 24, 136, 3, 1, 1, 1, False, False, 0),  # partial 128-tiles in both channel dims, Wo < 32
     (2, 256, 32, 32, 256, 3, 1, 1, 1, False, False, 0),  # several K-splits of the weight gradient
     (1, 128, 40, 72, 64, 3, 2, 1, 1, False, False, 0),   # Wo = 36: two 32-pixel units per row, stride 2
+    (2, 128, 12, 12, 256, 1, 1, 0, 1, True, True, 1),    # pipelined kernel: bias + residual + ReLU epilogue
+    (1, 192, 9, 9, 130, 3, 1, 1, 1, True, False, 0),     # pipelined kernel, Cout % 4 != 0: scalar epilogue, 3 K-steps/tap
 ]
 
 
