@@ -234,33 +234,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
 
   // Loads are unconditional (a padded tap / a row beyond M or Nout reads a harmless valid address) and the zero
   // fill is applied from a bit mask when the set is written to LDS: no divergent branch around any load.
+  // K-steps are visited in order, so the (tap, channel block) decomposition is carried incrementally: the per-row
+  // source offsets are recomputed only when the tap changes (integer divisions cost ~40 VALU instructions each on
+  // CDNA; at 32 MFMAs per step they were the bottleneck), a step inside a tap just advances the channel offset.
   unsigned b_mask = 0;
 #pragma unroll
   for (int i = 0; i < BR; ++i) b_mask |= (n0 + lrow + 32 * i < p.Nout ? 1u : 0u) << i;
-  auto gload = [&](int kt, half8 (&ra)[AR], half8 (&rb)[BR], unsigned &mask) {
-    const int tap = kt / kpt, cb = (kt - tap * kpt) * (BK * 2) + chunk * 16;   // byte offset of this thread's channels
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    mask = 0;
+  unsigned w_off[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) w_off[i] = ((b_mask >> i) & 1u) ? w_off0 + (unsigned)i * 32u * wrow_bytes : (unsigned)chunk * 16u;
+  int g_kh = 0, g_kw = 0, g_kc = 0;          // next tile to load: tap (g_kh, g_kw), channel block g_kc
+  unsigned a_off[AR], a_cur = 0;              // per-row byte offset of the tap's source pixel (+ this thread's chunk), validity
+  auto tap_setup = [&]() {
+    a_cur = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int sy, sx;
       bool ok = a_ok[i];
       if (DGRAD) {
-        const int ty = a_h[i] - kh * p.dil, tx = a_w[i] - kw * p.dil;
-        sy = ty / p.stride; sx = tx / p.stride;
-        ok = ok && ty >= 0 && tx >= 0 && (sy * p.stride == ty) && (sx * p.stride == tx) && sy < p.H && sx < p.W;
+        const int ty = a_h[i] - g_kh * p.dil, tx = a_w[i] - g_kw * p.dil;
+        if (p.stride == 1) { sy = ty; sx = tx; }
+        else { sy = ty / p.stride; sx = tx / p.stride; ok = ok && (sy * p.stride == ty) && (sx * p.stride == tx); }
+        ok = ok && ty >= 0 && tx >= 0 && sy < p.H && sx < p.W;
       } else {
-        sy = a_h[i] + kh * p.dil; sx = a_w[i] + kw * p.dil;
+        sy = a_h[i] + g_kh * p.dil; sx = a_w[i] + g_kw * p.dil;
         ok = ok && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
       }
-      const unsigned off = ok ? (unsigned)(a_base[i] + sy * p.W + sx) * in_ps_bytes + (unsigned)cb : 0u;
-      ra[i] = *reinterpret_cast<const half8 *>(xb + off);
-      mask |= (ok ? 1u : 0u) << i;
+      a_off[i] = ok ? (unsigned)(a_base[i] + sy * p.W + sx) * in_ps_bytes + (unsigned)chunk * 16u : (unsigned)chunk * 16u;
+      a_cur |= (ok ? 1u : 0u) << i;
     }
-    const unsigned wo = w_off0 + (unsigned)(tap * p.Cin) * 2u + (unsigned)(cb - chunk * 16);
+  };
+  tap_setup();
+  auto gload = [&](half8 (&ra)[AR], half8 (&rb)[BR], unsigned &mask) {
+    const unsigned cbo = (unsigned)g_kc * (BK * 2);
+    mask = a_cur;
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      rb[i] = *reinterpret_cast<const half8 *>(wb + (((b_mask >> i) & 1u) ? wo + (unsigned)i * 32u * wrow_bytes : 0u));
+    for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const half8 *>(xb + (a_off[i] + (((a_cur >> i) & 1u) ? cbo : 0u)));
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      rb[i] = *reinterpret_cast<const half8 *>(wb + w_off[i]);
+      w_off[i] += ((b_mask >> i) & 1u) ? BK * 2 : 0;      // weight rows are [tap][Cin]: consecutive K-steps are contiguous
+    }
+    if (++g_kc == kpt) {
+      g_kc = 0;
+      if (++g_kw == p.KW) { g_kw = 0; ++g_kh; }
+      tap_setup();
+    }
   };
   const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto lstore = [&](int buf, const half8 (&ra)[AR], const half8 (&rb)[BR], unsigned mask) {
@@ -301,21 +320,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
 
   half8 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
   unsigned mk0 = 0, mk1 = 0;
-  gload(0, ra0, rb0, mk0);
-  if (nk > 1) gload(1, ra1, rb1, mk1);
+  gload(ra0, rb0, mk0);
+  if (nk > 1) gload(ra1, rb1, mk1);
   lstore(0, ra0, rb0, mk0);
-  if (nk > 2) gload(2, ra0, rb0, mk0);
+  if (nk > 2) gload(ra0, rb0, mk0);
   __syncthreads();
   for (int t = 0; t < nk; t += 2) {
     // even step t: tile t+1 lives in set 1, tile t+2 in set 0
     if (t + 1 < nk) lstore(1, ra1, rb1, mk1);
-    if (t + 3 < nk) gload(t + 3, ra1, rb1, mk1);
+    if (t + 3 < nk) gload(ra1, rb1, mk1);
     compute(0);
     __syncthreads();
     if (t + 1 >= nk) break;
     // odd step t+1: tile t+2 lives in set 0, tile t+3 in set 1
     if (t + 2 < nk) lstore(0, ra0, rb0, mk0);
-    if (t + 4 < nk) gload(t + 4, ra0, rb0, mk0);
+    if (t + 4 < nk) gload(ra0, rb0, mk0);
     compute(1);
     __syncthreads();
   }
@@ -564,7 +583,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // LDS image: 32 rows (pixels) x 256 B (128 channels); the 32-byte segment index is XORed with (row & 7) so that the
 // 8 rows a 32-lane service group touches fall on 8 distinct bank octets (reads) and the 8 lanes of a
 // ds_write_b128 group on 8 distinct 16-byte slots (writes).
-// Tile 128 (co) x 128 (ci) x 32 (pixels) per 256-thread workgroup, waves 2x2, register-staged double buffer.
+// Tile 128 (co) x 128 (ci) per 256-thread workgroup, waves 2x2.
 typedef short short4v __attribute__((vector_size(8)));
 
 __device__ __forceinline__ half8 tr_frag(const half_t *lds_tile, int off) {
@@ -577,8 +596,12 @@ __device__ __forceinline__ half8 tr_frag(const half_t *lds_tile, int off) {
   return u.h;
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p) {
-  constexpr int MI = 4, NI = 4, TILE = 32 * 128;
+// K-step = 64 pixels = two 32-pixel units (rows 0-31 / 32-63 of the LDS tile); two register sets in flight ahead of
+// the tile being multiplied, one barrier per 32 MFMAs (same pipeline as conv_igemm_p2_kernel).  Units are walked
+// with an incremental (img, oy, x-chunk) iterator -- no integer division in the loop -- that skips units whose
+// source row is padding; all of its state is workgroup-uniform.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams p) {
+  constexpr int MI = 4, NI = 4, TILE = 64 * 128;
   __shared__ __attribute__((aligned(16))) half_t sA[2][TILE];
   __shared__ __attribute__((aligned(16))) half_t sB[2][TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -592,16 +615,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
   const int nunits = p.N * p.Ho * cpr;
   const int u_begin = split * p.units_per_split, u_end = min(nunits, u_begin + p.units_per_split);
 
-  // loader: rows lr, lr+16 of the unit; 16-byte chunk `chunk` of the 128 channels
+  // loader: rows lr, lr+16 of each unit; 16-byte chunk `chunk` of the 128 channels
   const int lr = tid >> 4, chunk = tid & 15;
   const int a_c = co0 + chunk * 8, b_c = ci0 + chunk * 8;
   const bool a_cok = a_c < p.Cout, b_cok = b_c < p.Cin;
-  int st_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = lr + 16 * i;
-    st_off[i] = row * 128 + ((((chunk >> 1) ^ (row & 7)) << 4) | ((chunk & 1) << 3));
-  }
+  // rows lr + 16*i (i = 0..3): (row & 7) alternates between lr & 7 and (lr + 16) & 7 = lr & 7 -> one swizzle for all
+  const int st_off = lr * 128 + ((((chunk >> 1) ^ (lr & 7)) << 4) | ((chunk & 1) << 3));
   // fragment reads: lane (fr, fq) points at row fq*4 + fr/4, 8-byte piece fr%4 of the fragment's 32-byte segment
   const int row0 = fq * 4 + (fr >> 2), r7 = row0 & 7;
   int a_off[MI], b_off[NI];
@@ -610,36 +629,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
 #pragma unroll
   for (int j = 0; j < NI; ++j) b_off[j] = row0 * 128 + ((((wn * 4 + j) ^ r7) << 4) | ((fr & 3) << 2));
 
-  auto next_valid = [&](int u) {  // skip units whose whole source row is padding
-    for (; u < u_end; ++u) {
-      const int r = u / cpr, oy = r % p.Ho;
-      const int sy = oy * p.stride - p.pad + kh * p.dil;
-      if ((unsigned)sy < (unsigned)p.H) break;
-    }
-    return u;
-  };
-  half8 ra[2], rb[2];
-  auto gload = [&](int u) {
-    const int r = u / cpr, ox0 = (u - r * cpr) * 32;
-    const int img = r / p.Ho, oy = r - img * p.Ho;
-    const int sy = oy * p.stride - p.pad + kh * p.dil;
-    const half_t *dyr = p.dy + (size_t)r * p.Wo * p.dy_ps + a_c;
-    const half_t *xr = p.x + ((size_t)img * p.H + sy) * p.W * (size_t)p.x_ps + b_c;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ox = ox0 + lr + 16 * i, sx = ox * p.stride - p.pad + kw * p.dil;
-      half8 va = {0, 0, 0, 0, 0, 0, 0, 0}, vb = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ox < p.Wo && a_cok) va = *reinterpret_cast<const half8 *>(dyr + (size_t)ox * p.dy_ps);
-      if (ox < p.Wo && b_cok && (unsigned)sx < (unsigned)p.W) vb = *reinterpret_cast<const half8 *>(xr + (size_t)sx * p.x_ps);
-      ra[i] = va;
-      rb[i] = vb;
+  // unit iterator (uniform)
+  int it_left = u_end - u_begin;
+  int it_r = u_begin / cpr, it_xc = u_begin - it_r * cpr;
+  int it_img = it_r / p.Ho, it_oy = it_r - it_img * p.Ho;
+  auto it_advance = [&]() {
+    --it_left;
+    if (++it_xc == cpr) {
+      it_xc = 0;
+      ++it_r;
+      if (++it_oy == p.Ho) { it_oy = 0; ++it_img; }
     }
   };
-  auto lstore = [&](int buf) {
+  const char *dyb = reinterpret_cast<const char *>(p.dy), *xbp = reinterpret_cast<const char *>(p.x);
+  const unsigned dy_ps_b = (unsigned)p.dy_ps * 2u, x_ps_b = (unsigned)p.x_ps * 2u;
+  // one register set = one 64-pixel tile: rows {lr, lr+16} of unit 0 and of unit 1, A (dY) and B (X)
+  auto gload = [&](half8 (&ra)[4], half8 (&rb)[4], unsigned &mask) -> bool {
+    mask = 0;
+    bool any = false;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<half8 *>(&sA[buf][st_off[i]]) = ra[i];
-      *reinterpret_cast<half8 *>(&sB[buf][st_off[i]]) = rb[i];
+    for (int h = 0; h < 2; ++h) {
+      int sy = 0;
+      while (it_left > 0) {   // skip units whose whole source row is padding
+        sy = it_oy * p.stride - p.pad + kh * p.dil;
+        if ((unsigned)sy < (unsigned)p.H) break;
+        it_advance();
+      }
+      const bool have = it_left > 0;
+      any = any || have;
+      const int ox0 = it_xc * 32;
+      const unsigned dy_row = (unsigned)(it_r * p.Wo) * dy_ps_b + (unsigned)a_c * 2u;
+      const unsigned x_row = (unsigned)((it_img * p.H + sy) * p.W) * x_ps_b + (unsigned)b_c * 2u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ox = ox0 + lr + 16 * i, sx = ox * p.stride - p.pad + kw * p.dil;
+        const bool oka = have && ox < p.Wo && a_cok;
+        const bool okb = have && ox < p.Wo && b_cok && (unsigned)sx < (unsigned)p.W;
+        ra[h * 2 + i] = *reinterpret_cast<const half8 *>(dyb + (oka ? dy_row + (unsigned)ox * dy_ps_b : 0u));
+        rb[h * 2 + i] = *reinterpret_cast<const half8 *>(xbp + (okb ? x_row + (unsigned)sx * x_ps_b : 0u));
+        mask |= (oka ? 1u : 0u) << (h * 2 + i);
+        mask |= (okb ? 16u : 0u) << (h * 2 + i);
+      }
+      if (have) it_advance();
+    }
+    return any;
+  };
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto lstore = [&](int buf, const half8 (&ra)[4], const half8 (&rb)[4], unsigned mask) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // q = h*2 + i -> tile row h*32 + lr + 16*i
+      *reinterpret_cast<half8 *>(&sA[buf][st_off + q * 16 * 128]) = ((mask >> q) & 1u) ? ra[q] : zero8;
+      *reinterpret_cast<half8 *>(&sB[buf][st_off + q * 16 * 128]) = ((mask >> (4 + q)) & 1u) ? rb[q] : zero8;
     }
   };
 
@@ -648,31 +688,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradParams p)
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = tr_frag(sA[buf] + ks * 32 * 128, a_off[i]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = tr_frag(sB[buf] + ks * 32 * 128, b_off[j]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
 
-  int u = next_valid(u_begin);
-  if (u >= u_end) return;  // block-uniform
-  gload(u);
-  lstore(0);
+  half8 ra0[4], rb0[4], ra1[4], rb1[4];
+  unsigned mk0 = 0, mk1 = 0;
+  bool h0 = gload(ra0, rb0, mk0);          // tile 0
+  if (!h0) return;                         // block-uniform
+  bool h1 = gload(ra1, rb1, mk1);          // tile 1
+  lstore(0, ra0, rb0, mk0);
+  h0 = gload(ra0, rb0, mk0);               // tile 2
   __syncthreads();
-  int cur = 0;
   while (true) {
-    const int un = next_valid(u + 1);
-    const bool more = un < u_end;
-    if (more) gload(un);
-    half8 fa[MI], fb[NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) fa[i] = tr_frag(sA[cur], a_off[i]);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) fb[j] = tr_frag(sB[cur], b_off[j]);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    if (more) lstore(cur ^ 1);
+    // LDS[0] = tile t; set 1 = tile t+1 (h1), set 0 = tile t+2 (h0)
+    if (h1) lstore(1, ra1, rb1, mk1);
+    const bool h1n = h1 ? gload(ra1, rb1, mk1) : false;   // tile t+3
+    compute(0);
     __syncthreads();
-    if (!more) break;
-    u = un;
-    cur ^= 1;
+    if (!h1) break;
+    // LDS[1] = tile t+1; set 0 = tile t+2 (h0), set 1 = tile t+3 (h1n)
+    if (h0) lstore(0, ra0, rb0, mk0);
+    const bool h0n = h0 ? gload(ra0, rb0, mk0) : false;   // tile t+4
+    compute(1);
+    __syncthreads();
+    if (!h0) break;
+    h1 = h1n;
+    h0 = h0n;
   }
   // D: row = co (A operand), col = ci (B operand)
 #pragma unroll
@@ -711,8 +764,8 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
   // 16-byte channel runs: pixel strides multiples of 8 that cover the last (possibly partial) chunk, aligned bases
   const bool vec_ok = dy_pix_stride % 8 == 0 && x_pix_stride % 8 == 0 && dy_pix_stride >= sn_div_up(Cout, 8) * 8 &&
                       x_pix_stride >= sn_div_up(Cin, 8) * 8 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0;
-  // K-splits: ~3 workgroups per CU (LDS 32 KB, ~128 VGPR); every split adds a 128x128 atomic epilogue
-  int splits = sn_div_up(vec_ok ? 768 : 1024, gx * gy * taps);
+  // K-splits: 2 workgroups per CU (LDS 64 KB); every split adds a 128x128 atomic epilogue
+  int splits = sn_div_up(vec_ok ? 512 : 1024, gx * gy * taps);
   if (splits > nunits) splits = nunits;
   if (splits < 1) splits = 1;
   p.units_per_split = sn_div_up(nunits, splits);
