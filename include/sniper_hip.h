@@ -122,6 +122,9 @@ int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *res
 /* conv0 on the packed stem input (xp (N,Hp,Wp,4) fp16 from sn_pack_stem_input; w [Cout][KH][KWP*4]). */
 int sn_conv_stem_fwd(const void *xp, const void *w, const float *bias, void *y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
                      int out_pix_stride, int KH, int KWP, int stride, int relu, int out_f32, sn_stream_t stream);
+/* Weight gradient of the stem convolution, accumulated into the packed fp32 weight [Cout][KH][KWP*4]. */
+int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp, int Wp, int Ho, int Wo, int Cout, int dy_pix_stride,
+                       int KH, int KWP, int stride, sn_stream_t stream);
 /* Data gradient; wt = weights as [Cin][KH*KW][Cout] fp16; `accumulate` (fp16, may alias dx) is added. */
 int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
                   int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil,
@@ -148,10 +151,23 @@ int sn_bn_finalize(const void *ws, int M, int C, float eps, float momentum, cons
 int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int C, float eps,
                              float *scale, float *shift, sn_stream_t stream);
 int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, const float *scale, const float *shift, int relu,
-                sn_stream_t stream);
+                sn_stream_t stream); /* relu: 0 none, 1 ReLU, 2 ReLU6 = clip(0,6); same code in sn_bn_backward */
 int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy, int ps_x, int ps_acc,
                    int ps_dx, const float *scale, const float *shift, const float *mean, const float *invstd, int relu, void *ws,
                    float *dgamma, float *dbeta, sn_stream_t stream);
+
+/* Depthwise 3x3 convolution (Convolution with num_group == channels; mobilenetv2_e2e.py:27-43,57-66), channels-last
+ * fp16, weights [C][KH*KW] fp16.  dgrad adds `accumulate` (may be NULL / alias dx); wgrad accumulates (+=) into fp32
+ * dw [C][KH*KW]. */
+int sn_dwconv_fwd(const void *x, const void *w, void *y, int N, int H, int W, int C, int in_pix_stride, int out_pix_stride, int KH,
+                  int KW, int stride, int pad, int dil, sn_stream_t stream);
+int sn_dwconv_dgrad(const void *dy, const void *w, const void *accumulate, void *dx, int N, int H, int W, int C, int dy_pix_stride,
+                    int acc_pix_stride, int dx_pix_stride, int KH, int KW, int stride, int pad, int dil, sn_stream_t stream);
+int sn_dwconv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int C, int dy_pix_stride, int x_pix_stride,
+                    int KH, int KW, int stride, int pad, int dil, sn_stream_t stream);
+/* clip(lo, hi) (mx.sym.clip; relu6) forward, or backward = (lo <= ref <= hi ? a : 0) [+ accumulate]. */
+int sn_clip_f16(const void *a, const void *ref, const void *accumulate, void *y, long rows, int C, int ps_a, int ps_ref, int ps_acc,
+                int ps_y, float lo, float hi, int backward, sn_stream_t stream);
 
 /* fp16 channels-last element-wise: mode 0 relu(a), 1 a+b, 2 relu-backward (ref>0 ? a : 0) [+ b]. */
 int sn_ew_f16(const void *a, const void *b, const void *ref, void *y, long rows, int C, int ps_a, int ps_b, int ps_ref, int ps_y,

@@ -45,6 +45,7 @@ struct ConvParams {
   int KH, KW, stride, pad, dil;
   int M;               // N*Ho*Wo
   int relu, out_f32;
+  unsigned x_bytes, w_bytes;  // addressable extent of x / w (buffer-descriptor bounds of the pipelined kernel)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
@@ -232,21 +233,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
   const char *xb = reinterpret_cast<const char *>(p.x), *wb = reinterpret_cast<const char *>(p.w);
   const unsigned in_ps_bytes = (unsigned)p.in_ps * 2u;
 
-  // Loads are unconditional (a padded tap / a row beyond M or Nout reads a harmless valid address) and the zero
-  // fill is applied from a bit mask when the set is written to LDS: no divergent branch around any load.
-  // K-steps are visited in order, so the (tap, channel block) decomposition is carried incrementally: the per-row
-  // source offsets are recomputed only when the tap changes (integer divisions cost ~40 VALU instructions each on
-  // CDNA; at 32 MFMAs per step they were the bottleneck), a step inside a tap just advances the channel offset.
-  unsigned b_mask = 0;
+  // Loads go through buffer descriptors (buffer_load_dwordx4 ... offen): a row that must read as zero -- padded tap,
+  // pixel beyond M, weight row beyond Nout -- simply carries an out-of-range voffset and the hardware returns 0, so
+  // there is no branch and no select anywhere.  K-steps are visited in order: the per-row voffsets change only when
+  // the tap changes (the integer divisions of the tap decomposition cost ~40 VALU instructions each on CDNA and
+  // dominated the step before); inside a tap a step only moves the descriptors' base (scalar ALU).  The loop body is
+  // 32 MFMA + 16 ds_read + 8 ds_write + 8 buffer_load and a handful of VALU.
+  constexpr unsigned kOob = 0xFFFFFF00u;
+  unsigned w_voff[BR];
 #pragma unroll
-  for (int i = 0; i < BR; ++i) b_mask |= (n0 + lrow + 32 * i < p.Nout ? 1u : 0u) << i;
-  unsigned w_off[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) w_off[i] = ((b_mask >> i) & 1u) ? w_off0 + (unsigned)i * 32u * wrow_bytes : (unsigned)chunk * 16u;
-  int g_kh = 0, g_kw = 0, g_kc = 0;          // next tile to load: tap (g_kh, g_kw), channel block g_kc
-  unsigned a_off[AR], a_cur = 0;              // per-row byte offset of the tap's source pixel (+ this thread's chunk), validity
+  for (int i = 0; i < BR; ++i) w_voff[i] = (n0 + lrow + 32 * i < p.Nout) ? w_off0 + (unsigned)i * 32u * wrow_bytes : kOob;
+  int g_kh = 0, g_kw = 0, g_kc = 0, g_kt = 0;   // next tile to load: tap (g_kh, g_kw), channel block g_kc, K-step g_kt
+  unsigned a_voff[AR];
   auto tap_setup = [&]() {
-    a_cur = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int sy, sx;
@@ -260,33 +259,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
         sy = a_h[i] + g_kh * p.dil; sx = a_w[i] + g_kw * p.dil;
         ok = ok && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
       }
-      a_off[i] = ok ? (unsigned)(a_base[i] + sy * p.W + sx) * in_ps_bytes + (unsigned)chunk * 16u : (unsigned)chunk * 16u;
-      a_cur |= (ok ? 1u : 0u) << i;
+      a_voff[i] = ok ? (unsigned)(a_base[i] + sy * p.W + sx) * in_ps_bytes + (unsigned)chunk * 16u : kOob;
     }
   };
   tap_setup();
-  auto gload = [&](half8 (&ra)[AR], half8 (&rb)[BR], unsigned &mask) {
-    const unsigned cbo = (unsigned)g_kc * (BK * 2);
-    mask = a_cur;
+  auto gload = [&](half8 (&ra)[AR], half8 (&rb)[BR]) {
+    const unsigned cbo = (unsigned)g_kc * (BK * 2), wbo = (unsigned)g_kt * (BK * 2);   // uniform
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb) + cbo, 0, (int)(p.x_bytes - cbo), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb) + wbo, 0, (int)(p.w_bytes - wbo), 0x00020000);
 #pragma unroll
-    for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const half8 *>(xb + (a_off[i] + (((a_cur >> i) & 1u) ? cbo : 0u)));
+    for (int i = 0; i < AR; ++i) ra[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], 0, 0));
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      rb[i] = *reinterpret_cast<const half8 *>(wb + w_off[i]);
-      w_off[i] += ((b_mask >> i) & 1u) ? BK * 2 : 0;      // weight rows are [tap][Cin]: consecutive K-steps are contiguous
-    }
+    for (int i = 0; i < BR; ++i) rb[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff[i], 0, 0));
+    ++g_kt;
     if (++g_kc == kpt) {
       g_kc = 0;
       if (++g_kw == p.KW) { g_kw = 0; ++g_kh; }
       tap_setup();
     }
   };
-  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto lstore = [&](int buf, const half8 (&ra)[AR], const half8 (&rb)[BR], unsigned mask) {
+  auto lstore = [&](int buf, const half8 (&ra)[AR], const half8 (&rb)[BR]) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<half8 *>(&sA[buf][st_off + i * 32 * BK]) = ((mask >> i) & 1u) ? ra[i] : zero8;
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<half8 *>(&sA[buf][st_off + i * 32 * BK]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<half8 *>(&sB[buf][st_off + i * 32 * BK]) = ((b_mask >> i) & 1u) ? rb[i] : zero8;
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<half8 *>(&sB[buf][st_off + i * 32 * BK]) = rb[i];
   };
 
   floatx4 acc[MI][NI];
@@ -319,22 +315,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
   };
 
   half8 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
-  unsigned mk0 = 0, mk1 = 0;
-  gload(ra0, rb0, mk0);
-  if (nk > 1) gload(ra1, rb1, mk1);
-  lstore(0, ra0, rb0, mk0);
-  if (nk > 2) gload(ra0, rb0, mk0);
+  gload(ra0, rb0);
+  if (nk > 1) gload(ra1, rb1);
+  lstore(0, ra0, rb0);
+  if (nk > 2) gload(ra0, rb0);
   __syncthreads();
   for (int t = 0; t < nk; t += 2) {
     // even step t: tile t+1 lives in set 1, tile t+2 in set 0
-    if (t + 1 < nk) lstore(1, ra1, rb1, mk1);
-    if (t + 3 < nk) gload(ra1, rb1, mk1);
+    if (t + 1 < nk) lstore(1, ra1, rb1);
+    if (t + 3 < nk) gload(ra1, rb1);
     compute(0);
     __syncthreads();
     if (t + 1 >= nk) break;
     // odd step t+1: tile t+2 lives in set 0, tile t+3 in set 1
-    if (t + 2 < nk) lstore(0, ra0, rb0, mk0);
-    if (t + 4 < nk) gload(ra0, rb0, mk0);
+    if (t + 2 < nk) lstore(0, ra0, rb0);
+    if (t + 4 < nk) gload(ra0, rb0);
     compute(1);
     __syncthreads();
   }
@@ -408,9 +403,15 @@ template <bool DGRAD>
 static int conv_launch(const ConvParams &p, hipStream_t s) {
   // BN = 64 when the output is narrow (stage1 / RPN heads), 128 otherwise; BM = 128 always.  Layers whose taps are
   // whole 64-channel K-steps and 16-byte addressable take the pipelined kernel.
-  if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && !getenv("SNIPER_CONV_V1")) {
+  const unsigned long x_bytes = ((unsigned long)p.N * p.H * p.W - 1) * p.in_ps * 2 + (unsigned long)p.Cin * 2;
+  const unsigned long w_bytes = (unsigned long)p.Nout * p.KH * p.KW * p.Cin * 2;
+  if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul &&
+      !getenv("SNIPER_CONV_V1")) {
+    ConvParams q = p;
+    q.x_bytes = (unsigned)x_bytes;
+    q.w_bytes = (unsigned)w_bytes;
     const int mtiles = sn_div_up(p.M, 128), ntiles = sn_div_up(p.Nout, 128);
-    hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, p, mtiles, ntiles);
+    hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, q, mtiles, ntiles);
   } else if (p.Nout <= 64) {
     dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 64));
     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, DGRAD>), grid, dim3(256), 0, s, p);
@@ -643,9 +644,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   };
   const char *dyb = reinterpret_cast<const char *>(p.dy), *xbp = reinterpret_cast<const char *>(p.x);
   const unsigned dy_ps_b = (unsigned)p.dy_ps * 2u, x_ps_b = (unsigned)p.x_ps * 2u;
+  // Buffer-descriptor loads (out-of-range voffset / exhausted descriptor -> zeros, no branch, no select): the
+  // descriptor of a unit covers exactly the rest of its dY row and its source X row, so pixels beyond Wo and source
+  // columns outside [0, W) read as zero by construction.
+  constexpr unsigned kOob = 0xFFFFFF00u;
+  unsigned dy_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dy_voff[i] = a_cok ? (unsigned)(lr + 16 * i) * dy_ps_b + (unsigned)a_c * 2u : kOob;
   // one register set = one 64-pixel tile: rows {lr, lr+16} of unit 0 and of unit 1, A (dY) and B (X)
-  auto gload = [&](half8 (&ra)[4], half8 (&rb)[4], unsigned &mask) -> bool {
-    mask = 0;
+  auto gload = [&](half8 (&ra)[4], half8 (&rb)[4]) -> bool {
     bool any = false;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -658,28 +665,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
       const bool have = it_left > 0;
       any = any || have;
       const int ox0 = it_xc * 32;
-      const unsigned dy_row = (unsigned)(it_r * p.Wo) * dy_ps_b + (unsigned)a_c * 2u;
-      const unsigned x_row = (unsigned)((it_img * p.H + sy) * p.W) * x_ps_b + (unsigned)b_c * 2u;
+      const size_t dy_base = ((size_t)it_r * p.Wo + ox0) * dy_ps_b;
+      const size_t x_base = ((size_t)it_img * p.H + (have ? sy : 0)) * p.W * (size_t)x_ps_b;
+      const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(dyb) + (have ? dy_base : 0), 0, have ? (int)((unsigned)(p.Wo - ox0) * dy_ps_b) : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(xbp) + (have ? x_base : 0), 0, have ? (int)((unsigned)p.W * x_ps_b) : 0, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ox = ox0 + lr + 16 * i, sx = ox * p.stride - p.pad + kw * p.dil;
-        const bool oka = have && ox < p.Wo && a_cok;
-        const bool okb = have && ox < p.Wo && b_cok && (unsigned)sx < (unsigned)p.W;
-        ra[h * 2 + i] = *reinterpret_cast<const half8 *>(dyb + (oka ? dy_row + (unsigned)ox * dy_ps_b : 0u));
-        rb[h * 2 + i] = *reinterpret_cast<const half8 *>(xbp + (okb ? x_row + (unsigned)sx * x_ps_b : 0u));
-        mask |= (oka ? 1u : 0u) << (h * 2 + i);
-        mask |= (okb ? 16u : 0u) << (h * 2 + i);
+        const bool okb = ox < p.Wo && b_cok && (unsigned)sx < (unsigned)p.W;
+        ra[h * 2 + i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rdy, dy_voff[i], 0, 0));
+        rb[h * 2 + i] = __builtin_bit_cast(
+            half8, __builtin_amdgcn_raw_buffer_load_b128(rxx, okb ? (unsigned)sx * x_ps_b + (unsigned)b_c * 2u : kOob, 0, 0));
       }
       if (have) it_advance();
     }
     return any;
   };
-  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto lstore = [&](int buf, const half8 (&ra)[4], const half8 (&rb)[4], unsigned mask) {
+  auto lstore = [&](int buf, const half8 (&ra)[4], const half8 (&rb)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // q = h*2 + i -> tile row h*32 + lr + 16*i
-      *reinterpret_cast<half8 *>(&sA[buf][st_off + q * 16 * 128]) = ((mask >> q) & 1u) ? ra[q] : zero8;
-      *reinterpret_cast<half8 *>(&sB[buf][st_off + q * 16 * 128]) = ((mask >> (4 + q)) & 1u) ? rb[q] : zero8;
+      *reinterpret_cast<half8 *>(&sA[buf][st_off + q * 16 * 128]) = ra[q];
+      *reinterpret_cast<half8 *>(&sB[buf][st_off + q * 16 * 128]) = rb[q];
     }
   };
 
@@ -704,23 +712,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   };
 
   half8 ra0[4], rb0[4], ra1[4], rb1[4];
-  unsigned mk0 = 0, mk1 = 0;
-  bool h0 = gload(ra0, rb0, mk0);          // tile 0
+  bool h0 = gload(ra0, rb0);               // tile 0
   if (!h0) return;                         // block-uniform
-  bool h1 = gload(ra1, rb1, mk1);          // tile 1
-  lstore(0, ra0, rb0, mk0);
-  h0 = gload(ra0, rb0, mk0);               // tile 2
+  bool h1 = gload(ra1, rb1);               // tile 1
+  lstore(0, ra0, rb0);
+  h0 = gload(ra0, rb0);                    // tile 2
   __syncthreads();
   while (true) {
     // LDS[0] = tile t; set 1 = tile t+1 (h1), set 0 = tile t+2 (h0)
-    if (h1) lstore(1, ra1, rb1, mk1);
-    const bool h1n = h1 ? gload(ra1, rb1, mk1) : false;   // tile t+3
+    if (h1) lstore(1, ra1, rb1);
+    const bool h1n = h1 ? gload(ra1, rb1) : false;   // tile t+3
     compute(0);
     __syncthreads();
     if (!h1) break;
     // LDS[1] = tile t+1; set 0 = tile t+2 (h0), set 1 = tile t+3 (h1n)
-    if (h0) lstore(0, ra0, rb0, mk0);
-    const bool h0n = h0 ? gload(ra0, rb0, mk0) : false;   // tile t+4
+    if (h0) lstore(0, ra0, rb0);
+    const bool h0n = h0 ? gload(ra0, rb0) : false;   // tile t+4
     compute(1);
     __syncthreads();
     if (!h0) break;
@@ -774,6 +781,30 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
     hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
   else
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// Weight gradient of the stem convolution on the packed input of sn_pack_stem_input (MobileNetV2's first 3x3/2 conv
+// is trainable: `conv1` in its FIXED_PARAMS matches no parameter name of that network).  dw is the packed weight
+// [Cout][KH][KWP*4] fp32 (accumulated into); geometry as sn_conv_stem_fwd.  The packed rows are only 8-byte aligned,
+// so this runs on the gather kernel (version 1).
+SN_EXPORT int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
+                                 int dy_pix_stride, int KH, int KWP, int stride, sn_stream_t stream) {
+  SN_REQUIRE(dy && xp && dw && N > 0 && Ho > 0 && Wo > 0 && Cout > 0, "sn_conv_stem_wgrad: bad arguments");
+  SN_REQUIRE((Ho - 1) * stride + KH <= Hp && (Wo - 1) * stride + KWP <= Wp, "sn_conv_stem_wgrad: padded input too small");
+  WgradParams p;
+  p.dy = (const half_t *)dy; p.x = (const half_t *)xp; p.dw = dw;
+  p.N = N; p.H = Hp; p.W = Wp; p.Ho = Ho; p.Wo = Wo; p.Cin = 4 * KWP; p.Cout = Cout; p.dy_ps = dy_pix_stride; p.x_ps = 4;
+  p.KH = KH; p.KW = 1; p.stride = stride; p.pad = 0; p.dil = 1;
+  const int gx = sn_div_up(Cout, 128), gy = sn_div_up(p.Cin, 128);
+  const int nunits = N * Ho * sn_div_up(Wo, 32);
+  int splits = sn_div_up(1024, gx * gy * KH);
+  if (splits > nunits) splits = nunits;
+  if (splits < 1) splits = 1;
+  p.units_per_split = sn_div_up(nunits, splits);
+  splits = sn_div_up(nunits, p.units_per_split);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, KH * splits), dim3(256), 0, sn_stream(stream), p);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -59,12 +59,17 @@ SN_EXPORT int sn_pack_stem_input(const float *x_nchw, void *out, int N, int C, i
 // 16-byte loads in flight (HBM-bound: bytes in flight per CU decide the rate, guide section "memory").
 //   bn_stats    : per-channel sum and sum of squares -> fp64 accumulators (one atomic per block and channel)
 //   bn_finalize : mean/var -> scale = gamma*invstd, shift = beta - mean*scale; running stats
-//   bn_apply    : y = relu?(x*scale + shift)
+//   bn_apply    : y = act(x*scale + shift), act = none / relu / relu6 (`relu` argument 0 / 1 / 2)
 //   bn_bwd_reduce / bn_bwd_dx : gradients through (ReLU o BN) in training mode
 // BatchNorm(fix_gamma=False, eps=2e-5, momentum) call sites: resnet_mx_101_e2e.py:38-58.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBnThreads = 256;
 constexpr int kBnUnroll = 4;
+
+// gradient mask of the fused activation: act 0 none, 1 relu (y > 0), 2 relu6 = clip(0,6) (0 <= y <= 6, mx.sym.clip's rule)
+__device__ __forceinline__ bool bn_act_pass(float y, int act) {
+  return act == 0 || (act == 1 ? y > 0.f : (y >= 0.f && y <= 6.f));
+}
 
 struct BnMap {
   int cb, rpp, chunk, rl;
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const half_t *__restrict_
     for (int j = 0; j < 8; ++j) {
       float f = (float)v[j] * scale[chunk * 8 + j] + shift[chunk * 8 + j];
       if (relu) f = f > 0.f ? f : 0.f;
+      if (relu == 2) f = f < 6.f ? f : 6.f;   // relu6 = clip(0, 6) (mobilenetv2_e2e.py:18-19)
       o[j] = (half_t)f;
     }
     *reinterpret_cast<half8 *>(y + r * ps_out + chunk * 8) = o;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
       for (int j = 0; j < 8; ++j) {
         const float xf = (float)v[j];
         float gf = (float)g[j];
-        if (relu && !(xf * sc[j] + sh[j] > 0.f)) gf = 0.f;
+        if (!bn_act_pass(xf * sc[j] + sh[j], relu)) gf = 0.f;
         s[j] += gf;
         q[j] += gf * (xf - mu[j]);
       }
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
     for (int j = 0; j < 8; ++j) {
       const float xf = (float)v[j];
       float gf = (float)g[j];
-      if (relu && !(xf * sc[j] + sh[j] > 0.f)) gf = 0.f;
+      if (!bn_act_pass(xf * sc[j] + sh[j], relu)) gf = 0.f;
       o[j] = (half_t)(sc[j] * gf + kb[j] * xf + kd[j] + (float)a[j]);
     }
     *reinterpret_cast<half8 *>(po + r * ps_dx) = o;

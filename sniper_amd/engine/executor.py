@@ -69,6 +69,11 @@ class Param(object):
         a = np.asarray(a, np.float32).reshape(self.ref_shape)
         if self.kind == 'conv':
             return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+        if self.kind == 'stem':      # (O, C<=4, KH, KW) -> [O][KH][KWP*4], zero padded
+            kh, kw, kwp = self.fc_in
+            out = np.zeros((a.shape[0], kh, kwp, 4), np.float32)
+            out[:, :, :kw, :a.shape[1]] = a.transpose(0, 2, 3, 1)
+            return out.reshape(self.int_shape)
         if self.kind == 'fc' and self.fc_in is not None:
             c, h, w = self.fc_in
             return np.ascontiguousarray(a.reshape(a.shape[0], c, h, w).transpose(0, 2, 3, 1))
@@ -79,6 +84,9 @@ class Param(object):
         if self.kind == 'conv':
             o, i, kh, kw = self.ref_shape
             return np.ascontiguousarray(a.reshape(o, kh, kw, i).transpose(0, 3, 1, 2))
+        if self.kind == 'stem':
+            o, i, kh, kw = self.ref_shape
+            return np.ascontiguousarray(a.reshape(o, kh, self.fc_in[2], 4)[:, :, :kw, :i].transpose(0, 3, 1, 2))
         if self.kind == 'fc' and self.fc_in is not None:
             c, h, w = self.fc_in
             return np.ascontiguousarray(a.reshape(-1, h, w, c).transpose(0, 3, 1, 2)).reshape(self.ref_shape)
@@ -281,6 +289,9 @@ class Executor(object):
         if kind == 'conv':
             o, i, kh, kw = shp
             p.int_shape = (o, kh * kw, i)
+        elif kind == 'stem':
+            kh, kw, kwp = fc_in
+            p.int_shape = (shp[0], kh, kwp * 4)
         elif kind == 'fc':
             o = shp[0]
             if fc_in is not None:
@@ -290,6 +301,7 @@ class Executor(object):
                 p.int_shape = (o, 1, int(np.prod(shp[1:])))
         else:
             p.int_shape = tuple(shp)
+        p.numel = int(np.prod(p.int_shape))      # the packed stem layout is larger than the reference tensor
         p.trainable = self.for_training and not any(f == name for f in self.fixed)
         return p
 
@@ -352,7 +364,7 @@ class Executor(object):
                 a = a.asnumpy() if hasattr(a, 'asnumpy') else np.asarray(a)
                 if tuple(a.shape) != p.ref_shape:
                     raise ValueError('parameter %s: shape %s, expected %s' % (name, a.shape, p.ref_shape))
-                t = torch.from_numpy(p.to_internal(a)).to(self.device).view(p.int_shape)
+                t = torch.from_numpy(np.ascontiguousarray(p.to_internal(a))).to(self.device).view(p.int_shape)
                 p.master.copy_(t)
             elif not allow_missing:
                 raise KeyError('missing parameter %s' % name)

@@ -100,6 +100,9 @@ class BatchNormStep(Step):
         cons = ex.consumers.get((id(self.node), 0), [])
         self.relu = (not self.is_stem and len(cons) == 1 and cons[0].op == 'Activation' and
                      cons[0].attrs.get('act_type') == 'relu')
+        self.act = 1 if self.relu else 0      # fused activation code of the BN kernels: 0 none, 1 ReLU, 2 ReLU6
+        if not self.is_stem and len(cons) == 1 and _is_relu6(cons[0]):
+            self.act = 2
         if self.is_stem:
             self.y = self.new_out('f32', alloc=False)
             self.y.stem = (self.x, self.scale, self.shift)
@@ -139,7 +142,7 @@ class BatchNormStep(Step):
             hip.call('sn_bn_stats', x, M, c, c, self.bws, hip.stream())
             hip.call('sn_bn_finalize', self.bws, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
                      self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
-        hip.call('sn_bn_apply', x, self.y.t, M, c, c, c, self.scale, self.shift, 1 if self.relu else 0, hip.stream())
+        hip.call('sn_bn_apply', x, self.y.t, M, c, c, c, self.scale, self.shift, self.act, hip.stream())
 
     def backward(self):
         ex = self.ex
@@ -156,7 +159,7 @@ class BatchNormStep(Step):
         if self.x.needs_grad:
             dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty(x.shape, F16), False)
         hip.call('sn_bn_backward', self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale, self.shift,
-                 self.save_mean, self.save_invstd, 1 if self.relu else 0, self.bws,
+                 self.save_mean, self.save_invstd, self.act, self.bws,
                  self.gamma.grad if self.gamma.trainable else None, self.beta.grad if self.beta.trainable else None,
                  hip.stream())
         if self.x.needs_grad and self.x.fmt != 'act':
@@ -201,6 +204,56 @@ class ActivationStep(Step):
         self.y.grad = None
 
 
+def _is_relu6(node):
+    if node.op != 'clip':
+        return False
+    a = node.attrs
+    return float(a.get('a_min', a.get('amin', 1))) == 0.0 and float(a.get('a_max', a.get('amax', 0))) == 6.0
+
+
+@register('clip')
+class ClipStep(Step):
+    """mx.sym.clip(data, a_min, a_max) -- MobileNetV2's relu6 (mobilenetv2_e2e.py:18-19).  Behind a BatchNorm with
+    no other consumer, clip(0, 6) is applied (and differentiated) by the BN kernels and this step is an alias."""
+
+    def setup(self):
+        ex, a = self.ex, self.a
+        self.x = self.ins[0]
+        self.lo = float(a.get('a_min', a.get('amin')))
+        self.hi = float(a.get('a_max', a.get('amax')))
+        prod = self.node.inputs[0][0]
+        self.fused = (prod.op == 'BatchNorm' and len(ex.consumers.get((id(prod), 0), [])) == 1 and self.x.fmt == 'act' and
+                      _is_relu6(self.node))
+        if self.fused:
+            ex.vals[(id(self.node), 0)] = self.x
+            self.y = self.x
+        else:
+            self.y = self.new_out('act')
+            self.y.needs_grad = self.x.needs_grad
+
+    def forward(self):
+        if self.fused:
+            return
+        x = self.ex.as_act(self.x)
+        n, h, w, c = self.x.nhwc()
+        hip.call('sn_clip_f16', x, None, None, self.y.t, n * h * w, c, c, c, c, c, self.lo, self.hi, 0, hip.stream())
+
+    def backward(self):
+        if self.fused or self.y.grad is None or not self.x.needs_grad:
+            return
+        n, h, w, c = self.x.nhwc()
+        x = self.ex.as_act(self.x)
+        if self.x.fmt == 'act':
+            dx, acc = self.ex.grad_slot(self.x)
+            hip.call('sn_clip_f16', self.y.grad, x, dx if acc else None, dx, n * h * w, c, c, c, c, c, self.lo, self.hi, 1,
+                     hip.stream())
+        else:
+            tmp = self.ex.empty(self.y.t.shape, F16)
+            hip.call('sn_clip_f16', self.y.grad, x, None, tmp, n * h * w, c, c, c, c, c, self.lo, self.hi, 1, hip.stream())
+            self.ex.add_grad(self.x, tmp, 'act')
+        self.y.grad = None
+
+
 # ---------------------------------------------------------------------------------------------
 # Convolution / FullyConnected on the implicit-GEMM MFMA kernels
 # ---------------------------------------------------------------------------------------------
@@ -217,7 +270,7 @@ class _GemmLike(Step):
         self.y = self.new_out('f32' if self.out_f32 else 'act')
         wt = ex.for_training and (self.pname('weight') not in ex.fixed)
         self.y.needs_grad = ex.for_training and (self.x.needs_grad or wt)
-        if self.x.needs_grad and ex.for_training:
+        if self.x.needs_grad and ex.for_training and not getattr(self, 'depthwise', False):
             self.w.need_wT = True
         self.tmp_nhwc32 = None
         if self.out_f32 and self.Ho * self.Wo > 1:
@@ -280,30 +333,27 @@ class ConvolutionStep(_GemmLike):
         self.s = _tup(a.get('stride', (1, 1)))
         self.p = _tup(a.get('pad', (0, 0)))
         self.d = _tup(a.get('dilate', (1, 1)))
-        if int(a.get('num_group', 1)) != 1:
-            raise NotImplementedError('grouped / depthwise convolution (%s): next row (MobileNetV2)' % self.node.name)
         assert self.s[0] == self.s[1] and self.p[0] == self.p[1] and self.d[0] == self.d[1], 'square geometry only'
         self.N, self.C, self.H, self.W = self.x.shape
         _, self.O, self.Ho, self.Wo = self.out_shape()
+        g = int(a.get('num_group', 1))
+        self.depthwise = g > 1
+        if self.depthwise and not (g == self.C == self.O):
+            raise NotImplementedError('grouped convolution with num_group=%d, %d -> %d channels (%s): only depthwise '
+                                      '(num_group == channels, MobileNetV2) is built' % (g, self.C, self.O, self.node.name))
         self.wkind, self.fc_in = 'conv', None
         self.is_stem = self.C <= 4
         if self.is_stem:
+            # the image convolution runs on a packed (N, Hp, Wp, 4) fp16 input; its weight lives in the matching
+            # packed layout [O][KH][KWP*4] (zero padded), so forward, weight gradient and SGD all see one tensor
             ex = self.ex
             kh, kw = self.k
             self.KWP = (kw + 1) // 2 * 2
             self.Hp = (self.Ho - 1) * self.s[0] + kh
             self.Wp = ((self.Wo - 1) * self.s[1] + self.KWP + 1) // 2 * 2
             self.xp = ex.empty((self.N, self.Hp, self.Wp, 4), F16)
-            self.w_stem = ex.zeros((self.O, kh, self.KWP * 4), F16)
-
-    def params_changed(self, only_trainable=False):
-        if self.is_stem and not (only_trainable and not self.w.trainable):
-            o, t, i = self.w.int_shape
-            kh, kw = self.k
-            w = self.w.master.view(o, kh, kw, i)
-            buf = torch.zeros((o, kh, self.KWP, 4), dtype=F16, device=self.ex.device)
-            buf[:, :, :kw, :i] = w.half()
-            self.w_stem.copy_(buf.view(o, kh, self.KWP * 4))
+            self.wkind = 'stem'
+            self.fc_in = (kh, kw, self.KWP)
 
     def x_tensor(self):
         return None if self.is_stem else self.ex.as_act(self.x)
@@ -317,19 +367,36 @@ class ConvolutionStep(_GemmLike):
             src, scale, shift = (self.x.stem if self.x.stem is not None else (self.x, None, None))
             hip.call('sn_pack_stem_input', src.t, self.xp, self.N, self.C, self.H, self.W, self.Hp, self.Wp, self.p[0], self.p[1],
                      scale, shift, hip.stream())
-            hip.call('sn_conv_stem_fwd', self.xp, self.w_stem, bias, dst, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O,
+            hip.call('sn_conv_stem_fwd', self.xp, self.w.w16, bias, dst, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O,
                      self.O, self.k[0], self.KWP, self.s[0], 0, 1 if self.out_f32 else 0, hip.stream())
+            return
+        if self.depthwise:
+            if bias is not None or self.out_f32:
+                raise NotImplementedError('depthwise convolution with bias / fp32 output (%s)' % self.node.name)
+            hip.call('sn_dwconv_fwd', x, self.w.w16, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.k[0], self.k[1],
+                     self.s[0], self.p[0], self.d[0], hip.stream())
             return
         hip.call('sn_conv_fwd', x, self.w.w16, bias, None, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0,
                  self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0, 1 if self.out_f32 else 0, hip.stream())
 
     def launch_dgrad(self, dy, Op, acc, dx):
+        if self.depthwise:
+            hip.call('sn_dwconv_dgrad', dy, self.w.w16, acc, dx, self.N, self.H, self.W, self.C, Op, self.C, self.C, self.k[0],
+                     self.k[1], self.s[0], self.p[0], self.d[0], hip.stream())
+            return
         hip.call('sn_conv_dgrad', dy, self.w.wT16, acc, dx, self.N, self.H, self.W, self.C, self.C, Op, Op, self.C,
                  self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0, hip.stream())
 
     def launch_wgrad(self, dy, Op, x):
         if self.is_stem:
-            raise NotImplementedError('weight gradient of the stem convolution (frozen in every SNIPER config)')
+            # the packed input self.xp still holds this step's image batch (written by launch_fwd)
+            hip.call('sn_conv_stem_wgrad', dy, self.xp, self.w.grad, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O, Op,
+                     self.k[0], self.KWP, self.s[0], hip.stream())
+            return
+        if self.depthwise:
+            hip.call('sn_dwconv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, Op, self.C, self.k[0], self.k[1],
+                     self.s[0], self.p[0], self.d[0], hip.stream())
+            return
         hip.call('sn_conv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, self.O, Op, self.k[0], self.k[1],
                  self.s[0], self.p[0], self.d[0], hip.stream())
 

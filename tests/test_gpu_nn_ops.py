@@ -457,3 +457,99 @@ def test_deformable_sampling_vs_oracle(N, C, H, W, DG):
         tol = 1e-3 if f32 else 1e-2
         assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wdata, tol, tol * np.abs(wdata).max(), 'deform d_data')
         assert_close(d_off.cpu().numpy().transpose(0, 3, 1, 2), woff, 1e-3, 1e-3 * np.abs(woff).max(), 'deform d_offset')
+
+
+@pytest.mark.parametrize('N,C,H,W,s', [(2, 32, 12, 10, 1), (2, 96, 11, 13, 2), (1, 960, 8, 8, 1), (3, 1024 + 64, 5, 6, 2)])
+def test_depthwise_conv_vs_torch(N, C, H, W, s):
+    """MobileNetV2 depthwise 3x3 (mobilenetv2_e2e.py:57-66): forward, data gradient (+accumulate), weight gradient."""
+    hip = _hip()
+    rs = np.random.RandomState(C + s)
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rs.standard_normal((C, 1, 3, 3)) / 3).astype(np.float32)
+    xt, wt = torch.from_numpy(f16r(x)).requires_grad_(True), torch.from_numpy(f16r(w)).requires_grad_(True)
+    y = Fnn.conv2d(xt, wt, None, s, 1, 1, groups=C)
+    dy = rs.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(torch.from_numpy(f16r(dy)))
+    Ho, Wo = y.shape[2], y.shape[3]
+    xd, wd = to_nhwc_f16(x), torch.from_numpy(w.reshape(C, 9)).to(dev()).half().contiguous()
+    yd = torch.empty((N, Ho, Wo, C), dtype=torch.float16, device=dev())
+    hip.call('sn_dwconv_fwd', xd, wd, yd, N, H, W, C, C, C, 3, 3, s, 1, 1, hip.stream())
+    assert_close(from_nhwc(yd), y.detach().numpy(), 1e-2, 1e-2 * np.abs(y.detach().numpy()).max(), 'dw fwd')
+    dyd = to_nhwc_f16(dy)
+    dx = torch.full((N, H, W, C), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_dwconv_dgrad', dyd, wd, None, dx, N, H, W, C, C, C, C, 3, 3, s, 1, 1, hip.stream())
+    want_dx = xt.grad.numpy()
+    assert_close(from_nhwc(dx), want_dx, 1e-2, 1e-2 * np.abs(want_dx).max(), 'dw dgrad')
+    hip.call('sn_dwconv_dgrad', dyd, wd, dx, dx, N, H, W, C, C, C, C, 3, 3, s, 1, 1, hip.stream())
+    assert_close(from_nhwc(dx), 2 * want_dx, 2e-2, 2e-2 * np.abs(want_dx).max(), 'dw dgrad accumulate')
+    dw = torch.zeros((C, 9), dtype=torch.float32, device=dev())
+    hip.call('sn_dwconv_wgrad', dyd, xd, dw, N, H, W, C, C, C, 3, 3, s, 1, 1, hip.stream())
+    want_dw = wt.grad.numpy().reshape(C, 9)
+    assert_close(dw.cpu().numpy(), want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'dw wgrad')
+
+
+def test_clip_and_bn_relu6():
+    hip = _hip()
+    rs = np.random.RandomState(21)
+    N, C, H, W = 2, 24, 6, 5
+    M = N * H * W
+    x = (rs.standard_normal((N, C, H, W)) * 4 + 2).astype(np.float32)
+    dy = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    xd, dyd = to_nhwc_f16(x), to_nhwc_f16(dy)
+    y = torch.empty_like(xd)
+    hip.call('sn_clip_f16', xd, None, None, y, M, C, C, C, C, C, 0.0, 6.0, 0, hip.stream())
+    assert_close(from_nhwc(y), np.clip(f16r(x), 0, 6), 1e-3, 1e-3, 'clip fwd')
+    dx = torch.empty_like(xd)
+    hip.call('sn_clip_f16', dyd, xd, None, dx, M, C, C, C, C, C, 0.0, 6.0, 1, hip.stream())
+    xr = f16r(x)
+    assert_close(from_nhwc(dx), np.where((xr >= 0) & (xr <= 6), f16r(dy), 0), 1e-3, 1e-3, 'clip bwd')
+    # BatchNorm + relu6 fused (activation code 2) against torch: y = clip(BN(x), 0, 6)
+    gamma, beta = rs.uniform(1.0, 3.0, C).astype(np.float32), rs.uniform(0, 3, C).astype(np.float32)
+    f = lambda n: torch.zeros(n, dtype=torch.float32, device=dev())
+    ws = torch.empty(hip.query('sn_bn_workspace_bytes', M, C), dtype=torch.uint8, device=dev())
+    scale, shift, mean, invstd, rm, rv = f(C), f(C), f(C), f(C), f(C), f(C)
+    g_d, b_d = torch.from_numpy(gamma).to(dev()), torch.from_numpy(beta).to(dev())
+    hip.call('sn_bn_stats', xd, M, C, C, ws, hip.stream())
+    hip.call('sn_bn_finalize', ws, M, C, 1e-5, 0.9, g_d, b_d, rm, rv, scale, shift, mean, invstd, hip.stream())
+    hip.call('sn_bn_apply', xd, y, M, C, C, C, scale, shift, 2, hip.stream())
+    xt = torch.from_numpy(xr).requires_grad_(True)
+    gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    yt = torch.clamp(Fnn.batch_norm(xt, None, None, gt, bt, True, 0.0, 1e-5), 0, 6)
+    yt.backward(torch.from_numpy(f16r(dy)))
+    assert_close(from_nhwc(y), yt.detach().numpy(), 1e-2, 2e-2, 'bn relu6 fwd')
+    dg, db = f(C), f(C)
+    hip.call('sn_bn_backward', dyd, xd, None, dx, M, C, C, C, C, C, scale, shift, mean, invstd, 2, ws, dg, db, hip.stream())
+    assert_close(db.cpu().numpy(), bt.grad.numpy(), 3e-2, 3e-2 * np.abs(bt.grad.numpy()).max(), 'bn relu6 dbeta')
+    assert_close(dg.cpu().numpy(), gt.grad.numpy(), 3e-2, 3e-2 * np.abs(gt.grad.numpy()).max(), 'bn relu6 dgamma')
+    assert_close(from_nhwc(dx), xt.grad.numpy(), 3e-2, 3e-2 * np.abs(xt.grad.numpy()).max(), 'bn relu6 dx')
+
+
+def test_stem_conv_3x3_wgrad_packed():
+    """MobileNetV2's first convolution (3 -> 32, 3x3/2, pad 1; mobilenetv2_e2e.py:196-204) is trainable: forward and
+    weight gradient on the packed NHWC4 input, weight in the packed [O][KH][KWP*4] layout."""
+    hip = _hip()
+    rs = np.random.RandomState(31)
+    N, H, W, O, K, s, pad = 2, 32, 40, 32, 3, 2, 1
+    x = (rs.standard_normal((N, 3, H, W)) * 2).astype(np.float32)
+    w = (rs.standard_normal((O, 3, K, K)) / 5).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - K) // s + 1, (W + 2 * pad - K) // s + 1
+    KWP = (K + 1) // 2 * 2
+    Hp, Wp = (Ho - 1) * s + K, ((Wo - 1) * s + KWP + 1) // 2 * 2
+    xp = torch.empty((N, Hp, Wp, 4), dtype=torch.float16, device=dev())
+    hip.call('sn_pack_stem_input', torch.from_numpy(x).to(dev()), xp, N, 3, H, W, Hp, Wp, pad, pad, None, None, hip.stream())
+    wk = np.zeros((O, K, KWP, 4), np.float32)
+    wk[:, :, :K, :3] = w.transpose(0, 2, 3, 1)
+    wd = torch.from_numpy(wk.reshape(O, K, KWP * 4)).to(dev()).half().contiguous()
+    y = torch.empty((N, Ho, Wo, O), dtype=torch.float16, device=dev())
+    hip.call('sn_conv_stem_fwd', xp, wd, None, y, N, Hp, Wp, Ho, Wo, O, O, K, KWP, s, 0, 0, hip.stream())
+    xt, wt = torch.from_numpy(f16r(x)), torch.from_numpy(f16r(w)).requires_grad_(True)
+    yt = Fnn.conv2d(xt, wt, None, s, pad)
+    assert_close(from_nhwc(y), yt.detach().numpy(), 1e-2, 1e-2 * float(yt.abs().max()), 'stem 3x3 fwd')
+    dy = rs.standard_normal(tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.from_numpy(f16r(dy)))
+    dw = torch.zeros((O, K, KWP * 4), dtype=torch.float32, device=dev())
+    hip.call('sn_conv_stem_wgrad', to_nhwc_f16(dy), xp, dw, N, Hp, Wp, Ho, Wo, O, O, K, KWP, s, hip.stream())
+    got = dw.cpu().numpy().reshape(O, K, KWP, 4)
+    want = wt.grad.numpy().transpose(0, 2, 3, 1)
+    assert_close(got[:, :, :K, :3], want, 1e-2, 1e-2 * np.abs(want).max(), 'stem wgrad')
+    assert float(np.abs(got[:, :, :, 3]).max()) == 0.0            # channel padding carries no gradient

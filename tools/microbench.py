@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--batch', type=int, default=20)
+    ap.add_argument('--only', default='', help='run only the conv shapes whose name contains this, then exit')
     a = ap.parse_args()
     d = torch.device('cuda', 0)
     B = a.batch
@@ -47,7 +48,12 @@ def main():
         ('stage4 1x1 2048->512 @32', 32, 32, 2048, 512, 1, 1, 0, 1),
         ('rpn 3x3 3072->512 @32', 32, 32, 3072, 512, 3, 1, 1, 1),
     ]
+    if a.only:
+        convs = [c for c in convs if a.only in c[0]] + [
+            ('probe 1x1 4096->512 M=16384', 32, 32, 4096, 512, 1, 1, 0, 1)]   # B=16: exactly 512 tiles
     for name, H, W, C, O, K, s, p, dl in convs:
+        if name.startswith('probe'):
+            B = 16
         x, w = h(B, H, W, C), h(O, K * K, C)
         Ho, Wo = (H + 2 * p - dl * (K - 1) - 1) // s + 1, (W + 2 * p - dl * (K - 1) - 1) // s + 1
         y = torch.empty((B, Ho, Wo, O), dtype=torch.float16, device=d)
@@ -61,6 +67,8 @@ def main():
             dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=d)
             ms = timeit(lambda: hip.call('sn_conv_wgrad', y, x, dw, B, H, W, C, C, O, O, K, K, s, p, dl, hip.stream()), it)
             print('conv_wgrad %-27s %8.3f ms %8.1f TFLOP/s' % (name, ms, fl / ms / 1e9), flush=True)
+    if a.only:
+        return
     # fc_new_1: 6000 x 12544 -> 1024
     M, K_, O = B * 300, 12544, 1024
     x, w, y = h(M, K_), h(O, K_), torch.empty((M, O), dtype=torch.float16, device=d)
