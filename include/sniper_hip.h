@@ -129,9 +129,13 @@ int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp,
 int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
                   int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil,
                   int out_f32, sn_stream_t stream);
-/* Weight gradient, accumulated (+=) into dw fp32 [Cout][KH*KW][Cin]. */
+/* Weight gradient, accumulated (+=) into dw fp32 [Cout][KH*KW][Cin].  Layers whose weight tensor is small relative to
+ * the pixel count are split over K; with ws = sn_conv_wgrad_workspace_bytes(...) bytes of scratch the partials are
+ * reduced without atomics (deterministic); ws may be NULL (atomic accumulation). */
+size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH, int KW,
+                                     int stride, int pad, int dil);
 int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride, int Cout,
-                  int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, sn_stream_t stream);
+                  int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws, size_t ws_bytes, sn_stream_t stream);
 /* bias gradient: db[c] += sum_rows dy[r][c] */
 int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, sn_stream_t stream);
 

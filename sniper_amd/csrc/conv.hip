@@ -495,6 +495,8 @@ struct WgradParams {
   int N, H, W, Ho, Wo, Cin, Cout, dy_ps, x_ps;
   int KH, KW, stride, pad, dil;
   int units_per_split;  // 32-pixel K chunks handled per blockIdx.z split
+  float *slab;          // split-K partials [split][Cout][taps][Cin] (plain stores, reduced by wgrad_reduce_kernel) or null
+  size_t slab_stride;   // elements per split
 };
 
 __device__ __forceinline__ half8 gather8(const half_t *base, int stride_elems, unsigned valid_mask) {
@@ -707,18 +709,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   };
 
   half8 ra0[4], rb0[4], ra1[4], rb1[4];
-  bool h0 = gload(ra0, rb0);               // tile 0
-  if (!h0) return;                         // block-uniform
-  bool h1 = gload(ra1, rb1);               // tile 1
-  lstore(0, ra0, rb0);
-  h0 = gload(ra0, rb0);                    // tile 2
+  bool h0 = gload(ra0, rb0);               // tile 0 (all flags are block-uniform)
+  bool h1 = h0 ? gload(ra1, rb1) : false;  // tile 1
+  if (h0) lstore(0, ra0, rb0);
+  const bool any_tile = h0;
+  h0 = h0 ? gload(ra0, rb0) : false;       // tile 2
   __syncthreads();
-  while (true) {
+  while (any_tile) {
     // LDS[0] = tile t; set 1 = tile t+1 (h1), set 0 = tile t+2 (h0)
     if (h1) lstore(1, ra1, rb1);
     const bool h1n = h1 ? gload(ra1, rb1) : false;   // tile t+3
@@ -734,54 +736,129 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
     h1 = h1n;
     h0 = h0n;
   }
-  // D: row = co (A operand), col = ci (B operand)
+  // The product was formed transposed (X as the MFMA A operand): lane (fr, fq) holds, for each (i, j), output channel
+  // co = ..+fr and 4 consecutive input channels ci = ..+fq*4 .. +3 -> one 16-byte store per (i, j).
+  // With K-splits the partial tile goes to this split's slab with plain stores (a split without any valid unit
+  // stores zeros) and wgrad_reduce_kernel sums the slabs into dw: no atomics, fixed summation order.
+  float *dst = p.slab ? p.slab + (size_t)split * p.slab_stride : p.dw;
+  const bool vec4 = (p.Cin % 4) == 0;
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const int co = co0 + wm * 64 + i * 16 + fr;
+    if (co >= p.Cout) continue;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int co = co0 + wm * 64 + i * 16 + fq * 4 + rr;
-      if (co >= p.Cout) continue;
+    for (int j = 0; j < NI; ++j) {
+      const int ci = ci0 + wn * 64 + j * 16 + fq * 4;
+      if (ci >= p.Cin) continue;
+      float *q = dst + ((size_t)co * taps + tap) * p.Cin + ci;
+      if (p.slab) {
+        if (vec4) *reinterpret_cast<float4 *>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        else
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int ci = ci0 + wn * 64 + j * 16 + fr;
-        if (ci < p.Cin) atomicAdd(p.dw + ((size_t)co * taps + tap) * p.Cin + ci, acc[i][j][rr]);
+          for (int r = 0; r < 4; ++r)
+            if (ci + r < p.Cin) q[r] = acc[i][j][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ci + r < p.Cin) atomicAdd(q + r, acc[i][j][r]);
       }
     }
+  }
+}
+
+// dw[e] += sum over splits of slab[s][e]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int splits, size_t n, float *__restrict__ dw) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4 *>(dw)[i];
+    for (int sidx = 0; sidx < splits; ++sidx) {
+      const float4 v = reinterpret_cast<const float4 *>(slab + (size_t)sidx * n)[i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4 *>(dw)[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t e = (n4 << 2) + threadIdx.x;
+    float a = dw[e];
+    for (int sidx = 0; sidx < splits; ++sidx) a += slab[(size_t)sidx * n + e];
+    dw[e] = a;
+  }
+}
+
+// K-split plan shared by the workspace query and the launch
+struct WgradPlan {
+  int gx, gy, taps, nunits, splits, units_per_split, Ho, Wo, flat;
+  bool vec_ok;
+};
+static WgradPlan wgrad_plan(const void *dy, const void *x, int N, int H, int W, int Cin, int x_ps, int Cout, int dy_ps, int KH,
+                            int KW, int stride, int pad, int dil) {
+  WgradPlan q;
+  q.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  q.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  q.flat = KH == 1 && KW == 1 && stride == 1 && pad == 0;   // one long row of pixels
+  q.taps = KH * KW;
+  q.gx = sn_div_up(Cout, 128);
+  q.gy = sn_div_up(Cin, 128);
+  q.nunits = q.flat ? sn_div_up(N * H * W, 32) : N * q.Ho * sn_div_up(q.Wo, 32);
+  // 16-byte channel runs: pixel strides multiples of 8 that cover the last (possibly partial) chunk, aligned bases
+  q.vec_ok = dy_ps % 8 == 0 && x_ps % 8 == 0 && dy_ps >= sn_div_up(Cout, 8) * 8 && x_ps >= sn_div_up(Cin, 8) * 8 &&
+             ((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0;
+  // K-splits: 2 workgroups per CU (LDS 64 KB)
+  int splits = sn_div_up(q.vec_ok ? 512 : 1024, q.gx * q.gy * q.taps);
+  if (splits > q.nunits / 2) splits = q.nunits / 2;   // at least one 64-pixel K-step per split
+  if (splits < 1) splits = 1;
+  q.units_per_split = sn_div_up(q.nunits, splits);
+  q.splits = sn_div_up(q.nunits, q.units_per_split);
+  return q;
+}
+
+// Scratch for the split-K partials of sn_conv_wgrad (0 when the layer needs no split).  Pointer alignment is assumed
+// (the query has no pointers); an unaligned call falls back to the atomic kernel and ignores the workspace.
+SN_EXPORT size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH,
+                                               int KW, int stride, int pad, int dil) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const WgradPlan q = wgrad_plan(nullptr, nullptr, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil);
+  if (!q.vec_ok || q.splits <= 1) return 0;
+  return sn_align(sizeof(float) * (size_t)q.splits * Cout * q.taps * Cin);
 }
 
 SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride,
-                            int Cout, int dy_pix_stride, int KH, int KW, int stride, int pad, int dil,
-                            sn_stream_t stream) {
+                            int Cout, int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws,
+                            size_t ws_bytes, sn_stream_t stream) {
   SN_REQUIRE(dy && x && dw, "sn_conv_wgrad: null pointer");
   WgradParams p;
   p.dy = (const half_t *)dy; p.x = (const half_t *)x; p.dw = dw;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dy_ps = dy_pix_stride; p.x_ps = x_pix_stride;
-  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
-  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
-  SN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && p.Ho > 0 && p.Wo > 0, "sn_conv_wgrad: bad dims");
+  SN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sn_conv_wgrad: bad dims");
+  const WgradPlan q = wgrad_plan(dy, x, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil);
+  p.Ho = q.Ho; p.Wo = q.Wo;
+  SN_REQUIRE(p.Ho > 0 && p.Wo > 0, "sn_conv_wgrad: bad dims");
   SN_REQUIRE((long)N * H * W * x_pix_stride < (1l << 31) && (long)N * p.Ho * p.Wo * dy_pix_stride < (1l << 31),
              "sn_conv_wgrad: tensor too large for 32-bit offsets");
-  if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {  // flat: one long row of pixels
-    p.W = p.Wo = N * H * W; p.H = p.Ho = 1; p.N = 1;
+  if (q.flat) { p.W = p.Wo = N * H * W; p.H = p.Ho = 1; p.N = 1; }
+  p.units_per_split = q.units_per_split;
+  const size_t n = (size_t)Cout * q.taps * Cin;
+  const size_t need = sizeof(float) * (size_t)q.splits * n;
+  p.slab = nullptr;
+  p.slab_stride = n;
+  hipStream_t s = sn_stream(stream);
+  const dim3 grid(q.gx, q.gy, q.taps * q.splits);
+  if (q.vec_ok) {
+    if (q.splits > 1 && ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) p.slab = (float *)ws;
+    hipLaunchKernelGGL(conv_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    SN_CHECK_LAUNCH();
+    if (p.slab) {
+      long blocks = (long)((n / 4 + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)p.slab, q.splits, n, dw);
+      SN_CHECK_LAUNCH();
+    }
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    SN_CHECK_LAUNCH();
   }
-  const int taps = KH * KW;
-  const int gx = sn_div_up(Cout, 128), gy = sn_div_up(Cin, 128);
-  const int nunits = p.N * p.Ho * sn_div_up(p.Wo, 32);
-  // 16-byte channel runs: pixel strides multiples of 8 that cover the last (possibly partial) chunk, aligned bases
-  const bool vec_ok = dy_pix_stride % 8 == 0 && x_pix_stride % 8 == 0 && dy_pix_stride >= sn_div_up(Cout, 8) * 8 &&
-                      x_pix_stride >= sn_div_up(Cin, 8) * 8 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0;
-  // K-splits: 2 workgroups per CU (LDS 64 KB); every split adds a 128x128 atomic epilogue
-  int splits = sn_div_up(vec_ok ? 512 : 1024, gx * gy * taps);
-  if (splits > nunits) splits = nunits;
-  if (splits < 1) splits = 1;
-  p.units_per_split = sn_div_up(nunits, splits);
-  splits = sn_div_up(nunits, p.units_per_split);
-  if (vec_ok)
-    hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, taps * splits), dim3(256), 0, sn_stream(stream), p);
-  SN_CHECK_LAUNCH();
   return SN_OK;
 }
 
@@ -797,6 +874,7 @@ SN_EXPORT int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int 
   p.dy = (const half_t *)dy; p.x = (const half_t *)xp; p.dw = dw;
   p.N = N; p.H = Hp; p.W = Wp; p.Ho = Ho; p.Wo = Wo; p.Cin = 4 * KWP; p.Cout = Cout; p.dy_ps = dy_pix_stride; p.x_ps = 4;
   p.KH = KH; p.KW = 1; p.stride = stride; p.pad = 0; p.dil = 1;
+  p.slab = nullptr; p.slab_stride = 0;
   const int gx = sn_div_up(Cout, 128), gy = sn_div_up(p.Cin, 128);
   const int nunits = N * Ho * sn_div_up(Wo, 32);
   int splits = sn_div_up(1024, gx * gy * KH);

@@ -257,6 +257,13 @@ class ClipStep(Step):
 # ---------------------------------------------------------------------------------------------
 # Convolution / FullyConnected on the implicit-GEMM MFMA kernels
 # ---------------------------------------------------------------------------------------------
+def _wgrad(ex, dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil):
+    """sn_conv_wgrad with the executor's shared split-K scratch (deterministic, atomic-free reduction)."""
+    need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil)
+    ws = ex.ws.get(need) if need else None
+    hip.call('sn_conv_wgrad', dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil, ws, need, hip.stream())
+
+
 class _GemmLike(Step):
     """Shared by Convolution and FullyConnected.  Sub-classes fill geometry in setup_geom()."""
 
@@ -397,8 +404,8 @@ class ConvolutionStep(_GemmLike):
             hip.call('sn_dwconv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, Op, self.C, self.k[0], self.k[1],
                      self.s[0], self.p[0], self.d[0], hip.stream())
             return
-        hip.call('sn_conv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, self.O, Op, self.k[0], self.k[1],
-                 self.s[0], self.p[0], self.d[0], hip.stream())
+        _wgrad(self.ex, dy, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, self.O, Op, self.k[0], self.k[1],
+               self.s[0], self.p[0], self.d[0])
 
 
 @register('FullyConnected')
@@ -430,7 +437,7 @@ class FullyConnectedStep(_GemmLike):
                  hip.stream())
 
     def launch_wgrad(self, dy, Op, x):
-        hip.call('sn_conv_wgrad', dy, x, self.w.grad, self.N, 1, 1, self.C, self.C, self.O, Op, 1, 1, 1, 0, 1, hip.stream())
+        _wgrad(self.ex, dy, x, self.w.grad, self.N, 1, 1, self.C, self.C, self.O, Op, 1, 1, 1, 0, 1)
 
 
 @register('DeformableConvolution')
@@ -480,7 +487,7 @@ class DeformableConvolutionStep(Step):
         Op = _pad8(self.O)
         assert Op == self.O
         if self.w.trainable:
-            hip.call('sn_conv_wgrad', dy, self.col, self.w.grad, M, 1, 1, K, K, self.O, Op, 1, 1, 1, 0, 1, hip.stream())
+            _wgrad(ex, dy, self.col, self.w.grad, M, 1, 1, K, K, self.O, Op, 1, 1, 1, 0, 1)
         if self.b is not None and self.b.trainable:
             hip.call('sn_bias_grad', dy, self.b.grad, M, self.O, Op, 0, hip.stream())
         if self.x.needs_grad or self.off.needs_grad:

@@ -147,10 +147,18 @@ def test_conv_dgrad_wgrad(case):
     assert_close(from_nhwc(dx2), 2 * want_dx, 2e-2, 2e-2 * np.abs(want_dx).max(), 'dgrad accumulate')
     # wgrad (+= into zeroed fp32)
     dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=dev())
-    hip.call('sn_conv_wgrad', d_dy, to_nhwc_f16(x), dw, N, H, W, C, C, O, Op, K, K, s, p, d, hip.stream())
+    need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, d)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev())
+    hip.call('sn_conv_wgrad', d_dy, to_nhwc_f16(x), dw, N, H, W, C, C, O, Op, K, K, s, p, d, ws, need, hip.stream())
     torch.cuda.synchronize()
     got_dw = dw.cpu().numpy().reshape(O, K, K, C).transpose(0, 3, 1, 2)
     assert_close(got_dw, want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'wgrad %s' % (case,))
+    # without scratch the K-splits accumulate with atomics: same result, and += semantics on a non-zero dw
+    dw2 = dw.clone()
+    hip.call('sn_conv_wgrad', d_dy, to_nhwc_f16(x), dw2, N, H, W, C, C, O, Op, K, K, s, p, d, None, 0, hip.stream())
+    torch.cuda.synchronize()
+    got2 = dw2.cpu().numpy().reshape(O, K, K, C).transpose(0, 3, 1, 2)
+    assert_close(got2, 2 * want_dw, 1e-2, 2e-2 * np.abs(want_dw).max(), 'wgrad atomic path %s' % (case,))
 
 
 def test_fc_as_conv_and_bias_grad():
@@ -175,7 +183,7 @@ def test_fc_as_conv_and_bias_grad():
     dy16 = torch.zeros((M, 104), dtype=torch.float16, device=dev())
     dy16[:, :O] = dyd.half()
     dw = torch.zeros((O, K), dtype=torch.float32, device=dev())
-    hip.call('sn_conv_wgrad', dy16, xd, dw, M, 1, 1, K, K, O, 104, 1, 1, 1, 0, 1, hip.stream())
+    hip.call('sn_conv_wgrad', dy16, xd, dw, M, 1, 1, K, K, O, 104, 1, 1, 1, 0, 1, None, 0, hip.stream())
     want_dw = f16r(dy).T @ f16r(x)
     assert_close(dw.cpu().numpy(), want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'fc wgrad')
 

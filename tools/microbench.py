@@ -65,7 +65,9 @@ def main():
             ms = timeit(lambda: hip.call('sn_conv_dgrad', y, wt, None, dx, B, H, W, C, C, O, O, C, K, K, s, p, dl, 0, hip.stream()), it)
             print('conv_dgrad %-27s %8.3f ms %8.1f TFLOP/s' % (name, ms, fl / ms / 1e9), flush=True)
             dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=d)
-            ms = timeit(lambda: hip.call('sn_conv_wgrad', y, x, dw, B, H, W, C, C, O, O, K, K, s, p, dl, hip.stream()), it)
+            need = hip.query('sn_conv_wgrad_workspace_bytes', B, H, W, C, C, O, O, K, K, s, p, dl)
+            wsb = torch.empty(max(need, 16), dtype=torch.uint8, device=d)
+            ms = timeit(lambda: hip.call('sn_conv_wgrad', y, x, dw, B, H, W, C, C, O, O, K, K, s, p, dl, wsb, need, hip.stream()), it)
             print('conv_wgrad %-27s %8.3f ms %8.1f TFLOP/s' % (name, ms, fl / ms / 1e9), flush=True)
     if a.only:
         return
