@@ -331,9 +331,16 @@ def _create(op, pos_inputs, kwargs):
     return Symbol([(node, i) for i in range(nout)])
 
 
+_POS_ATTRS = {'clip': ('a_min', 'a_max')}
+
+
 def _make_op(op):
     def fn(*args, **kwargs):
         pos = [a for a in args if isinstance(a, Symbol)]
+        # positional scalar attributes (mx.sym.clip(data, a_min, a_max), mobilenetv2_e2e.py:19)
+        scalars = [a for a in args if not isinstance(a, Symbol)]
+        for k, v in zip(_POS_ATTRS.get(op, ()), scalars):
+            kwargs.setdefault(k, v)
         return _create(op, pos, kwargs)
 
     fn.__name__ = op

@@ -55,3 +55,29 @@ def test_test_graph_lowers():
     ex = Executor(sym, shapes, False, [], device=torch.device('cpu'))
     assert any(type(s).__name__ == 'MultiProposalStep' for s in ex.steps)
     assert ex.n_trainable == 0
+
+
+def test_mobilenetv2_lowering_plan():
+    """BASELINE C1 graph: depthwise convolutions, BN+relu6 fusion, the trainable packed stem, stride-32 heads."""
+    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
+    B = 2
+    cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
+    net = mn.mobilenetv2_e2e()
+    sym = net.get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, 15 * 16 * 16),
+                  bbox_target=(B, 60, 16, 16), bbox_weight=(B, 60, 16, 16), gt_boxes=(B, 100, 5), crowd_boxes=(B, 10, 5))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    convs = [s for s in ex.steps if type(s).__name__ == 'ConvolutionStep']
+    assert len(convs) == 57 and sum(1 for s in convs if s.depthwise) == 17 and sum(1 for s in convs if s.is_stem) == 1
+    bns = [s for s in ex.steps if type(s).__name__ == 'BatchNormStep']
+    assert len(bns) == 53 and sum(1 for s in bns if s.act == 2) == 36          # every BN but the 17 linear ones feeds a relu6
+    assert all(s.fused for s in ex.steps if type(s).__name__ == 'ClipStep')
+    # FIXED_PARAMS of the MobileNetV2 config freeze every gamma/beta and nothing else: all convolutions train
+    assert all(s.w.trainable for s in convs)
+    assert not any(p.trainable for n, p in ex.params.items() if n.endswith('_gamma') or n.endswith('_beta'))
+    stem = ex.params['first-3x3-conv-conv2d_weight']
+    assert stem.kind == 'stem' and stem.int_shape == (32, 3, 16)
+    a = np.random.RandomState(0).standard_normal(stem.ref_shape).astype(np.float32)
+    assert np.array_equal(stem.to_reference(stem.to_internal(a)), a)
+    dw = ex.params['seq-3-block1-depthwise-conv2d_weight']
+    assert dw.int_shape == (384, 9, 1) and dw.wT16 is None

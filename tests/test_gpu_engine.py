@@ -315,3 +315,99 @@ def test_hip_graph_replay_matches_eager(monkeypatch):
             assert_close(y.cpu().numpy(), x.cpu().numpy(), 2e-2, 2e-2 * float(x.abs().max()) + 1e-6, 'graph vs eager outputs')
     for k in pe:
         assert_close(pg[k].cpu().numpy(), pe[k].cpu().numpy(), 2e-2, 2e-2 * float(pe[k].abs().max()) + 1e-6, 'graph vs eager ' + k)
+
+
+def _grad_close(got, want, name):
+    """fp16 storage through a deep network vs the fp32 CPU evaluation: 5% of the tensor's scale for at least 90% of
+    the elements, 20% for all (ReLU / clip masks flip on pre-activations within fp16 rounding of the kink), 10% in L2."""
+    scale = np.abs(want).max() + 1e-6
+    err = np.abs(got.astype(np.float64) - want)
+    tol = 5e-2 * np.abs(want) + 5e-2 * scale
+    assert (err > tol).mean() <= 0.10, 'grad %s: %.1f%% of the elements outside 5%%' % (name, 100 * (err > tol).mean())
+    assert_close(got, want, 2e-1, 2e-1 * scale, 'grad %s (outliers)' % name)
+    assert np.linalg.norm(err) <= 0.1 * np.linalg.norm(want) + 1e-6, 'grad %s: relative L2 error %.3f' % (
+        name, np.linalg.norm(err) / np.linalg.norm(want))
+
+
+def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
+    """BASELINE config C1: MobileNetV2 Faster-RCNN, 1 scale, 2 x 512 x 512 synthetic chips.  The HIP engine's
+    training step against the whole graph evaluated with reference-semantics CPU ops (oracle/graph_cpu.py, fp32):
+    RPN outputs, RoI-head outputs and every parameter gradient.  Tolerance: north_star's 1e-2 relative on conv / loss
+    tensors (fp16 storage), looser where a gradient is a sum over thousands of fp16 activations (see _grad_close)."""
+    import sniper_amd.mx as mx
+    from oracle import graph_cpu
+    from sniper_amd import config as cfgmod
+    from sniper_amd.engine.executor import Executor
+    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
+    from sniper_amd.train import fixed_param_names
+    B, A, F = 2, 15, 16
+    cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
+    net = mn.mobilenetv2_e2e()
+    sym = net.get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                  bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5), crowd_boxes=(B, 10, 5))
+    import os
+    os.environ['SNIPER_HIP_GRAPHS'] = '0'
+    try:
+        ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym))
+    finally:
+        os.environ.pop('SNIPER_HIP_GRAPHS', None)
+    rs = np.random.RandomState(11)
+    args, _, auxs = sym.infer_shape(**shapes)
+    P, AUX = {}, {}
+    for name, shp in zip(sym.list_arguments(), args):
+        if name in shapes:
+            continue
+        if name.endswith('_gamma'):
+            P[name] = rs.uniform(0.8, 1.2, shp).astype(np.float32)
+        elif name.endswith('_beta'):
+            P[name] = rs.uniform(0.0, 0.5, shp).astype(np.float32)
+        elif name.endswith('_bias'):
+            P[name] = np.zeros(shp, np.float32)
+        elif name.startswith('offset'):
+            P[name] = (rs.standard_normal(shp) * 1e-3).astype(np.float32)     # non-zero: exercises the trans branch
+        elif any(name.startswith(h) for h in ('rpn_', 'conv_new_1', 'fc_new', 'cls_score', 'bbox_pred')):
+            P[name] = (rs.standard_normal(shp) * 0.01).astype(np.float32)
+        else:
+            P[name] = (rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))).astype(np.float32)
+    for name, shp in zip(sym.list_auxiliary_states(), auxs):
+        AUX[name] = np.ones(shp, np.float32) if name.endswith('_var') else np.zeros(shp, np.float32)
+    # weights as the device multiplies them (fp16-rounded matrices), identical on both sides
+    P = {k: (f16r(v) if v.ndim > 1 else v) for k, v in P.items()}
+    ex.set_params(P, AUX)
+    gt = -np.ones((B, 100, 5), np.float32)
+    for b in range(B):
+        n = 6
+        c = rs.uniform(80, 430, (n, 2))
+        wh = rs.uniform(30, 200, (n, 2))
+        gt[b, :n, :4] = np.clip(np.concatenate((c - wh / 2, c + wh / 2), 1), 0, 511)
+        gt[b, :n, 4] = rs.randint(1, 81, n)
+    inp = dict(data=(rs.standard_normal((B, 3, 512, 512)) * 50).astype(np.float32),
+               valid_ranges=np.array([[0, 512]] * B, np.float32), im_info=np.array([[512, 512, 1.0]] * B, np.float32),
+               label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.9, 0.07, 0.03]).astype(np.float32),
+               bbox_target=(rs.standard_normal((B, 4 * A, F, F)) * 0.3).astype(np.float32),
+               bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.05).astype(np.float32), gt_boxes=gt,
+               crowd_boxes=-np.ones((B, 10, 5), np.float32))
+    outs = ex.forward(inp, is_train=True)
+    ex.backward()
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy() for o in outs]
+    assert all(np.isfinite(g).all() for g in got)
+    # the RoI set the device selected, handed to the CPU evaluation (proposal parity itself: test_gpu_nn_ops)
+    mpt = [n for n in sym._topo() if n.op == 'MultiProposalTarget'][0]
+    ov = {(mpt.name, i): ex.vals[(id(mpt), i)].t.cpu().numpy().reshape(ex.vals[(id(mpt), i)].shape) for i in range(4)}
+    assert (ov[(mpt.name, 1)] > 0).sum() >= 4, 'the synthetic GT must produce some foreground RoIs'
+    want, wgrads = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False)
+    assert_close(got[0], want[0], 1e-2, 1e-2, 'rpn_cls_prob')
+    assert_close(got[1], want[1], 1e-2, 1e-2 * np.abs(want[1]).max() + 1e-4, 'rpn_bbox_loss')
+    assert_close(got[2], want[2], 1e-2, 1e-2, 'cls_prob')
+    assert_close(got[3], want[3], 1e-2, 1e-2 * np.abs(want[3]).max() + 1e-4, 'bbox_loss')
+    assert np.array_equal(got[4], want[4])
+    checked = 0
+    for name, p in ex.params.items():
+        if not p.trainable:
+            assert name.endswith('_gamma') or name.endswith('_beta'), name
+            continue
+        _grad_close(p.to_reference(p.grad.detach().cpu().numpy()), wgrads[name], name)
+        checked += 1
+    assert checked == 53 + 4 + 4 + 4 + 1 + 5       # trunk convs, head convs (+bias), FC weights/biases, offset

@@ -98,3 +98,72 @@ def test_same_graph_as_reference_symbol_file():
         nb = [norm(n) for n in sb._topo() if n.op]
         assert len(na) == len(nb)
         assert sorted(na) == sorted(nb)
+
+
+def _mnv2_shapes(B, train=True, A=15, F=16):
+    if train:
+        return dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                    bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5), crowd_boxes=(B, 10, 5))
+    return dict(data=(B, 3, 512, 512), im_info=(B, 3), im_ids=(B,), chip_ids=(B,))
+
+
+def test_mobilenetv2_graph_shapes():
+    """BASELINE C1 network: 53 trunk convolutions (17 depthwise) + 4 head convolutions, stride-32 map, 15 anchors."""
+    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
+    B = 2
+    cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
+    net = mn.mobilenetv2_e2e()
+    sym = net.get_symbol_rcnn(cfg)
+    assert sym.list_outputs() == ['rpn_cls_prob_output', 'rpn_bbox_loss_output', 'cls_prob_reshape_output',
+                                  'bbox_loss_reshape_output', 'blockgrad0_output']
+    net.infer_shape(_mnv2_shapes(B))
+    assert net.out_shape_dict['rpn_cls_prob_output'] == (B, 2, 15 * 16, 16)
+    assert net.out_shape_dict['cls_prob_reshape_output'] == (B, 300, 81)
+    assert net.arg_shape_dict['first-3x3-conv-conv2d_weight'] == (32, 3, 3, 3)
+    assert net.arg_shape_dict['seq-1-block0-depthwise-conv2d_weight'] == (96, 1, 3, 3)
+    assert net.arg_shape_dict['last-1x1-conv-conv2d_weight'] == (1280, 320, 1, 1)
+    assert net.arg_shape_dict['rpn_conv_3x3_weight'] == (256, 1280, 3, 3)
+    assert net.arg_shape_dict['fc_new_1_weight'] == (512, 256 * 49)
+    ops = [n for n in sym._topo() if n.op == 'Convolution']
+    assert len(ops) == 53 + 4 and sum(1 for n in ops if int(n.attrs.get('num_group', 1)) > 1) == 17
+    t = net.get_symbol_rcnn(cfg, is_train=False)
+    assert t.list_outputs() == ['rois_output', 'cls_prob_reshape_output', 'bbox_pred_reshape_output', 'im_ids', 'im_info',
+                                'chip_ids']
+
+
+@pytest.mark.ref
+def test_mobilenetv2_same_graph_as_reference_symbol_file():
+    import importlib
+    import sniper_amd.mx as mx
+    from sniper_amd.mx import symbol as _symmod
+    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
+    mx.alias_as('mxnet')
+    for p in ('/root/reference', '/root/reference/lib', '/root/reference/symbols/faster'):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    sys.dont_write_bytecode = True
+    refmod = importlib.import_module('mobilenetv2_e2e')
+    B = 2
+    for train in (True, False):
+        cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
+        a, b = refmod.mobilenetv2_e2e(test_nbatch=B), mn.mobilenetv2_e2e(test_nbatch=B)
+        _symmod._counter().clear()
+        sa = a.get_symbol_rcnn(cfg, is_train=train)
+        _symmod._counter().clear()
+        sb = b.get_symbol_rcnn(cfg, is_train=train)
+        assert sa.list_outputs() == sb.list_outputs()
+        assert sorted(sa.list_arguments()) == sorted(sb.list_arguments())
+        assert sorted(sa.list_auxiliary_states()) == sorted(sb.list_auxiliary_states())
+        # the reference class never calls Symbol.__init__; infer through the base-class method all the same
+        a.infer_shape(_mnv2_shapes(B, train))
+        b.infer_shape(_mnv2_shapes(B, train))
+        assert a.arg_shape_dict == b.arg_shape_dict and a.out_shape_dict == b.out_shape_dict
+        dflt = {'dilate': '(1, 1)', 'stride': '(1, 1)', 'pad': '(0, 0)', 'num_group': '1'}
+
+        def norm(n):
+            kv = [(k, str(tuple(v)) if isinstance(v, (list, tuple)) else str(v)) for k, v in n.attrs.items()
+                  if k not in ('workspace', 'cudnn_off')]
+            return (n.op, n.name, sorted((k, v) for k, v in kv if dflt.get(k) != v))
+
+        na, nb = [norm(n) for n in sa._topo() if n.op], [norm(n) for n in sb._topo() if n.op]
+        assert len(na) == len(nb) and sorted(na) == sorted(nb)
