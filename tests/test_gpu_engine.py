@@ -410,4 +410,4 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
             continue
         _grad_close(p.to_reference(p.grad.detach().cpu().numpy()), wgrads[name], name)
         checked += 1
-    assert checked == 53 + 4 + 4 + 4 + 1 + 5       # trunk convs, head convs (+bias), FC weights/biases, offset
+    assert checked == 71       # 53 trunk convolutions + 4 head convolutions and 5 FCs with their biases
