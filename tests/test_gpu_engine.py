@@ -403,11 +403,19 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
     assert_close(got[2], want[2], 1e-2, 1e-2, 'cls_prob')
     assert_close(got[3], want[3], 1e-2, 1e-2 * np.abs(want[3]).max() + 1e-4, 'bbox_loss')
     assert np.array_equal(got[4], want[4])
-    checked = 0
+    checked, report, bad = 0, [], []
     for name, p in ex.params.items():
         if not p.trainable:
             assert name.endswith('_gamma') or name.endswith('_beta'), name
             continue
-        _grad_close(p.to_reference(p.grad.detach().cpu().numpy()), wgrads[name], name)
+        g, w = p.to_reference(p.grad.detach().cpu().numpy()), wgrads[name]
+        rel = float(np.linalg.norm(g.astype(np.float64) - w) / (np.linalg.norm(w) + 1e-12))
+        report.append('%-44s relL2 %.4f  max|want| %.3g' % (name, rel, np.abs(w).max()))
+        try:
+            _grad_close(g, w, name)
+        except AssertionError as e:
+            bad.append(str(e)[:160])
         checked += 1
+    print('\n'.join(report))
+    assert not bad, '%d of %d gradients out of tolerance:\n%s' % (len(bad), checked, '\n'.join(bad))
     assert checked == 71       # 53 trunk convolutions + 4 head convolutions and 5 FCs with their biases
