@@ -392,19 +392,19 @@ def test_multi_proposal_target_vs_oracle():
     assert (sc.view(B, post)[:, :-1] >= sc.view(B, post)[:, 1:]).float().mean() > 0.95
 
 
-@pytest.mark.parametrize('B,C,H,W,R', [(2, 64, 12, 12, 9), (3, 256, 10, 14, 40)])
-def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R):
+@pytest.mark.parametrize('B,C,H,W,R,SC', [(2, 64, 12, 12, 9, 16), (3, 256, 10, 14, 40, 16), (2, 128, 16, 16, 600, 32)])
+def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R, SC):
     hip = _hip()
     rs = np.random.RandomState(9)
     P, S = 7, 4
     data = rs.standard_normal((B, C, H, W)).astype(np.float32)
     rois = np.zeros((R, 5), np.float32)
     rois[:, 0] = rs.randint(0, B, R)
-    c = rs.uniform(20, 16 * min(H, W) - 20, (R, 2))
-    wh = rs.uniform(4, 120, (R, 2))
+    c = rs.uniform(20, SC * min(H, W) - 20, (R, 2))
+    wh = rs.uniform(4, 120 * SC / 16, (R, 2))
     rois[:, 1:3], rois[:, 3:5] = c - wh / 2, c + wh / 2
     rois[0, 1:] = [-30, -20, 40, 50]   # partly outside
-    rois[1, 1:] = [0, 0, 16 * W - 1, 16 * H - 1]   # whole map
+    rois[1, 1:] = [0, 0, SC * W - 1, SC * H - 1]   # whole map
     rois[2, 1:] = [33, 47, 34, 48]   # tiny: every sample of a bin in one cell
     trans = (rs.standard_normal((R, 2, P, P)) * 0.5).astype(np.float32)
     dd = to_nhwc_f16(data)
@@ -412,18 +412,18 @@ def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R):
     ws = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=dev())
     for tr, tstd in ((None, 0.0), (trans, 0.1)):
         out = torch.empty((R, P, P, C), dtype=torch.float16, device=dev())
-        hip.call('sn_dpsroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, C, P, S, 1 / 16., tstd, hip.stream())
-        want = onn.dpsroi_pool(f16r(data).astype(np.float64), rois, tr, P, S, 1 / 16., tstd)
+        hip.call('sn_dpsroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, C, P, S, 1.0 / SC, tstd, hip.stream())
+        want = onn.dpsroi_pool(f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC, tstd)
         assert_close(out.float().cpu().numpy().transpose(0, 3, 1, 2), want, 1e-2, 1e-2, 'dpsroi fwd')
         dout = rs.standard_normal((R, C, P, P)).astype(np.float32)
         dod = torch.from_numpy(np.ascontiguousarray(dout.transpose(0, 2, 3, 1))).to(dev()).half()
-        wd, wtr = onn.dpsroi_pool_backward(f16r(dout).astype(np.float64), f16r(data).astype(np.float64), rois, tr, P, S, 1 / 16., tstd)
+        wd, wtr = onn.dpsroi_pool_backward(f16r(dout).astype(np.float64), f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC, tstd)
         for f32 in (1, 0):
             # poisoned outputs: the kernels must overwrite every element (no zeroing contract)
             d_data = torch.full((B, H, W, C), 7.0, dtype=torch.float32 if f32 else torch.float16, device=dev())
             d_trans = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
             hip.call('sn_dpsroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d_data, f32,
-                     d_trans if tr is not None else None, R, B, H, W, C, P, S, 1 / 16., tstd, ws, hip.stream())
+                     d_trans if tr is not None else None, R, B, H, W, C, P, S, 1.0 / SC, tstd, ws, hip.stream())
             tol = 1e-3 if f32 else 1e-2
             assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, tol, tol * np.abs(wd).max(), 'dpsroi d_data')
             if tr is not None:
@@ -431,7 +431,7 @@ def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R):
         # the tile kernel sums in a fixed order: bit-reproducible
         d2 = torch.empty_like(d_data)
         hip.call('sn_dpsroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d2, 0,
-                 d_trans if tr is not None else None, R, B, H, W, C, P, S, 1 / 16., tstd, ws, hip.stream())
+                 d_trans if tr is not None else None, R, B, H, W, C, P, S, 1.0 / SC, tstd, ws, hip.stream())
         assert torch.equal(d2, d_data)
 
 
