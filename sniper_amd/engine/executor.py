@@ -391,6 +391,10 @@ class Executor(object):
                 hip.call('sn_copy2d', p.master, p.w16, 1, p.numel, p.numel, p.numel, 1, 0, hip.stream())
             if p.wT16 is not None:
                 o, t, i = p.int_shape
+                if p.kind == 'fc':
+                    # an FC over a pooled (h, w, c) tensor is a 1x1 GEMM whose K index is the flat (hw, c) feature:
+                    # its data gradient needs W^T as [hw*C + c][O], not the convolution's [c][tap][O]
+                    t, i = 1, t * i
                 hip.call('sn_weight_transpose', p.master, p.wT16, o, t, i, _pad8(o), hip.stream())
         self._bn_cache_valid = False
         for s in self.steps:
