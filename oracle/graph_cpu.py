@@ -86,6 +86,22 @@ class _SoftmaxOutput(torch.autograd.Function):
         return g.reshape(p.shape), None, None, None, None, None, None
 
 
+class _RoundF16(torch.autograd.Function):
+    """value -> nearest fp16 (what the device stores for an activation); gradient passes straight through."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+# operators whose output the engine keeps as an fp16 activation tensor (sniper_amd/engine/executor.py, _PRODUCES_ACT)
+_F16_OUT = {'Convolution', 'FullyConnected', 'BatchNorm', 'Activation', 'Pooling', 'Concat', 'DeformableConvolution',
+            'DeformablePSROIPooling', 'clip', '_plus', 'elemwise_add'}
+
+
 class _MakeLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, grad_scale):
@@ -126,12 +142,15 @@ class _DeformIm2col(torch.autograd.Function):
         return torch.from_numpy(dd).float(), torch.from_numpy(do).float(), None, None, None, None, None
 
 
-def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None, fork_ops=True):
+def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None, fork_ops=True, fp16_storage=False):
     """sym: sniper_amd.mx Symbol.  params / aux / inputs: {name: numpy array} in the reference's layouts.
     overrides: {(node name, output index): array} replaces that node output (used to compare the RoI heads on the
     very RoI set the device selected: a proposal whose score ties or whose IoU sits on the NMS threshold may
     legitimately differ between fp16 and fp32 features).  fork_ops=False skips the evaluation of an overridden
-    MultiProposal(Target) altogether.  Returns (list of output arrays, {param name: gradient array or None})."""
+    MultiProposal(Target) altogether.  fp16_storage=True rounds every activation the engine stores in fp16 to fp16
+    (arithmetic stays fp32): the ReLU / clip / max-pool decisions of a 50-layer network then coincide with the
+    device's instead of flipping wherever a pre-activation lies within fp16 rounding of the kink, which is what
+    an end-to-end GRADIENT comparison needs.  Returns (list of output arrays, {param name: gradient array or None})."""
     overrides = overrides or {}
     t = {k: torch.from_numpy(np.asarray(v, np.float32).copy()).requires_grad_(want_grads) for k, v in params.items()}
     auxt = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in aux.items()}
@@ -246,6 +265,8 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
                 y = y + s['bias'].reshape(1, -1, 1, 1)
         else:
             raise NotImplementedError('oracle.graph_cpu: operator %s (%s)' % (op, node.name))
+        if fp16_storage and op in _F16_OUT and not isinstance(y, tuple):
+            y = _RoundF16.apply(y)
         if isinstance(y, tuple):
             for i, yi in enumerate(y):
                 val[(id(node), i)] = yi

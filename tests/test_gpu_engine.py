@@ -397,7 +397,7 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
     mpt = [n for n in sym._topo() if n.op == 'MultiProposalTarget'][0]
     ov = {(mpt.name, i): ex.vals[(id(mpt), i)].t.cpu().numpy().reshape(ex.vals[(id(mpt), i)].shape) for i in range(4)}
     assert (ov[(mpt.name, 1)] > 0).sum() >= 1, 'the synthetic GT must produce some foreground RoIs'
-    want, wgrads = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False)
+    want, wgrads = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False, fp16_storage=True)
     assert_close(got[0], want[0], 1e-2, 1e-2, 'rpn_cls_prob')
     assert_close(got[1], want[1], 1e-2, 1e-2 * np.abs(want[1]).max() + 1e-4, 'rpn_bbox_loss')
     assert_close(got[2], want[2], 1e-2, 1e-2, 'cls_prob')
