@@ -142,7 +142,8 @@ class _DeformIm2col(torch.autograd.Function):
         return torch.from_numpy(dd).float(), torch.from_numpy(do).float(), None, None, None, None, None
 
 
-def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None, fork_ops=True, fp16_storage=False):
+def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None, fork_ops=True, fp16_storage=False,
+        probe=None):
     """sym: sniper_amd.mx Symbol.  params / aux / inputs: {name: numpy array} in the reference's layouts.
     overrides: {(node name, output index): array} replaces that node output (used to compare the RoI heads on the
     very RoI set the device selected: a proposal whose score ties or whose IoU sits on the NMS threshold may
@@ -152,6 +153,7 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
     device's instead of flipping wherever a pre-activation lies within fp16 rounding of the kink, which is what
     an end-to-end GRADIENT comparison needs.  Returns (list of output arrays, {param name: gradient array or None})."""
     overrides = overrides or {}
+    probes = {}     # probe: list of node names -> run() additionally returns {name: (value, gradient)} as a third result
     t = {k: torch.from_numpy(np.asarray(v, np.float32).copy()).requires_grad_(want_grads) for k, v in params.items()}
     auxt = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in aux.items()}
     val = {}
@@ -272,6 +274,9 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
                 val[(id(node), i)] = yi
         else:
             val[(id(node), 0)] = y
+        if probe and node.name in probe and not isinstance(y, tuple) and val[(id(node), 0)].requires_grad:
+            val[(id(node), 0)].retain_grad()
+            probes[node.name] = val[(id(node), 0)]
         for i in range(node.num_outputs):
             if (node.name, i) in overrides:
                 val[(id(node), i)] = torch.from_numpy(np.asarray(overrides[(node.name, i)], np.float32))
@@ -281,4 +286,7 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
         diff = [o for o in outs if o.requires_grad]
         torch.autograd.backward(diff, [torch.ones_like(o) for o in diff])
         grads = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in t.items()}
+    if probe:
+        return [o.detach().numpy() for o in outs], grads, {k: (v.detach().numpy(), None if v.grad is None else v.grad.numpy())
+                                                            for k, v in probes.items()}
     return [o.detach().numpy() for o in outs], grads
