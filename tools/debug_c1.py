@@ -52,7 +52,7 @@ for b in range(B):
     wh = rs.uniform(40, 320, (n, 2))
     gt[b, :n, :4] = np.clip(np.concatenate((c - wh / 2, c + wh / 2), 1), 0, 511)
     gt[b, :n, 4] = rs.randint(1, 81, n)
-inp = dict(data=(rs.standard_normal((B, 3, 512, 512)) * 50).astype(np.float32),
+inp = dict(data=f16r(rs.standard_normal((B, 3, 512, 512)) * 50),   # fp16-representable pixels: the stem packs the image to fp16
            valid_ranges=np.array([[0, 512]] * B, np.float32), im_info=np.array([[512, 512, 1.0]] * B, np.float32),
            label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.9, 0.07, 0.03]).astype(np.float32),
            bbox_target=(rs.standard_normal((B, 4 * A, F, F)) * 0.3).astype(np.float32),
