@@ -359,9 +359,9 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
         if name in shapes:
             continue
         if name.endswith('_gamma'):
-            P[name] = rs.uniform(0.8, 1.2, shp).astype(np.float32)
+            P[name] = rs.uniform(0.5, 0.9, shp).astype(np.float32)
         elif name.endswith('_beta'):
-            P[name] = rs.uniform(0.0, 0.5, shp).astype(np.float32)
+            P[name] = rs.uniform(0.3, 1.2, shp).astype(np.float32)
         elif name.endswith('_bias'):
             P[name] = np.zeros(shp, np.float32)
         elif name.startswith('offset'):
