@@ -143,7 +143,7 @@ class _DeformIm2col(torch.autograd.Function):
 
 
 def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None, fork_ops=True, fp16_storage=False,
-        probe=None):
+        probe=None, force=None):
     """sym: sniper_amd.mx Symbol.  params / aux / inputs: {name: numpy array} in the reference's layouts.
     overrides: {(node name, output index): array} replaces that node output (used to compare the RoI heads on the
     very RoI set the device selected: a proposal whose score ties or whose IoU sits on the NMS threshold may
@@ -153,6 +153,13 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
     device's instead of flipping wherever a pre-activation lies within fp16 rounding of the kink, which is what
     an end-to-end GRADIENT comparison needs.  Returns (list of output arrays, {param name: gradient array or None})."""
     overrides = overrides or {}
+    # force: {node name: value} -- teacher forcing.  The node is evaluated by the oracle on its (forced) inputs, the
+    # mismatch with the given value is recorded in run.local_err[name] (relative L2), and the given value replaces the
+    # oracle's downstream while the GRADIENT still flows through the oracle's operator (y + (forced - y).detach()).
+    # Every op is then compared on identical inputs and every ReLU / clip / max-pool takes the device's decisions, so
+    # parameter gradients can be compared tightly instead of through the chaotic sensitivity of a random-init network.
+    force = force or {}
+    run.local_err = {}
     probes = {}     # probe: list of node names -> run() additionally returns {name: (value, gradient)} as a third result
     t = {k: torch.from_numpy(np.asarray(v, np.float32).copy()).requires_grad_(want_grads) for k, v in params.items()}
     auxt = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in aux.items()}
@@ -269,6 +276,10 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
             raise NotImplementedError('oracle.graph_cpu: operator %s (%s)' % (op, node.name))
         if fp16_storage and op in _F16_OUT and not isinstance(y, tuple):
             y = _RoundF16.apply(y)
+        if node.name in force and not isinstance(y, tuple):
+            fv = torch.from_numpy(np.asarray(force[node.name], np.float32)).reshape(y.shape)
+            run.local_err[node.name] = float((y.detach() - fv).norm() / (fv.norm() + 1e-20))
+            y = y + (fv - y.detach())
         if isinstance(y, tuple):
             for i, yi in enumerate(y):
                 val[(id(node), i)] = yi

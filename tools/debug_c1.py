@@ -81,7 +81,18 @@ torch.cuda.synchronize()
 mpt = [n for n in sym._topo() if n.op == 'MultiProposalTarget'][0]
 ov = {(mpt.name, i): ex.vals[(id(mpt), i)].t.cpu().numpy().reshape(ex.vals[(id(mpt), i)].shape) for i in range(4)}
 names = list(rec.keys())
-want, wgrads, probes = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False, fp16_storage=True, probe=names)
+force = {}
+for st in ex.steps:
+    if st.node.name in rec and not (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)):
+        force[st.node.name] = rec[st.node.name][0]
+want, wgrads, probes = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False, fp16_storage=True, probe=names, force=force)
+le = graph_cpu.run.local_err
+print('teacher-forced per-node forward mismatch: max %.5f at %s; nodes > 2e-3: %s' % (
+    max(le.values()), max(le, key=le.get), [(k, round(v, 5)) for k, v in le.items() if v > 2e-3]))
+for name, p_ in ex.params.items():
+    if p_.trainable:
+        g, w = p_.to_reference(p_.grad.detach().cpu().numpy()), wgrads[name]
+        print('PARAM %-44s relL2 %.4f' % (name, float(np.linalg.norm(g.astype(np.float64) - w) / (np.linalg.norm(w) + 1e-20))))
 
 
 def rel(a, b):
