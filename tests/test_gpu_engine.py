@@ -317,64 +317,32 @@ def test_hip_graph_replay_matches_eager(monkeypatch):
         assert_close(pg[k].cpu().numpy(), pe[k].cpu().numpy(), 2e-2, 2e-2 * float(pe[k].abs().max()) + 1e-6, 'graph vs eager ' + k)
 
 
-def _grad_close(got, want, name):
-    """fp16 storage through a deep network vs the fp32 CPU evaluation: 5% of the tensor's scale for at least 90% of
-    the elements, 20% for all (ReLU / clip masks flip on pre-activations within fp16 rounding of the kink), 10% in L2."""
-    scale = np.abs(want).max() + 1e-6
-    err = np.abs(got.astype(np.float64) - want)
-    tol = 5e-2 * np.abs(want) + 5e-2 * scale
-    assert (err > tol).mean() <= 0.10, 'grad %s: %.1f%% of the elements outside 5%%' % (name, 100 * (err > tol).mean())
-    assert_close(got, want, 2e-1, 2e-1 * scale, 'grad %s (outliers)' % name)
-    assert np.linalg.norm(err) <= 0.1 * np.linalg.norm(want) + 1e-6, 'grad %s: relative L2 error %.3f' % (
-        name, np.linalg.norm(err) / np.linalg.norm(want))
-
-
-def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
-    """BASELINE config C1: MobileNetV2 Faster-RCNN, 1 scale, 2 x 512 x 512 synthetic chips.  The HIP engine's
-    training step against the whole graph evaluated with reference-semantics CPU ops (oracle/graph_cpu.py, fp32):
-    RPN outputs, RoI-head outputs and every parameter gradient.  Tolerance: north_star's 1e-2 relative on conv / loss
-    tensors (fp16 storage), looser where a gradient is a sum over thousands of fp16 activations (see _grad_close)."""
-    import sniper_amd.mx as mx
-    from oracle import graph_cpu
-    from sniper_amd import config as cfgmod
-    from sniper_amd.engine.executor import Executor
-    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
-    from sniper_amd.train import fixed_param_names
-    B, A, F = 2, 15, 16
-    cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
-    net = mn.mobilenetv2_e2e()
-    sym = net.get_symbol_rcnn(cfg)
-    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
-                  bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5), crowd_boxes=(B, 10, 5))
-    import os
-    os.environ['SNIPER_HIP_GRAPHS'] = '0'
-    try:
-        ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym))
-    finally:
-        os.environ.pop('SNIPER_HIP_GRAPHS', None)
-    rs = np.random.RandomState(11)
+def _init_params(sym, shapes, rs, bn_gamma=(0.5, 0.9), bn_beta=(0.3, 1.2)):
+    """Random parameters in the reference's layouts; matrices are fp16-representable (what the device multiplies)."""
     args, _, auxs = sym.infer_shape(**shapes)
     P, AUX = {}, {}
     for name, shp in zip(sym.list_arguments(), args):
         if name in shapes:
             continue
         if name.endswith('_gamma'):
-            P[name] = rs.uniform(0.5, 0.9, shp).astype(np.float32)
+            P[name] = rs.uniform(bn_gamma[0], bn_gamma[1], shp).astype(np.float32)
         elif name.endswith('_beta'):
-            P[name] = rs.uniform(0.3, 1.2, shp).astype(np.float32)
+            P[name] = rs.uniform(bn_beta[0], bn_beta[1], shp).astype(np.float32)
         elif name.endswith('_bias'):
             P[name] = np.zeros(shp, np.float32)
-        elif name.startswith('offset'):
-            P[name] = (rs.standard_normal(shp) * 1e-3).astype(np.float32)     # non-zero: exercises the trans branch
+        elif 'offset' in name:
+            P[name] = (rs.standard_normal(shp) * 1e-3).astype(np.float32)     # non-zero: exercises the offset branches
         elif any(name.startswith(h) for h in ('rpn_', 'conv_new_1', 'fc_new', 'cls_score', 'bbox_pred')):
             P[name] = (rs.standard_normal(shp) * 0.01).astype(np.float32)
         else:
             P[name] = (rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))).astype(np.float32)
     for name, shp in zip(sym.list_auxiliary_states(), auxs):
-        AUX[name] = np.ones(shp, np.float32) if name.endswith('_var') else np.zeros(shp, np.float32)
-    # weights as the device multiplies them (fp16-rounded matrices), identical on both sides
-    P = {k: (f16r(v) if v.ndim > 1 else v) for k, v in P.items()}
-    ex.set_params(P, AUX)
+        AUX[name] = rs.uniform(0.5, 1.5, shp).astype(np.float32) if name.endswith('_var') else \
+            (rs.standard_normal(shp) * 0.1).astype(np.float32)
+    return {k: (f16r(v) if v.ndim > 1 else v) for k, v in P.items()}, AUX
+
+
+def _train_inputs(rs, B, A, F, extra=()):
     gt = -np.ones((B, 100, 5), np.float32)
     for b in range(B):
         n = 40
@@ -382,40 +350,131 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
         wh = rs.uniform(40, 320, (n, 2))
         gt[b, :n, :4] = np.clip(np.concatenate((c - wh / 2, c + wh / 2), 1), 0, 511)
         gt[b, :n, 4] = rs.randint(1, 81, n)
-    inp = dict(data=f16r(rs.standard_normal((B, 3, 512, 512)) * 50),   # fp16-representable pixels: the stem packs the image to fp16
+    inp = dict(data=f16r(rs.standard_normal((B, 3, 512, 512)) * 50),   # fp16-representable pixels (the stem packs to fp16)
                valid_ranges=np.array([[0, 512]] * B, np.float32), im_info=np.array([[512, 512, 1.0]] * B, np.float32),
                label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.9, 0.07, 0.03]).astype(np.float32),
                bbox_target=(rs.standard_normal((B, 4 * A, F, F)) * 0.3).astype(np.float32),
-               bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.05).astype(np.float32), gt_boxes=gt,
-               crowd_boxes=-np.ones((B, 10, 5), np.float32))
+               bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.05).astype(np.float32), gt_boxes=gt)
+    for k in extra:
+        inp[k] = -np.ones((B, 10, 5), np.float32)
+    return inp
+
+
+def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
+    """One training step of the HIP engine against the whole graph evaluated by oracle/graph_cpu.py with TEACHER
+    FORCING: every operator of the CPU evaluation receives the device's input activations (so each node is compared
+    on identical inputs, and every ReLU / clip / max-pool / proposal decision is the device's), while gradients flow
+    through the CPU operators.  Without it a random-init 50-100 layer BatchNorm network amplifies the first fp16
+    rounding disagreement exponentially (measured: 1e-4 -> 1.5e-2 relative over MobileNetV2) and the flipped
+    activation masks put ~sqrt(noise) into every gradient -- the comparison would say nothing about the kernels.
+    Asserts: per-node forward mismatch <= tol_fwd (relative L2), every parameter gradient <= tol_grad (relative L2)."""
+    from oracle import graph_cpu
+    ex.set_params(P, AUX)
     outs = ex.forward(inp, is_train=True)
+    dev_vals = {}
+    for st in ex.steps:
+        y = getattr(st, 'y', None)
+        if y is None or y.t is None or (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)):
+            continue            # a BN fused with its activation holds the post-activation tensor: forced at the activation node
+        if getattr(st, 'fused', False) is False and type(st).__name__ in ('ActivationStep', 'ClipStep') or \
+                type(st).__name__ not in ('ActivationStep', 'ClipStep'):
+            pass
+        t = y.t.float()
+        if y.fmt == 'act' and len(y.shape) == 4:
+            t = t.permute(0, 3, 1, 2)
+        if int(np.prod(y.shape)) != t.numel():
+            continue
+        dev_vals[st.node.name] = t.reshape(y.shape).cpu().numpy()
     ex.backward()
     torch.cuda.synchronize()
     got = [o.cpu().numpy() for o in outs]
     assert all(np.isfinite(g).all() for g in got)
-    # the RoI set the device selected, handed to the CPU evaluation (proposal parity itself: test_gpu_nn_ops)
-    mpt = [n for n in sym._topo() if n.op == 'MultiProposalTarget'][0]
-    ov = {(mpt.name, i): ex.vals[(id(mpt), i)].t.cpu().numpy().reshape(ex.vals[(id(mpt), i)].shape) for i in range(4)}
-    assert (ov[(mpt.name, 1)] > 0).sum() >= 1, 'the synthetic GT must produce some foreground RoIs'
-    want, wgrads = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False, fp16_storage=True)
-    assert_close(got[0], want[0], 1e-2, 1e-2, 'rpn_cls_prob')
-    assert_close(got[1], want[1], 1e-2, 1e-2 * np.abs(want[1]).max() + 1e-4, 'rpn_bbox_loss')
-    assert_close(got[2], want[2], 1e-2, 1e-2, 'cls_prob')
-    assert_close(got[3], want[3], 1e-2, 1e-2 * np.abs(want[3]).max() + 1e-4, 'bbox_loss')
-    assert np.array_equal(got[4], want[4])
-    checked, report, bad = 0, [], []
+    ov = {}
+    for node in sym._topo():
+        if node.op in ('MultiProposalTarget', 'MultiProposal'):
+            for i in range(node.num_outputs):
+                v = ex.vals.get((id(node), i))
+                if v is not None and v.t is not None:
+                    ov[(node.name, i)] = v.t.cpu().numpy().reshape(v.shape)
+            dev_vals.pop(node.name, None)
+    want, wgrads = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False, fp16_storage=True, force=dev_vals)
+    le = graph_cpu.run.local_err
+    assert len(le) > 0.8 * len(dev_vals)
+    worst = max(le, key=le.get)
+    assert le[worst] <= tol_fwd, 'forward mismatch %.5f at node %s (tolerance %.1e); all > tol: %s' % (
+        le[worst], worst, tol_fwd, [(k, round(v, 5)) for k, v in le.items() if v > tol_fwd])
+    for g, w in zip(got, want):
+        assert_close(g, w, 1e-2, 1e-2 * np.abs(w).max() + 1e-5, 'graph output')
+    report, bad, checked = [], [], 0
     for name, p in ex.params.items():
         if not p.trainable:
-            assert name.endswith('_gamma') or name.endswith('_beta'), name
             continue
         g, w = p.to_reference(p.grad.detach().cpu().numpy()), wgrads[name]
-        rel = float(np.linalg.norm(g.astype(np.float64) - w) / (np.linalg.norm(w) + 1e-12))
-        report.append('%-44s relL2 %.4f  max|want| %.3g' % (name, rel, np.abs(w).max()))
-        try:
-            _grad_close(g, w, name)
-        except AssertionError as e:
-            bad.append(str(e)[:160])
+        rel = float(np.linalg.norm(g.astype(np.float64) - w) / (np.linalg.norm(w) + 1e-20))
+        report.append('%-44s relL2 %.5f' % (name, rel))
+        if not rel <= tol_grad:
+            bad.append(report[-1])
         checked += 1
     print('\n'.join(report))
-    assert not bad, '%d of %d gradients out of tolerance:\n%s' % (len(bad), checked, '\n'.join(bad))
+    assert not bad, '%d of %d parameter gradients beyond %.1e:\n%s' % (len(bad), checked, tol_grad, '\n'.join(bad))
+    return checked, ov
+
+
+def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
+    """BASELINE config C1: MobileNetV2 Faster-RCNN, 1 scale, 2 x 512 x 512 synthetic chips, against reference-semantics
+    CPU ops.  Tolerances: north_star asks 1e-2 relative for conv / loss tensors at fp16 storage; measured 2e-4 per node
+    and <= 1e-2 for every parameter gradient (the 3-channel stem: a sum over 131 072 pixels of fp16 gradients)."""
+    import os
+    from sniper_amd import config as cfgmod
+    from sniper_amd.engine.executor import Executor
+    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
+    from sniper_amd.train import fixed_param_names
+    B, A, F = 2, 15, 16
+    cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
+    sym = mn.mobilenetv2_e2e().get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                  bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5), crowd_boxes=(B, 10, 5))
+    os.environ['SNIPER_HIP_GRAPHS'] = '0'
+    try:
+        ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym))
+    finally:
+        os.environ.pop('SNIPER_HIP_GRAPHS', None)
+    rs = np.random.RandomState(11)
+    P, AUX = _init_params(sym, shapes, rs)
+    inp = _train_inputs(rs, B, A, F, extra=('crowd_boxes',))
+    checked, ov = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=2e-2)
     assert checked == 71       # 53 trunk convolutions + 4 head convolutions and 5 FCs with their biases
+    assert (ov[('multi_proposal_target', 1)] > 0).sum() >= 1, 'the synthetic GT must produce some foreground RoIs'
+
+
+def test_r101_c2_network_parity_vs_cpu_reference_ops():
+    """The BASELINE C2/C3 network (ResNet-101 C4 + deformable C5 + RPN + deformable PS-RoI heads) at 2 chips, same
+    teacher-forced end-to-end comparison: covers the frozen stem (bn_data folded into the packed 7x7 conv), max-pool,
+    the 33 bottlenecks with BN+ReLU fusion and in-kernel gradient accumulation, the three deformable convolutions
+    (sampling + offsets), Concat, and both RoI poolings."""
+    import os
+    from sniper_amd import config as cfgmod
+    from sniper_amd.engine.executor import Executor
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+    from sniper_amd.train import fixed_param_names
+    B, A, F = 2, 21, 32
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    sym = rn.resnet_mx_101_e2e(momentum=0.995).get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                  bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5))
+    os.environ['SNIPER_HIP_GRAPHS'] = '0'
+    try:
+        ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym))
+    finally:
+        os.environ.pop('SNIPER_HIP_GRAPHS', None)
+    rs = np.random.RandomState(12)
+    P, AUX = _init_params(sym, shapes, rs, bn_gamma=(0.5, 1.0), bn_beta=(-0.2, 0.4))
+    P['bn_data_gamma'][:] = 1.0
+    AUX['bn_data_moving_mean'][:] = 0.0
+    AUX['bn_data_moving_var'][:] = 1.0 - 2e-5      # bn_data == identity: the image stays fp16-representable
+    P['bn_data_beta'][:] = 0.0
+    inp = _train_inputs(rs, B, A, F)
+    checked, _ = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=2e-2)
+    assert checked >= 250
+
+
