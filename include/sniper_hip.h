@@ -105,6 +105,13 @@ int sn_nms_batch(const float *d_boxes, const int32_t *d_n, int B, int N, int dim
 int sn_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
                 float nms_overlap_thresh, int device_id);
 
+/* Soft-NMS (cpu_soft_nms, lib/nms/cpu_nms.pyx:17-110; method 1 linear, 2 gaussian, else hard) for P independent
+ * problems: d_boxes (total,5) f32 [x1,y1,x2,y2,score], problem p owns rows [d_off[p], d_off[p+1]) (at most
+ * sn_soft_nms_max_boxes() each, max_n = the largest).  In place, like the reference: on return rows
+ * [d_off[p], d_off[p] + d_count[p]) are the surviving boxes in the reference's order with their decayed scores. */
+size_t sn_soft_nms_max_boxes(void);
+int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, float sigma, float Nt, float threshold, int method,
+                      int32_t *d_count, sn_stream_t stream);
 
 /* ================================================================ network operators ===========
  * The graph operators of the un-vendored SNIPER-mxnet fork, at the call sites of

@@ -182,3 +182,156 @@ SN_EXPORT int sn_nms_host(int *keep_out, int *num_out, const float *boxes_host, 
   if (prev != device_id) (void)hipSetDevice(prev);
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Soft-NMS (lib/nms/cpu_nms.pyx:17-110): the test-time per-class suppression (`TEST.NMS_SIGMA`, gaussian method 2),
+// 80 classes x images of independent problems on a Pool(32) in the reference (lib/inference.py:152-230).
+//
+// The reference algorithm is sequential and ORDER DEPENDENT (in-place selection sort; a box whose decayed score
+// drops below `threshold` is overwritten by the last box and N shrinks), so a GPU version that wants the same rows in
+// the same order has to reproduce the array permutation, not just the arithmetic.  One workgroup per problem, the
+// problem's (n,5) array in LDS, and per outer iteration i three parallel phases that are provably the sequential
+// pass:
+//   1. arg-max of the scores in [i, N), first position on ties (the reference's strict `<` scan) -> swap into i;
+//   2. every box in (i, N) is decayed exactly once by the reference pass, whatever the removal order -> all
+//      weights in parallel, same float expressions (compiled -ffp-contract=off; the gaussian weight is
+//      exp() in double of the float quotient, narrowed once, as `np.exp` on a C float does);
+//   3. the removals: "overwrite the dead box with the last one, shrink, re-examine" fills the dead slots below the
+//      new N in INCREASING position order with the surviving tail boxes in DECREASING position order -> ranks from
+//      a block-wide prefix sum of the keep flags, one parallel move.
+// LDS: 25 bytes per box (array + flags + tail list): n <= 4096 per problem.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSoftThreads = 256;
+
+__global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(float *__restrict__ boxes, const int32_t *__restrict__ off,
+                                                                float sigma, float Nt, float threshold, int method,
+                                                                int32_t *__restrict__ count, int max_n) {
+  extern __shared__ __attribute__((aligned(16))) float soft_smem[];
+  float *bx = soft_smem;                                           // [max_n][5]
+  int *tail = reinterpret_cast<int *>(bx + (size_t)max_n * 5);     // [max_n]
+  unsigned char *keepf = reinterpret_cast<unsigned char *>(tail + max_n);   // [max_n]
+  __shared__ float r_score[kSoftThreads];
+  __shared__ int r_pos[kSoftThreads];
+  __shared__ int cnt[kSoftThreads + 1];
+  const int p = blockIdx.x, t = threadIdx.x;
+  const int base = off[p];
+  int N = off[p + 1] - base;
+  float *g = boxes + (size_t)base * 5;
+  for (int k = t; k < N * 5; k += kSoftThreads) bx[k] = g[k];
+  __syncthreads();
+  for (int i = 0; i < N; ++i) {
+    // ---- 1. arg-max over [i, N), smallest position among equals
+    const int len = N - i, per = (len + kSoftThreads - 1) / kSoftThreads;
+    const int lo = i + t * per, hi = min(N, lo + per);
+    float best = -INFINITY;
+    int bpos = 0x7fffffff;
+    for (int q = lo; q < hi; ++q) {
+      const float s = bx[q * 5 + 4];
+      if (bpos == 0x7fffffff || best < s) { best = s; bpos = q; }
+    }
+    r_score[t] = best;
+    r_pos[t] = bpos;
+    __syncthreads();
+    for (int w = kSoftThreads / 2; w > 0; w >>= 1) {
+      if (t < w) {
+        const float s2 = r_score[t + w];
+        const int p2 = r_pos[t + w];
+        // chunks are in position order: the right half wins only with a strictly larger score (or if the left is empty)
+        if (p2 != 0x7fffffff && (r_pos[t] == 0x7fffffff || r_score[t] < s2)) { r_score[t] = s2; r_pos[t] = p2; }
+      }
+      __syncthreads();
+    }
+    const int maxpos = r_pos[0];
+    __syncthreads();
+    if (t < 5 && maxpos != i) {
+      const float a = bx[i * 5 + t], b = bx[maxpos * 5 + t];
+      bx[i * 5 + t] = b;
+      bx[maxpos * 5 + t] = a;
+    }
+    __syncthreads();
+    const float tx1 = bx[i * 5], ty1 = bx[i * 5 + 1], tx2 = bx[i * 5 + 2], ty2 = bx[i * 5 + 3];
+    // ---- 2. decay every box in (i, N)
+    const int len2 = N - i - 1, per2 = (len2 + kSoftThreads - 1) / kSoftThreads;
+    const int lo2 = i + 1 + t * per2, hi2 = min(N, lo2 + per2);
+    int kept = 0;
+    for (int q = lo2; q < hi2; ++q) {
+      const float x1 = bx[q * 5], y1 = bx[q * 5 + 1], x2 = bx[q * 5 + 2], y2 = bx[q * 5 + 3];
+      bool keep = true;
+      const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
+      const float iw = fminf(tx2, x2) - fmaxf(tx1, x1) + 1;
+      if (iw > 0) {
+        const float ih = fminf(ty2, y2) - fmaxf(ty1, y1) + 1;
+        if (ih > 0) {
+          const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
+          const float ov = iw * ih / ua;
+          float weight;
+          if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+          else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
+          else weight = ov > Nt ? 0 : 1;
+          const float ns = weight * bx[q * 5 + 4];
+          bx[q * 5 + 4] = ns;
+          keep = !(ns < threshold);
+        }
+      }
+      keepf[q] = keep ? 1 : 0;
+      kept += keep ? 1 : 0;
+    }
+    cnt[t + 1] = kept;
+    if (t == 0) cnt[0] = 0;
+    __syncthreads();
+    // ---- 3. inclusive scan of the per-thread keep counts (Hillis-Steele over 256 entries)
+    for (int d = 1; d < kSoftThreads; d <<= 1) {
+      int v = 0;
+      if (t + 1 > d) v = cnt[t + 1 - d];
+      __syncthreads();
+      if (t + 1 > d) cnt[t + 1] += v;
+      __syncthreads();
+    }
+    const int K = cnt[kSoftThreads];
+    const int Nn = i + 1 + K;
+    if (Nn < N) {
+      // surviving boxes at positions >= Nn, ranked from the end -> tail[rank]
+      int kb = cnt[t];   // kept boxes before this thread's chunk
+      for (int q = lo2; q < hi2; ++q) {
+        if (keepf[q]) {
+          if (q >= Nn) tail[K - kb - 1] = q;
+          ++kb;
+        }
+      }
+      __syncthreads();
+      kb = cnt[t];
+      for (int q = lo2; q < hi2; ++q) {
+        if (keepf[q]) { ++kb; continue; }
+        if (q < Nn) {
+          const int hole_rank = (q - (i + 1)) - kb;   // dead boxes before q
+          const int src = tail[hole_rank];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) bx[q * 5 + c] = bx[src * 5 + c];
+        }
+      }
+      __syncthreads();
+      N = Nn;
+    }
+  }
+  for (int k = t; k < N * 5; k += kSoftThreads) g[k] = bx[k];
+  if (t == 0) count[p] = N;
+}
+
+SN_EXPORT size_t sn_soft_nms_max_boxes(void) { return 4096; }
+
+SN_EXPORT int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, float sigma, float Nt, float threshold,
+                                int method, int32_t *d_count, sn_stream_t stream) {
+  SN_REQUIRE(d_boxes && d_off && d_count && P > 0 && max_n > 0, "sn_soft_nms_batch: bad arguments");
+  SN_REQUIRE(max_n <= 4096, "sn_soft_nms_batch: at most 4096 boxes per problem (got %d)", max_n);
+  const int mn = (max_n + 3) / 4 * 4;
+  const size_t smem = (size_t)mn * 5 * sizeof(float) + (size_t)mn * sizeof(int) + (size_t)mn;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(soft_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(soft_nms_kernel, dim3(P), dim3(kSoftThreads), smem, sn_stream(stream), d_boxes, d_off, sigma, Nt, threshold,
+                     method, d_count, mn);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}

@@ -3,8 +3,8 @@ gpu_nms unconditionally, so both must exist for `import inference` to work.
 
 cpu_nms (hard NMS, suppress when IoU >= thresh) runs on the bitmask kernel with the threshold moved
 to the largest float32 strictly below `thresh` (IoU > t  <=>  IoU >= thresh for float32 IoUs).
-cpu_soft_nms: sequential Gaussian soft-NMS; SURVEY.md section 8(f).1 marks its GPU version as the
-next row -- until then it raises rather than silently computing on the host."""
+cpu_soft_nms / soft_nms_batch: the order-dependent sequential soft-NMS reproduced row for row by soft_nms_kernel
+(one workgroup per (image, class) problem; sniper_amd/csrc/nms.hip)."""
 import numpy as np
 
 from . import gpu_nms as _g
@@ -19,5 +19,40 @@ def cpu_nms(dets, thresh):
     return _g.gpu_nms(dets, float(t))
 
 
+def soft_nms_batch(problems, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
+    """P independent (n_p, 5) float32 problems in one launch (the per-class loop of lib/inference.py:152-230).
+    -> list of (m_p, 5) arrays: surviving boxes, reference order, decayed scores."""
+    import torch
+
+    from .. import hip
+    probs = [np.ascontiguousarray(b, np.float32).reshape(-1, 5) for b in problems]
+    out = [None] * len(probs)
+    idx = [i for i, b in enumerate(probs) if b.shape[0] > 0]
+    for i, b in enumerate(probs):
+        if b.shape[0] == 0:
+            out[i] = b.copy()
+    if not idx:
+        return out
+    cap = hip.query('sn_soft_nms_max_boxes')
+    sizes = [probs[i].shape[0] for i in idx]
+    if max(sizes) > cap:
+        raise ValueError('soft-NMS problem with %d boxes (at most %d fit one workgroup's LDS)' % (max(sizes), cap))
+    off = np.zeros(len(idx) + 1, np.int32)
+    off[1:] = np.cumsum(sizes)
+    d = hip.dev(np.concatenate([probs[i] for i in idx], 0))
+    d_off = hip.dev(off)
+    cnt = torch.empty((len(idx),), dtype=torch.int32, device=d.device)
+    hip.call('sn_soft_nms_batch', d, d_off, len(idx), int(max(sizes)), float(sigma), float(Nt), float(threshold), int(method), cnt,
+             hip.stream())
+    h, c = d.cpu().numpy(), cnt.cpu().numpy()
+    for k, i in enumerate(idx):
+        out[i] = h[off[k]:off[k] + c[k]].copy()
+    return out
+
+
 def cpu_soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
-    raise NotImplementedError("soft-NMS on the GPU is SURVEY.md 8(f) item 1 (next row); not built yet")
+    """Reference signature (cpu_nms.pyx:17): mutates `boxes` like the original and returns the surviving rows."""
+    res = soft_nms_batch([boxes], sigma, Nt, threshold, method)[0]
+    if isinstance(boxes, np.ndarray) and boxes.dtype == np.float32 and boxes.ndim == 2:
+        boxes[:res.shape[0]] = res          # the surviving prefix, as the in-place original leaves it
+    return res

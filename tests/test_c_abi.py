@@ -1,0 +1,65 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports every symbol include/sniper_hip.h declares; the
+host-only entry points (sizes, plans, argument validation) behave.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from sniper_amd import build as hipbuild
+    hipbuild.build(verbose=False)          # no-op when the objects are current; hipcc cross-compiles without a GPU
+    from sniper_amd._lib import lib as load
+    return load()
+
+
+def test_c_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'sniper_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', ' ', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(sn_\w+)\s*\(', hdr))
+    assert len(declared) >= 45
+    assert declared == set(lib.protos), declared ^ set(lib.protos)
+    dll = ctypes.CDLL(os.path.join(ROOT, 'sniper_amd', 'lib', 'libsniper_hip.so'))
+    for name in declared:
+        assert hasattr(dll, name), name
+    # nothing but the declared C symbols is exported from the kernel library (-fvisibility=hidden)
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', os.path.join(ROOT, 'sniper_amd', 'lib', 'libsniper_hip.so')],
+                         stdout=subprocess.PIPE, text=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if ' T ' in l)
+    assert declared <= exported
+    assert not [e for e in exported - declared if e.startswith('sn_')]
+
+
+def test_host_only_entry_points(lib):
+    raw = lib.raw
+    assert raw('sn_version')() >= 100
+    # chips::cgenerate candidate count (cchips.cpp:62-108): 3 corner chips + grid + right column + bottom row
+    assert raw('sn_chips_num_candidates')(512, 512, 512, 56) == 3
+    nx = -(-(1920 - 512) // 56)
+    ny = -(-(1440 - 512) // 56)
+    assert raw('sn_chips_num_candidates')(1920, 1440, 512, 56) == 3 + nx * ny + nx + ny
+    assert raw('sn_nms_workspace_bytes')(20, 6000) >= 20 * 6000 * ((6000 + 63) // 64) * 8
+    assert raw('sn_bn_workspace_bytes')(81920, 512) > 0 and raw('sn_bn_workspace_bytes')(81920, 7) == 0
+    # a 3x3 256->256 layer at 20x32x32 needs K-splits (36 tiles for 512 slots); the RPN conv does not
+    assert raw('sn_conv_wgrad_workspace_bytes')(20, 32, 32, 256, 256, 256, 256, 3, 3, 1, 1, 1) > 0
+    assert raw('sn_conv_wgrad_workspace_bytes')(20, 32, 32, 3072, 3072, 512, 512, 3, 3, 1, 1, 1) == 0
+    assert raw('sn_dpsroi_bwd_workspace_bytes')(6000) >= 6000 * 16
+
+
+def test_argument_errors_are_reported_before_any_launch(lib):
+    from sniper_amd._lib import SniperHipError
+    with pytest.raises(SniperHipError) as e:
+        lib.call('sn_conv_fwd', None, None, None, None, None, 1, 8, 8, 8, 8, 8, 8, 8, 3, 3, 1, 1, 1, 0, 0, None)
+    assert 'null pointer' in str(e.value)
+    with pytest.raises(SniperHipError) as e:
+        lib.call('sn_bn_stats', ctypes.c_void_p(16), 10, 12, 12, ctypes.c_void_p(16), None)
+    assert 'multiple of 8' in str(e.value)
+    with pytest.raises(SniperHipError) as e:
+        lib.call('sn_dwconv_fwd', ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 8, 8, 16, 16, 16, 5, 5, 1, 2,
+                 1, None)
+    assert '3x3' in str(e.value)

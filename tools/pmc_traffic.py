@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-FAMILY = ('conv_igemm_kernel', 'conv_wgrad_tr_kernel', 'conv_wgrad_kernel')
+FAMILY = ('conv_igemm_p2_kernel', 'conv_igemm_kernel', 'conv_wgrad_tr_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_kernel')
 
 
 def collect(d, counter):
