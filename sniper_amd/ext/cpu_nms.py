@@ -36,7 +36,7 @@ def soft_nms_batch(problems, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
     cap = hip.query('sn_soft_nms_max_boxes')
     sizes = [probs[i].shape[0] for i in idx]
     if max(sizes) > cap:
-        raise ValueError('soft-NMS problem with %d boxes (at most %d fit one workgroup's LDS)' % (max(sizes), cap))
+        raise ValueError('soft-NMS problem with %d boxes (at most %d fit the LDS of one workgroup)' % (max(sizes), cap))
     off = np.zeros(len(idx) + 1, np.int32)
     off[1:] = np.cumsum(sizes)
     d = hip.dev(np.concatenate([probs[i] for i in idx], 0))

@@ -63,3 +63,20 @@ def test_argument_errors_are_reported_before_any_launch(lib):
         lib.call('sn_dwconv_fwd', ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 8, 8, 16, 16, 16, 5, 5, 1, 2,
                  1, None)
     assert '3x3' in str(e.value)
+
+
+def test_every_python_source_compiles():
+    """Modules that only the -m gpu tests import must still be syntactically valid on the CPU tier."""
+    import py_compile
+    bad = []
+    for top in ('sniper_amd', 'oracle', 'tools', 'tests'):
+        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+            for f in fs:
+                if f.endswith('.py'):
+                    try:
+                        py_compile.compile(os.path.join(dp, f), cfile=os.devnull, doraise=True)
+                    except py_compile.PyCompileError as e:
+                        bad.append(str(e))
+    for f in ('bench.py', '__graft_entry__.py'):
+        py_compile.compile(os.path.join(ROOT, f), cfile=os.devnull, doraise=True)
+    assert not bad, bad
