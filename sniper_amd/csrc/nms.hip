@@ -236,8 +236,11 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(float *__restric
       if (t < w) {
         const float s2 = r_score[t + w];
         const int p2 = r_pos[t + w];
-        // chunks are in position order: the right half wins only with a strictly larger score (or if the left is empty)
-        if (p2 != 0x7fffffff && (r_pos[t] == 0x7fffffff || r_score[t] < s2)) { r_score[t] = s2; r_pos[t] = p2; }
+        // first position among equal scores (an interleaved tree does not keep the halves in position order)
+        if (p2 != 0x7fffffff && (r_pos[t] == 0x7fffffff || r_score[t] < s2 || (r_score[t] == s2 && p2 < r_pos[t]))) {
+          r_score[t] = s2;
+          r_pos[t] = p2;
+        }
       }
       __syncthreads();
     }
