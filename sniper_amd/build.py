@@ -23,6 +23,7 @@ EXTRA = {
     "data_path.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],
     "proposal.hip": ["-ffp-contract=off"],
+    "infer.hip": ["-ffp-contract=off"],
 }
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
         "-munsafe-fp-atomics"]

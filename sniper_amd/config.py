@@ -68,6 +68,7 @@ def _base():
         'SCALES': ((1400, 2000), (800, 1280), (480, 512)), 'VALID_RANGES': ((-1, 90), (32, 180), (75, -1)),
         'BATCH_IMAGES': (2, 2, 4), 'RPN_NMS_THRESH': 0.7, 'RPN_PRE_NMS_TOP_N': 6000, 'RPN_POST_NMS_TOP_N': 300,
         'RPN_MIN_SIZE': 0, 'NMS': -1, 'NMS_SIGMA': 0.55, 'MAX_PER_IMAGE': 200, 'AUTO_FOCUS': False,
+        'DO_PRUNING': (False, False, False), 'CHIP_HYPERPARAMS': ((-1, -1, -1),) * 3, 'CONCURRENT_JOBS': 1,
     }
     return c
 
@@ -77,6 +78,20 @@ def res101_e2e(batch_images=20):
     c = _base()
     c.symbol = 'resnet_mx_101_e2e'
     c.TRAIN.BATCH_IMAGES = batch_images
+    return c
+
+
+def res101_e2e_autofocus(batch_images=20):
+    """configs/faster/sniper_res101_e2e_autofocus.yml TEST section (BASELINE C5): coarse-to-fine scales, FocusChips."""
+    c = res101_e2e(batch_images)
+    c.TEST.SCALES = ((480, 512), (800, 1280), (1400, 2000))
+    c.TEST.BATCH_IMAGES = (8, 8, 2)
+    c.TEST.VALID_RANGES = ((75, -1), (32, 180), (-1, 75))
+    c.TEST.AUTO_FOCUS = True
+    c.TEST.DO_PRUNING = (False, True, True)
+    c.TEST.CHIP_HYPERPARAMS = ((3, 0.02, 16), (3, 0.2, 20), (-1, -1, -1))
+    c.TEST.USE_CACHE = (False, False, False)
+    c.TEST.CONCURRENT_JOBS = 1
     return c
 
 

@@ -1,0 +1,80 @@
+"""`im_worker` (lib/data_utils/data_workers.py:40-121) on the GPU: the decoded BGR uint8 image is uploaded once and
+flip + crop + bilinear resize + mean subtraction + channel reversal + zero padding are one kernel (`sn_im_prepare`),
+writing straight into the batch tensor in HBM -- no per-image float32 host arrays, no 8-thread pool.
+
+Image source: the reference reads `roidb[i]['image']` with cv2.imread.  OpenCV is not part of this image; an entry may
+be a numpy (H,W,3) uint8 BGR array, a `.npy` path, or any file PIL can open (converted RGB -> BGR)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import hip
+
+
+def load_bgr(image):
+    if isinstance(image, np.ndarray):
+        im = image
+    elif isinstance(image, str) and image.endswith('.npy'):
+        im = np.load(image)
+    else:
+        from PIL import Image
+        im = np.asarray(Image.open(image).convert('RGB'))[:, :, ::-1]
+    im = np.ascontiguousarray(im, np.uint8)
+    if im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError('expected an (H, W, 3) BGR uint8 image, got %s' % (im.shape,))
+    return im
+
+
+def target_scale(width, height, target_size):
+    """Scale rule shared by im_worker.worker (:99-105), MNIteratorTestAutoFocus (:46-51) and add_chips."""
+    im_size_min, im_size_max = min(width, height), max(width, height)
+    scale = float(target_size[0]) / float(im_size_min)
+    if np.round(scale * im_size_max) > target_size[1]:
+        scale = float(target_size[1]) / float(im_size_max)
+    return scale
+
+
+class im_worker(object):
+    def __init__(self, cfg, crop_size=None, target_size=None):
+        self.cfg = cfg
+        self.crop_size = crop_size
+        self.target_size = target_size if target_size else cfg.TRAIN.SCALES[0]
+        self.means = np.asarray(cfg.network.PIXEL_MEANS, np.float32)
+        self._cache = {}
+
+    def _device_image(self, image):
+        key = image if isinstance(image, str) else id(image)
+        if key not in self._cache:
+            if len(self._cache) > 256:
+                self._cache.clear()
+            self._cache[key] = hip.dev(load_bgr(image))
+        return self._cache[key]
+
+    def _run(self, image, out, crop, scale, flip):
+        d = self._device_image(image)
+        H, W = int(d.shape[0]), int(d.shape[1])
+        hw = (ctypes.c_int32 * 2)()
+        x1, y1, x2, y2 = crop if crop is not None else (0, 0, W, H)
+        hip.call('sn_im_prepare', d, H, W, int(x1), int(y1), int(x2), int(y2), float(scale), 1 if flip else 0,
+                 self.means.ctypes.data_as(ctypes.c_void_p), out, int(out.shape[1]), int(out.shape[2]), hw, hip.stream())
+        return int(hw[0]), int(hw[1])
+
+    def worker_autofocus(self, data, out):
+        """data = [image, max_size, flipped, crop (x1,y1,x2,y2) or None, scale]; out (3, Hm, Wm) device view.
+        -> (scale, (resized_h, resized_w)) like the reference (:49-78) (the tensor is written in place)."""
+        image, max_size, flipped, crop, scale = data
+        c = None if crop is None else (max(int(crop[0]), 0), max(int(crop[1]), 0), int(crop[2]), int(crop[3]))
+        return scale, self._run(image, out, c, scale, False)
+
+    def worker(self, data, out):
+        """data = [image, crop-or-max_size, flipped]; full-image mode computes the scale from target_size (:99-105)."""
+        image, second, flipped = data[0], data[1], data[2]
+        if self.crop_size:
+            crop = second
+            c = (int(crop[0][0]), int(crop[0][1]), int(crop[0][2]), int(crop[0][3]))
+            self._run(image, out, c, crop[1], flipped)
+            return None
+        d = self._device_image(image)
+        scale = target_scale(int(d.shape[1]), int(d.shape[0]), self.target_size)
+        return scale, self._run(image, out, None, scale, flipped)

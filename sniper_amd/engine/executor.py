@@ -148,6 +148,10 @@ class Executor(object):
             self._const[key] = fn()
         return self._const[key]
 
+    def vals_shape(self, input_name):
+        """bound shape of a graph input"""
+        return self.shapes[('var', input_name)]
+
     def val_of(self, node, idx=0):
         return self.vals[(id(node), idx)]
 

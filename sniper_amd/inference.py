@@ -1,0 +1,299 @@
+"""Inference driver, contract of lib/inference.py (`Tester` :26-408, `detect_scale_worker` :411-436,
+`imdb_detection_wrapper` :439-529): forward -> decode/clip/rescale -> score threshold -> per-class (soft-)NMS ->
+AutoFocus pruning / FocusChips -> multi-scale aggregation.
+
+Same class, method names, arguments and return structures (`all_boxes[class][image][chip]` -> `(n,5)` arrays).  What
+moved to the GPU (MI355X first, not a translation of the host loops):
+  * `detect`: bbox_pred + clip_boxes + /scale of every chip of the batch is ONE `sn_bbox_decode` launch
+    (reference: a numpy loop per chip, :122-131);
+  * `nms_worker` / `aggregate`: the 80 classes x images of independent soft-NMS problems are batched into
+    `sn_soft_nms_batch` launches (reference: `Pool(32).map` over `cpu_soft_nms`, :159-201; ThreadPool(8) :308-310);
+  * hard NMS uses the bitmask kernel.
+Dataset I/O (imdb, pickled caches, visualisation) is out of scope: `imdb` only needs `result_path`, `num_classes`,
+`classes`, `name`."""
+import math
+
+import numpy as np
+import torch
+
+import sniper_amd.mx as mx
+
+from . import hip
+from .chips_inference import add_chips
+from .ext import cpu_nms as _cpu_nms
+from .ext import gpu_nms as _gpu_nms
+from .iterators.MNIteratorTestAutoFocus import MNIteratorTestAutoFocus
+from .iterators.PrefetchingIter import PrefetchingIter
+
+
+class nms_wrapper(object):
+    """lib/nms/nms.py:15-23: hard NMS when thresh > 0, gaussian soft-NMS (sigma) otherwise."""
+
+    def __init__(self, thresh, sigma):
+        assert thresh < 0 or sigma < 0, 'Either nms sigma or nms thresh should be set to negative'
+        self.thresh, self.sigma = thresh, sigma
+
+    def process(self, dets):
+        return self.process_many([dets])[0]
+
+    def process_many(self, problems):
+        """One launch for a list of independent (n,5) problems."""
+        problems = [np.ascontiguousarray(d, np.float32).reshape(-1, 5) for d in problems]
+        if self.thresh > 0:
+            out = []
+            for d in problems:
+                keep = _gpu_nms.gpu_nms(d, self.thresh) if d.shape[0] else []
+                out.append(d[keep, :] if len(keep) else np.zeros((0, 5), np.float32))
+            return out
+        cap = int(hip.query('sn_soft_nms_max_boxes'))
+        big = [i for i, d in enumerate(problems) if d.shape[0] > cap]
+        for i in big:       # keep the best-scoring `cap` boxes of an oversized problem (the rest could only lose score)
+            problems[i] = problems[i][np.argsort(-problems[i][:, 4], kind='stable')[:cap]]
+        return _cpu_nms.soft_nms_batch(problems, sigma=self.sigma, Nt=0.3, threshold=0.001, method=2)
+
+
+class nms_worker(object):
+    """lib/data_utils/data_workers.py:124-129."""
+
+    def __init__(self, nms_thresh, nms_sigma):
+        self.nms_wrapper = nms_wrapper(nms_thresh, nms_sigma)
+
+    def worker(self, data):
+        return self.nms_wrapper.process(data)
+
+    def worker_many(self, datas):
+        return self.nms_wrapper.process_many(datas)
+
+
+def _valid_range_filter(cls_dets, valid_range):
+    """lib/inference.py:176-186 (the names are swapped there too: `heights` is the x extent)."""
+    heights = cls_dets[:, 2] - cls_dets[:, 0]
+    widths = cls_dets[:, 3] - cls_dets[:, 1]
+    areas = widths * heights
+    ok = np.ones(len(areas), bool)
+    if valid_range[0] > 0:
+        ok &= areas > valid_range[0] * valid_range[0]
+    if valid_range[1] > 0:
+        ok &= areas <= valid_range[1] * valid_range[1]
+    return cls_dets[ok, :]
+
+
+class Tester(object):
+    def __init__(self, module, imdb, roidb, test_iter, cfg, rcnn_output_names=None, rpn_output_names=None, logger=None,
+                 batch_size=None):
+        self.test_iter = test_iter
+        if test_iter is not None and not isinstance(test_iter, PrefetchingIter):
+            self.test_iter = PrefetchingIter(self.test_iter)
+            self.scale = test_iter.test_scale
+        self.cfg = cfg
+        self.module = module
+        if test_iter is not None:
+            self.data_names = [k[0] for k in test_iter.provide_data_single]
+        self.rcnn_output_names = rcnn_output_names or {
+            'cls': 'cls_prob_reshape_output', 'bbox': 'bbox_pred_reshape_output', 'im_ids': 'im_ids',
+            'scale_map': 'scale_prob_output', 'im_info': 'im_info', 'chip_ids': 'chip_ids'}
+        self.rpn_output_names = rpn_output_names or {'scores': 'rois_score', 'rois': 'rois_output', 'im_ids': 'im_ids'}
+        self.logger = logger
+        self.result_path = getattr(imdb, 'result_path', None)
+        self.num_classes = imdb.num_classes
+        self.class_names = getattr(imdb, 'classes', None)
+        self.num_images = len(roidb)
+        self.imdb_name = getattr(imdb, 'name', 'imdb')
+        self.nms_worker = nms_worker(cfg.TEST.NMS, cfg.TEST.NMS_SIGMA)
+        self.batch_size = batch_size or self.cfg.TEST.BATCH_IMAGES
+        self.roidb = roidb
+        self.verbose = len(roidb) > 1
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, batch):
+        self.module.forward(batch, is_train=False)
+        return [dict(zip(self.module.output_names, i)) for i in zip(*self.module.get_outputs(merge_multi_context=False))]
+
+    def get_proposals(self, batch, scales):
+        data = dict(zip(self.data_names, batch.data))
+        outputs = self.forward(batch)
+        scores, rois = [], []
+        im_ids = np.array([], dtype=int)
+        for gpu_out, gpu_scales in zip(outputs, scales):
+            gpu_rois = gpu_out[self.rpn_output_names['rois']].asnumpy()
+            gpu_scores = gpu_out[self.rpn_output_names['scores']].asnumpy()
+            nper_gpu = gpu_rois.shape[0] // self.batch_size
+            im_ids = np.hstack((im_ids, gpu_out[self.rpn_output_names['im_ids']].asnumpy().astype(int)))
+            for idx in range(self.batch_size):
+                cids = np.where(gpu_rois[:, 0] == idx)[0]
+                assert len(cids) == nper_gpu, 'The number of rois per GPU should be fixed!'
+                scores.append(gpu_scores[cids])
+                rois.append(gpu_rois[cids, 1:] / gpu_scales[idx])
+        return scores, rois, data, im_ids
+
+    def detect(self, batch, scales):
+        data = dict(zip(self.data_names, batch.data))
+        outputs = self.forward(batch)
+        scores, preds, maps = [], [], []
+        im_ids = np.array([], dtype=int)
+        chip_ids = np.array([], dtype=int)
+        has_focus_maps = self.rcnn_output_names['scale_map'] in outputs[0]
+        for gpu_out, gpu_scales in zip(outputs, scales):
+            rois = gpu_out[self.rpn_output_names['rois']]._data              # (B*R, 5) device, rows of chip b contiguous
+            deltas = gpu_out[self.rcnn_output_names['bbox']]._data           # (B, R, 4)
+            infos = gpu_out[self.rcnn_output_names['im_info']]._data         # (B, 3) = h, w, scale
+            B, R = int(deltas.shape[0]), int(deltas.shape[1])
+            assert rois.shape[0] == B * R, 'The number of rois per GPU should be fixed!'
+            boxes = torch.empty((B, R, 4), dtype=torch.float64, device=rois.device)
+            hip.call('sn_bbox_decode', rois.contiguous(), deltas.contiguous(), infos.float().contiguous(), boxes, B, R, hip.stream())
+            gpu_scores = gpu_out[self.rcnn_output_names['cls']].asnumpy()
+            boxes = boxes.cpu().numpy()
+            if has_focus_maps:
+                scale_prob = gpu_out[self.rcnn_output_names['scale_map']].asnumpy()
+            im_ids = np.hstack((im_ids, gpu_out[self.rcnn_output_names['im_ids']].asnumpy().astype(int)))
+            chip_ids = np.hstack((chip_ids, gpu_out[self.rcnn_output_names['chip_ids']].asnumpy().astype(int)))
+            for idx in range(B):
+                scores.append(gpu_scores[idx])
+                preds.append(boxes[idx])
+                if has_focus_maps:
+                    maps.append(scale_prob[idx])
+        return scores, preds, data, im_ids, maps, chip_ids
+
+    def set_scale(self, scale):
+        it = self.test_iter.iters[0] if isinstance(self.test_iter, PrefetchingIter) else self.test_iter
+        it.set_scale(scale)
+        self.test_iter.reset()
+
+    def show_info(self, print_str):
+        print(print_str)
+        if self.logger:
+            self.logger.info(print_str)
+
+    # ---- multi-scale aggregation (:152-230) ---------------------------------------------------------
+    def aggregate(self, scale_cls_dets, vis=False, cache_name='cache', vis_path=None, vis_name=None, pre_nms_db_divide=10,
+                  vis_ext='.png'):
+        n_scales = len(scale_cls_dets)
+        assert n_scales == len(self.cfg.TEST.VALID_RANGES), 'A valid range should be specified for each test scale'
+        all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
+        problems = []
+        for i in range(self.num_images):
+            for j in range(1, self.num_classes):
+                agg = [np.empty((0, 5), np.float32)]
+                for all_cls_dets, valid_range in zip(scale_cls_dets, self.cfg.TEST.VALID_RANGES):
+                    for c in range(len(all_cls_dets[j][i])):
+                        cls_dets = _valid_range_filter(np.asarray(all_cls_dets[j][i][c], np.float32).reshape(-1, 5), valid_range)
+                        if cls_dets.shape[0] > 0:
+                            agg.append(cls_dets)
+                problems.append(np.vstack(agg))
+        final = self.nms_worker.worker_many(problems)          # one batched launch instead of Pool(32).map
+        k = 0
+        for i in range(self.num_images):
+            for j in range(1, self.num_classes):
+                all_boxes[j][i] = final[k]
+                k += 1
+        for i in range(self.num_images):
+            if self.cfg.TEST.MAX_PER_IMAGE > 0:
+                image_scores = np.hstack([all_boxes[j][i][:, -1] for j in range(1, self.num_classes)])
+                if len(image_scores) > self.cfg.TEST.MAX_PER_IMAGE:
+                    image_thresh = np.sort(image_scores)[-self.cfg.TEST.MAX_PER_IMAGE]
+                    for j in range(1, self.num_classes):
+                        keep = np.where(all_boxes[j][i][:, -1] >= image_thresh)[0]
+                        all_boxes[j][i] = all_boxes[j][i][keep, :]
+        return all_boxes
+
+    # ---- per-scale detection loop (:232-370) --------------------------------------------------------
+    @staticmethod
+    def _check_valid(det, chip, im_width, im_height, delta=10):
+        dx1, dy1, dx2, dy2 = det[0], det[1], det[2], det[3]
+        cx1, cy1, cx2, cy2 = chip[0], chip[1], chip[2], chip[3]
+        if cx1 >= 0.5 and abs(dx1 - cx1) < delta:
+            return False
+        if cy1 >= 0.5 and abs(dy1 - cy1) < delta:
+            return False
+        if cx2 < im_width - 0.5 and abs(dx2 - cx2) < delta:
+            return False
+        if cy2 < im_height - 0.5 and abs(dy2 - cy2) < delta:
+            return False
+        return True
+
+    def get_detections(self, cls_thresh=1e-3, cache_name='cache', evaluate=False, vis=False, vis_path=None, do_pruning=False,
+                       autofocus=False, vis_ext='.png'):
+        n_chips = [len(r['inference_crops']) for r in self.roidb]
+        all_boxes = [[[[] for _ in range(n_chips[i])] for i in range(self.num_images)] for _ in range(self.num_classes)]
+        all_maps = [[[] for _ in range(n_chips[i])] for i in range(self.num_images)]
+        for batch in self.test_iter:
+            im_info = batch.data[1].asnumpy()
+            scales = im_info[:, 2].reshape(-1, self.batch_size)
+            scores, boxes, data, im_ids, maps, chip_ids = self.detect(batch, scales)
+            todo = []
+            for i, (cscores, cboxes, im_id, chip_id) in enumerate(zip(scores, boxes, im_ids, chip_ids)):
+                if autofocus:
+                    all_maps[im_id][chip_id] = maps[i]
+                for j in range(1, self.num_classes):
+                    inds = np.where(cscores[:, j] > cls_thresh)[0]
+                    cls_dets = np.hstack((cboxes[inds, 0:4], cscores[inds, j, np.newaxis]))
+                    if evaluate:
+                        todo.append((j, im_id, chip_id, cls_dets))
+                    else:
+                        all_boxes[j][im_id][chip_id] = cls_dets
+            if evaluate:
+                final = self.nms_worker.worker_many([t[3] for t in todo])
+                for (j, im_id, chip_id, _), d in zip(todo, final):
+                    all_boxes[j][im_id][chip_id] = d
+                if self.cfg.TEST.MAX_PER_IMAGE:
+                    for im_id, chip_id in set((t[1], t[2]) for t in todo):
+                        image_scores = np.hstack([all_boxes[j][im_id][chip_id][:, -1] for j in range(1, self.num_classes)])
+                        if len(image_scores) > self.cfg.TEST.MAX_PER_IMAGE:
+                            image_thresh = np.sort(image_scores)[-self.cfg.TEST.MAX_PER_IMAGE]
+                            for j in range(1, self.num_classes):
+                                keep = np.where(all_boxes[j][im_id][chip_id][:, -1] >= image_thresh)[0]
+                                all_boxes[j][im_id][chip_id] = all_boxes[j][im_id][chip_id][keep, :]
+            if do_pruning:     # project the boxes back to image coordinates, drop those cut by a chip border (:336-353)
+                for im_id, chip_id in set(zip(im_ids.tolist(), chip_ids.tolist())):
+                    crop = self.roidb[im_id]['inference_crops'][chip_id]
+                    for j in range(1, self.num_classes):
+                        cls_dets = np.array(all_boxes[j][im_id][chip_id], dtype=np.float64).reshape(-1, 5)
+                        cls_dets[:, 0] += crop[0]; cls_dets[:, 2] += crop[0]
+                        cls_dets[:, 1] += crop[1]; cls_dets[:, 3] += crop[1]
+                        ok = [self._check_valid(d, crop, self.roidb[im_id]['width'], self.roidb[im_id]['height']) for d in cls_dets]
+                        cls_dets = cls_dets[np.array(ok, bool)] if len(ok) else cls_dets
+                        all_boxes[j][im_id][chip_id] = cls_dets if cls_dets.shape[0] > 0 else np.zeros((0, 5))
+        return all_boxes, all_maps
+
+    def extract_proposals(self, n_proposals=300, cache_name='cache', vis=False, vis_ext='.png'):
+        all_boxes = [[] for _ in range(self.num_images)]
+        for batch in self.test_iter:
+            im_info = batch.data[1].asnumpy()
+            scales = im_info[:, 2].reshape(-1, self.batch_size)
+            scores, boxes, data, im_ids = self.get_proposals(batch, scales)
+            for cscores, cboxes, im_id in zip(scores, boxes, im_ids):
+                all_boxes[im_id] = np.hstack((cboxes[0:n_proposals, 0:4], cscores[0:n_proposals].reshape(-1, 1))).astype(np.float32)
+        return all_boxes
+
+
+def detect_scale_worker(arguments):
+    """One test scale: bind the test graph for that scale's batch shape and run the Tester (:411-436)."""
+    [scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis] = arguments
+    nGPUs = len(context)
+    sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
+    sym = sym_inst.get_symbol_rcnn(config, is_train=False)
+    test_iter = MNIteratorTestAutoFocus(roidb=roidb, config=config, batch_size=nGPUs * nbatch, nGPUs=nGPUs, threads=32,
+                                        pad_rois_to=400, crop_size=None, test_scale=scale)
+    mod = mx.mod.Module(symbol=sym, context=context, data_names=[k[0] for k in test_iter.provide_data_single], label_names=None)
+    mod.bind(test_iter.provide_data, test_iter.provide_label, for_training=False)
+    mod.init_params(arg_params=arg_params, aux_params=aux_params, allow_missing=arg_params is None)
+    tester = Tester(mod, imdb, roidb, test_iter, cfg=config, batch_size=nbatch)
+    return tester.get_detections(vis=False, evaluate=False, cache_name='dets_scale_{}x{}'.format(scale[0], scale[1]),
+                                 do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
+
+
+def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False):
+    """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
+    AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips); detections of all scales
+    are aggregated under TEST.VALID_RANGES with per-class NMS."""
+    for r in roidb:
+        r['inference_crops'] = np.array([[0, 0, r['width'], r['height']]])
+    detections = []
+    for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
+        dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis])
+        detections.append(dets)
+        # chips of the next scale from this scale's FocusPixel maps (:497-499)
+        if scale_i + 1 < len(config.TEST.SCALES) and config.TEST.DO_PRUNING[scale_i + 1]:
+            add_chips(roidb, maps, scale_i, config)
+    tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
+    return tester.aggregate(detections, vis=False, cache_name=None)

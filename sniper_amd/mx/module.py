@@ -103,9 +103,24 @@ class Module(object):
         dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', self.contexts[0].device_id)) if self.world > 1
                            else self.contexts[0].device_id)
         torch.cuda.set_device(dev)
-        self.exe = Executor(self.symbol, shapes, for_training=for_training, fixed_param_names=self.fixed_param_names,
-                            device=dev)
+        self._device = dev
+        self._exes = {}          # test-time batches change shape (scale, chip size): one bound executor per input shape
+        self.exe = self._exe_for(shapes)
         self.binded = True
+
+    def _exe_for(self, shapes):
+        from ..engine.executor import Executor
+        key = tuple(sorted((k, tuple(v)) for k, v in shapes.items()))
+        ex = self._exes.get(key)
+        if ex is None:
+            ex = Executor(self.symbol, dict(shapes), for_training=self.for_training, fixed_param_names=self.fixed_param_names,
+                          device=self._device)
+            if self._arg_params is not None:
+                ex.set_params(self._arg_params, self._aux_params)
+            if len(self._exes) >= 8 and not self.for_training:      # bound the activation memory of stale shapes
+                self._exes.pop(next(iter(self._exes)))
+            self._exes[key] = ex
+        return ex
 
     # ---- parameters
     def init_params(self, initializer=None, arg_params=None, aux_params=None, allow_missing=False, force_init=False,
@@ -129,7 +144,10 @@ class Module(object):
         for name, t in self.exe.aux.items():
             if name not in aux:
                 aux[name] = np.ones(tuple(t.shape), np.float32) if name.endswith('_var') else np.zeros(tuple(t.shape), np.float32)
-        self.exe.set_params(arg, aux)
+        self._arg_params = {k: (v.asnumpy() if hasattr(v, 'asnumpy') else np.asarray(v)) for k, v in arg.items()}
+        self._aux_params = {k: (v.asnumpy() if hasattr(v, 'asnumpy') else np.asarray(v)) for k, v in aux.items()}
+        for ex in self._exes.values():
+            ex.set_params(self._arg_params, self._aux_params)
         self.params_initialized = True
 
     def set_params(self, arg_params, aux_params, allow_missing=False, force_init=True, allow_extra=True):
@@ -177,7 +195,12 @@ class Module(object):
         return {k: v for k, v in feed.items() if k in self.exe.input_names}
 
     def forward(self, data_batch, is_train=None):
-        self.exe.forward(self._feed(data_batch), is_train=self.for_training if is_train is None else is_train)
+        feed = self._feed(data_batch)
+        if not self.for_training:
+            shapes = {k: tuple(v.shape) for k, v in feed.items()}
+            if any(tuple(self.exe.vals_shape(k)) != s for k, s in shapes.items()):
+                self.exe = self._exe_for(shapes)                       # rebind for this batch shape (MXNet reshapes too)
+        self.exe.forward(feed, is_train=self.for_training if is_train is None else is_train)
 
     def backward(self, out_grads=None):
         self.exe.backward()

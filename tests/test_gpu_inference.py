@@ -1,0 +1,159 @@
+"""-m gpu: the test-time path: GPU image preparation, test iterators, box decoding,
+Tester.detect / get_detections / aggregate with batched soft-NMS, FocusChip generation, on synthetic images."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import dev  # noqa: E402
+
+
+class _Imdb(object):
+    def __init__(self, n):
+        self.num_classes, self.classes, self.name, self.result_path = n, ['c%d' % i for i in range(n)], 'synthetic', None
+
+
+def _roidb(n, rs, sizes=((480, 640), (640, 480))):
+    out = []
+    for i in range(n):
+        h, w = sizes[i % len(sizes)] if i >= n // 2 else sizes[0]
+        out.append({'image': rs.randint(0, 256, (h, w, 3)).astype(np.uint8), 'width': w, 'height': h, 'flipped': False,
+                    'gt_overlaps': np.zeros((1, 81), np.float32)})
+    return out
+
+
+def _np_im_prepare(im, crop, scale, flip, means, out_hw):
+    """numpy statement of sn_im_prepare's documented arithmetic (half-pixel centres, float bilinear, rint)."""
+    if flip:
+        im = im[:, ::-1, :]
+    x1, y1, x2, y2 = crop
+    im = im[max(y1, 0):min(y2, im.shape[0]), max(x1, 0):min(x2, im.shape[1]), :].astype(np.float32)
+    ch, cw = im.shape[:2]
+    rh, rw = max(int(np.rint(np.float32(ch) * np.float32(scale))), 1), max(int(np.rint(np.float32(cw) * np.float32(scale))), 1)
+    inv = np.float32(1.0) / np.float32(scale)
+
+    def axis(n_out, n_in):
+        f = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * inv - np.float32(0.5)
+        s = np.floor(f).astype(int)
+        a = (f - s).astype(np.float32)
+        a[s < 0] = 0
+        s[s < 0] = 0
+        hi = s >= n_in - 1
+        s[hi] = max(n_in - 2, 0)
+        a[hi] = 1.0 if n_in > 1 else 0.0
+        return s, np.minimum(s + (1 if n_in > 1 else 0), n_in - 1), a
+    sy, sy1, ay = axis(rh, ch)
+    sx, sx1, ax = axis(rw, cw)
+    top = im[sy][:, sx] * (1 - ax)[None, :, None] + im[sy][:, sx1] * ax[None, :, None]
+    bot = im[sy1][:, sx] * (1 - ax)[None, :, None] + im[sy1][:, sx1] * ax[None, :, None]
+    res = np.rint(top * (1 - ay)[:, None, None] + bot * ay[:, None, None])
+    out = np.zeros((3, out_hw[0], out_hw[1]), np.float32)
+    h, w = min(rh, out_hw[0]), min(rw, out_hw[1])
+    for j in range(3):
+        out[j, :h, :w] = res[:h, :w, 2 - j] - means[2 - j]
+    return out, (rh, rw)
+
+
+def test_im_prepare_against_its_statement():
+    import ctypes
+    from sniper_amd import hip
+    rs = np.random.RandomState(0)
+    im = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    means = np.array([103.939, 116.779, 123.68], np.float32)
+    d = torch.from_numpy(im).to(dev())
+    for crop, scale, flip, out_hw in (((0, 0, 53, 37), 1.0, 0, (40, 56)), ((5, 3, 40, 30), 1.7, 0, (64, 64)),
+                                      ((0, 0, 53, 37), 0.5, 1, (19, 27)), ((10, 10, 11, 11), 3.0, 0, (8, 8)),
+                                      ((-4, -2, 60, 50), 2.25, 1, (90, 100))):
+        out = torch.full((3,) + out_hw, 9.0, dtype=torch.float32, device=dev())
+        hw = (ctypes.c_int32 * 2)()
+        hip.call('sn_im_prepare', d, 37, 53, crop[0], crop[1], crop[2], crop[3], scale, flip, means.ctypes.data_as(ctypes.c_void_p), out,
+                 out_hw[0], out_hw[1], hw, hip.stream())
+        want, (rh, rw) = _np_im_prepare(im, crop, scale, flip, means, out_hw)
+        assert (hw[0], hw[1]) == (rh, rw)
+        got = out.cpu().numpy()
+        # bilinear weights are float32 on both sides; an exact .5 before rint may round differently: allow 1 level on <0.1%
+        diff = np.abs(got - want)
+        assert diff.max() <= 1.0 and (diff > 0).mean() < 1e-3, (crop, scale, diff.max(), (diff > 0).mean())
+    # scale 1, no crop: exact copy with channel reversal and mean subtraction
+    out = torch.empty((3, 37, 53), dtype=torch.float32, device=dev())
+    hip.call('sn_im_prepare', d, 37, 53, 0, 0, 53, 37, 1.0, 0, means.ctypes.data_as(ctypes.c_void_p), out, 37, 53, None, hip.stream())
+    assert np.array_equal(out.cpu().numpy(), im[:, :, ::-1].transpose(2, 0, 1).astype(np.float32) - means[::-1, None, None])
+
+
+def test_bbox_decode_matches_numpy_bbox_pred():
+    """sn_bbox_decode == bbox_pred + clip_boxes + /scale of lib/inference.py:127-131, in float64 like numpy."""
+    from oracle import data_path
+    from sniper_amd import hip
+    rs = np.random.RandomState(1)
+    B, R = 3, 50
+    rois = np.zeros((B * R, 5), np.float32)
+    rois[:, 0] = np.repeat(np.arange(B), R)
+    c = rs.uniform(0, 500, (B * R, 2))
+    wh = rs.uniform(2, 300, (B * R, 2))
+    rois[:, 1:3], rois[:, 3:5] = c - wh / 2, c + wh / 2
+    deltas = (rs.standard_normal((B, R, 4)) * 0.5).astype(np.float32)
+    info = np.array([[480, 640, 1.5], [512, 512, 0.75], [300, 400, 2.0]], np.float32)
+    out = torch.empty((B, R, 4), dtype=torch.float64, device=dev())
+    td = lambda a: torch.from_numpy(a).to(dev())
+    hip.call('sn_bbox_decode', td(rois), td(deltas), td(info), out, B, R, hip.stream())
+    got = out.cpu().numpy()
+    for b in range(B):
+        want = data_path.bbox_pred(rois[b * R:(b + 1) * R, 1:], deltas[b])
+        want = data_path.clip_boxes(want, info[b, :2]) / info[b, 2]
+        assert np.array_equal(got[b], want) or np.allclose(got[b], want, rtol=0, atol=1e-9), np.abs(got[b] - want).max()
+
+
+def test_autofocus_pipeline_end_to_end():
+    """Coarse-to-fine inference on synthetic images with the R101 AutoFocus test graph at reduced scales: the three
+    iterators, Module re-binding per batch shape, Tester.detect on the device decode, FocusChips, multi-scale aggregation."""
+    import sniper_amd.mx as mx
+    from sniper_amd import config as cfgmod
+    from sniper_amd.inference import Tester, imdb_detection_wrapper, nms_worker
+    from sniper_amd.iterators.MNIteratorTest import MNIteratorTest
+    from sniper_amd.iterators.MNIteratorTestAutoFocus import MNIteratorTestAutoFocus
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+    rs = np.random.RandomState(3)
+    roidb = _roidb(4, rs, sizes=((240, 320),))
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.SCALES = ((120, 160), (240, 320))
+    cfg.TEST.BATCH_IMAGES = (2, 2)
+    cfg.TEST.VALID_RANGES = ((40, -1), (-1, 60))
+    cfg.TEST.DO_PRUNING = (False, True)
+    cfg.TEST.CHIP_HYPERPARAMS = ((3, 0.3, 4), (-1, -1, -1))
+    cfg.TEST.MAX_PER_IMAGE = 50
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 500, 100
+    # iterator contracts
+    it = MNIteratorTest(roidb, cfg, test_scale=(120, 160), batch_size=2, crop_size=None)
+    assert [k for k, _ in it.provide_data] == ['data', 'im_info', 'im_ids'] and dict(it.provide_data)['data'] == (2, 3, 120, 160)
+    b = it.next()
+    info = b.data[1].asnumpy()
+    assert np.allclose(info[:, 2], 0.5) and np.array_equal(info[:, :2], [[120, 160]] * 2)
+    for r in roidb:
+        r['inference_crops'] = np.array([[0, 0, r['width'], r['height']]])
+    it2 = MNIteratorTestAutoFocus(roidb, cfg, test_scale=(240, 320), batch_size=2, crop_size=None)
+    assert [k for k, _ in it2.provide_data] == ['data', 'im_info', 'im_ids', 'chip_ids'] and len(it2) == 4
+    # the whole coarse-to-fine wrapper with random weights (detections are noise; structure and invariants are checked)
+    net = rn.resnet_mx_101_e2e
+    all_boxes = imdb_detection_wrapper(net, cfg, _Imdb(81), roidb, [mx.gpu(0)], None, None)
+    assert len(all_boxes) == 81 and len(all_boxes[1]) == 4
+    for i in range(4):
+        n = sum(all_boxes[j][i].shape[0] for j in range(1, 81))
+        assert n <= 50 + 80                       # MAX_PER_IMAGE keeps ties at the threshold
+        for j in range(1, 81):
+            d = all_boxes[j][i]
+            assert d.shape[1] == 5 and np.isfinite(d).all()
+            if d.shape[0]:
+                assert d[:, 0].min() >= -1e-6 and d[:, 2].max() <= roidb[i]['width'] + 1e-3
+                assert (np.diff(d[:, 4]) <= 1e-7).all()            # soft-NMS emits rows by descending decayed score
+    for r in roidb:                                 # FocusChips of the second scale lie inside their image
+        c = np.asarray(r['inference_crops'], np.float64).reshape(-1, 4)
+        if c.shape[0]:
+            assert c[:, 0].min() >= 0 and c[:, 1].min() >= 0 and c[:, 2].max() <= r['width'] + 1e-6 and c[:, 3].max() <= r['height'] + 1e-6
+    # batched soft-NMS worker == one problem at a time
+    w = nms_worker(-1, 0.55)
+    probs = [np.hstack((rs.uniform(0, 50, (n, 2)), rs.uniform(60, 120, (n, 2)), rs.uniform(0.01, 1, (n, 1)))).astype(np.float32)
+             for n in (5, 40, 0, 17)]
+    many = w.worker_many([p.copy() for p in probs])
+    for p, m in zip(probs, many):
+        assert np.array_equal(m, w.worker(p.copy()))
