@@ -101,7 +101,9 @@ def test_bbox_decode_matches_numpy_bbox_pred():
     for b in range(B):
         want = data_path.bbox_pred(rois[b * R:(b + 1) * R, 1:], deltas[b])
         want = data_path.clip_boxes(want, info[b, :2]) / info[b, 2]
-        assert np.array_equal(got[b], want) or np.allclose(got[b], want, rtol=0, atol=1e-9), np.abs(got[b] - want).max()
+        # float64 arithmetic; np.exp on the float32 deltas is a float32 routine whose last bit is implementation defined
+        # (the device narrows a double exp): one float32 ulp of exp(dw) on a <= 2000-pixel box
+        assert np.allclose(got[b], want, rtol=1e-6, atol=1e-6), np.abs(got[b] - want).max()
 
 
 def test_autofocus_pipeline_end_to_end():
