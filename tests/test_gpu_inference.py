@@ -103,7 +103,7 @@ def test_bbox_decode_matches_numpy_bbox_pred():
         want = data_path.clip_boxes(want, info[b, :2]) / info[b, 2]
         # float64 arithmetic; np.exp on the float32 deltas is a float32 routine whose last bit is implementation defined
         # (the device narrows a double exp): one float32 ulp of exp(dw) on a <= 2000-pixel box
-        assert np.allclose(got[b], want, rtol=1e-6, atol=1e-6), np.abs(got[b] - want).max()
+        assert np.allclose(got[b], want, rtol=1e-6, atol=2e-4), np.abs(got[b] - want).max()
 
 
 def test_autofocus_pipeline_end_to_end():
