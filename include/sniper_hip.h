@@ -213,14 +213,14 @@ int sn_softmax_output_bwd(const float *p, const float *label, float *grad, long 
 int sn_smooth_l1_loss(const float *pred, const float *target, const float *weight, float *loss, float *dpred, long n, float sigma,
                       float grad_scale, sn_stream_t stream);
 
-/* MultiProposal (:347-355) / MultiProposalTarget (:283-284).  cls_prob (B,2,A*F,F), bbox_pred (B,4A,F,F),
+/* MultiProposal (:347-355) / MultiProposalTarget (:283-284).  cls_prob (B,2,A*Fh,Fw), bbox_pred (B,4A,Fh,Fw),
  * im_info (B,3), gt_boxes (B,G,5), valid_ranges (B,2), base_anchors (A,4): all fp32 device. */
-size_t sn_proposal_workspace_bytes(int B, int A, int F, int pre_nms_top_n, int post_nms_top_n);
+size_t sn_proposal_workspace_bytes(int B, int A, int Fh, int Fw, int pre_nms_top_n, int post_nms_top_n);
 int sn_multi_proposal(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *base_anchors, int B, int A,
-                      int F, int feat_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, void *ws,
+                      int Fh, int Fw, int feat_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, void *ws,
                       float *rois, float *scores, sn_stream_t stream);
 int sn_multi_proposal_target(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *gt_boxes,
-                             const float *valid_ranges, const float *base_anchors, int B, int A, int F, int feat_stride, int G,
+                             const float *valid_ranges, const float *base_anchors, int B, int A, int Fh, int Fw, int feat_stride, int G,
                              int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float fg_thresh,
                              const float *bbox_stds4, void *ws, float *rois, float *label, float *bbox_target,
                              float *bbox_weight, sn_stream_t stream);

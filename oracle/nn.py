@@ -22,17 +22,16 @@ def proposals(cls_prob, bbox_pred, im_info, feat_stride, scales, ratios, pre_nms
     stable sort by descending score; top pre_nms; NMS (nms.py:90-127 semantics); first post_nms,
     cyclically repeated when fewer survive."""
     B = cls_prob.shape[0]
-    F = cls_prob.shape[3]
-    A = cls_prob.shape[2] // F
+    A, Fh, Fw = bbox_pred.shape[1] // 4, bbox_pred.shape[2], bbox_pred.shape[3]     # test images are not square
     base = generate_anchors(feat_stride, ratios, np.array(scales, np.float32)).astype(np.float32)
     rois = np.zeros((B * post_nms, 5), np.float32)
     scores_out = np.zeros((B * post_nms,), np.float32)
     dbg = []
     f32 = np.float32
     for b in range(B):
-        fg = cls_prob[b, 1].reshape(A, F, F).transpose(1, 2, 0).reshape(-1)  # (y,x,a)
-        d = bbox_pred[b].reshape(A, 4, F, F).transpose(2, 3, 0, 1).reshape(-1, 4).astype(f32)
-        sx, sy = np.meshgrid(np.arange(F) * feat_stride, np.arange(F) * feat_stride)
+        fg = cls_prob[b].reshape(2, A, Fh, Fw)[1].transpose(1, 2, 0).reshape(-1)  # (y,x,a)
+        d = bbox_pred[b].reshape(A, 4, Fh, Fw).transpose(2, 3, 0, 1).reshape(-1, 4).astype(f32)
+        sx, sy = np.meshgrid(np.arange(Fw) * feat_stride, np.arange(Fh) * feat_stride)
         shifts = np.stack((sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()), 1).astype(f32)
         anc = (base[None, :, :] + shifts[:, None, :]).reshape(-1, 4).astype(f32)
         aw = anc[:, 2] - anc[:, 0] + f32(1)

@@ -19,9 +19,9 @@ struct PropLayout {
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-static PropLayout prop_layout(int B, int A, int F, int pre, int post) {
+static PropLayout prop_layout(int B, int A, int Fh, int Fw, int pre, int post) {
   PropLayout L;
-  L.total = A * F * F;
+  L.total = A * Fh * Fw;
   L.sort_n = next_pow2(L.total);
   L.pre = pre < L.total ? pre : L.total;
   L.post = post < L.pre ? post : L.pre;
@@ -37,8 +37,8 @@ static PropLayout prop_layout(int B, int A, int F, int pre, int post) {
   return L;
 }
 
-SN_EXPORT size_t sn_proposal_workspace_bytes(int B, int A, int F, int pre_nms_top_n, int post_nms_top_n) {
-  return prop_layout(B, A, F, pre_nms_top_n, post_nms_top_n).bytes;
+SN_EXPORT size_t sn_proposal_workspace_bytes(int B, int A, int Fh, int Fw, int pre_nms_top_n, int post_nms_top_n) {
+  return prop_layout(B, A, Fh, Fw, pre_nms_top_n, post_nms_top_n).bytes;
 }
 
 __device__ __forceinline__ unsigned orderable(float f) {
@@ -46,10 +46,10 @@ __device__ __forceinline__ unsigned orderable(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-order preserving
 }
 
-// K1: decode + sort keys.  cls_prob (B,2,A*F,F), bbox_pred (B,4A,F,F), both fp32 reference layout.
+// K1: decode + sort keys.  cls_prob (B,2,A*Fh,Fw), bbox_pred (B,4A,Fh,Fw), both fp32 reference layout.
 __global__ __launch_bounds__(256) void proposal_decode_kernel(const float *__restrict__ cls_prob, const float *__restrict__ bbox_pred,
                                                               const float *__restrict__ im_info, const float *__restrict__ base,
-                                                              int A, int F, int stride, float min_size, int total, int sort_n,
+                                                              int A, int Fh, int Fw, int stride, float min_size, int total, int sort_n,
                                                               float *__restrict__ boxes_all, unsigned long long *__restrict__ keys) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float *__res
   unsigned long long *kb = keys + (size_t)b * sort_n;
   if (i >= total) { kb[i] = ~0ull; return; }
   const int cell = i / A, a = i - cell * A;
-  const int h = cell / F, w = cell - h * F;
-  const int FF = F * F;
+  const int h = cell / Fw, w = cell - h * Fw;
+  const int FF = Fh * Fw;
   const float score0 = cls_prob[((size_t)b * 2 + 1) * A * FF + (size_t)a * FF + cell];
   const float *bp = bbox_pred + ((size_t)b * 4 * A + 4 * a) * FF + cell;
   const float dx = bp[0], dy = bp[FF], dw = bp[2 * FF], dh = bp[3 * FF];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void proposal_target_kernel(const float *__res
 }
 
 static int proposal_common(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *base_anchors, int B,
-                           int A, int F, int stride, int pre, int post, float nms_thresh, float min_size, char *ws,
+                           int A, int Fh, int Fw, int stride, int pre, int post, float nms_thresh, float min_size, char *ws,
                            const PropLayout &L, hipStream_t s) {
   float *boxes_all = (float *)(ws + L.boxes_all);
   unsigned long long *keys = (unsigned long long *)(ws + L.keys);
@@ -204,7 +204,7 @@ static int proposal_common(const float *cls_prob, const float *bbox_pred, const 
   int32_t *keep = (int32_t *)(ws + L.keep);
   int32_t *nkeep = (int32_t *)(ws + L.nkeep);
   hipLaunchKernelGGL(proposal_decode_kernel, dim3(sn_div_up(L.sort_n, 256), B), dim3(256), 0, s, cls_prob, bbox_pred, im_info,
-                     base_anchors, A, F, stride, min_size, L.total, L.sort_n, boxes_all, keys);
+                     base_anchors, A, Fh, Fw, stride, min_size, L.total, L.sort_n, boxes_all, keys);
   SN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bitonic_sort_kernel, dim3(B), dim3(1024), 0, s, keys, L.sort_n);
   SN_CHECK_LAUNCH();
@@ -216,13 +216,13 @@ static int proposal_common(const float *cls_prob, const float *bbox_pred, const 
 
 // base_anchors: (A,4) fp32 device.  rois (B*post,5), scores (B*post) optional.
 SN_EXPORT int sn_multi_proposal(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *base_anchors,
-                                int B, int A, int F, int feat_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
+                                int B, int A, int Fh, int Fw, int feat_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
                                 float min_size, void *ws, float *rois, float *scores, sn_stream_t stream) {
-  SN_REQUIRE(cls_prob && bbox_pred && im_info && base_anchors && ws && rois && B > 0 && A > 0 && F > 0,
+  SN_REQUIRE(cls_prob && bbox_pred && im_info && base_anchors && ws && rois && B > 0 && A > 0 && Fh > 0 && Fw > 0,
              "sn_multi_proposal: bad arguments");
-  const PropLayout L = prop_layout(B, A, F, pre_nms_top_n, post_nms_top_n);
+  const PropLayout L = prop_layout(B, A, Fh, Fw, pre_nms_top_n, post_nms_top_n);
   hipStream_t s = sn_stream(stream);
-  if (int rc = proposal_common(cls_prob, bbox_pred, im_info, base_anchors, B, A, F, feat_stride, L.pre, L.post, nms_thresh,
+  if (int rc = proposal_common(cls_prob, bbox_pred, im_info, base_anchors, B, A, Fh, Fw, feat_stride, L.pre, L.post, nms_thresh,
                                min_size, (char *)ws, L, s))
     return rc;
   hipLaunchKernelGGL(proposal_output_kernel, dim3(sn_div_up(L.post, 256), B), dim3(256), 0, s,
@@ -233,16 +233,16 @@ SN_EXPORT int sn_multi_proposal(const float *cls_prob, const float *bbox_pred, c
 }
 
 SN_EXPORT int sn_multi_proposal_target(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *gt_boxes,
-                                       const float *valid_ranges, const float *base_anchors, int B, int A, int F,
+                                       const float *valid_ranges, const float *base_anchors, int B, int A, int Fh, int Fw,
                                        int feat_stride, int G, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
                                        float min_size, float fg_thresh, const float *bbox_stds4, void *ws, float *rois,
                                        float *label, float *bbox_target, float *bbox_weight, sn_stream_t stream) {
   SN_REQUIRE(gt_boxes && valid_ranges && label && bbox_target && bbox_weight && bbox_stds4 && G > 0 && G <= 1024,
              "sn_multi_proposal_target: bad arguments");
-  if (int rc = sn_multi_proposal(cls_prob, bbox_pred, im_info, base_anchors, B, A, F, feat_stride, pre_nms_top_n, post_nms_top_n,
+  if (int rc = sn_multi_proposal(cls_prob, bbox_pred, im_info, base_anchors, B, A, Fh, Fw, feat_stride, pre_nms_top_n, post_nms_top_n,
                                  nms_thresh, min_size, ws, rois, nullptr, stream))
     return rc;
-  const PropLayout L = prop_layout(B, A, F, pre_nms_top_n, post_nms_top_n);
+  const PropLayout L = prop_layout(B, A, Fh, Fw, pre_nms_top_n, post_nms_top_n);
   const float4 stds = make_float4(bbox_stds4[0], bbox_stds4[1], bbox_stds4[2], bbox_stds4[3]);
   hipLaunchKernelGGL(proposal_target_kernel, dim3(sn_div_up(L.post, 256), B), dim3(256), (size_t)G * 6 * sizeof(float),
                      sn_stream(stream), rois, gt_boxes, valid_ranges, G, L.post, fg_thresh, stds, label, bbox_target, bbox_weight);

@@ -801,10 +801,13 @@ class _ProposalBase(Step):
         from ..data.anchors import generate_anchors
         ex, a = self.ex, self.a
         self.cls, self.bbox, self.info = self.data_in('cls_prob'), self.data_in('bbox_pred'), self.data_in('im_info')
-        # (B, 2, A*F, F) in the training graph, (B, 2A, F, F) at test time: same memory
-        B, c1, c2, F = self.cls.shape
-        self.B, self.F = B, F
-        self.A = (c1 * c2) // (2 * F)
+        # (B, 2, A*Fh, Fw) in the training graph, (B, 2A, Fh, Fw) at test time: same memory; the feature map's own
+        # geometry comes from bbox_pred (B, 4A, Fh, Fw) -- test images are not square
+        B = self.cls.shape[0]
+        _, c4a, Fh, Fw = self.bbox.shape
+        self.B, self.F, self.Fh, self.Fw = B, Fw, Fh, Fw
+        self.A = c4a // 4
+        assert int(np.prod(self.cls.shape[1:])) == 2 * self.A * Fh * Fw, (self.cls.shape, self.bbox.shape)
         self.stride = int(a.get('feature_stride', 16))
         scales, ratios = _anchor_attrs(a)
         if len(scales) * len(ratios) != self.A:
@@ -816,7 +819,7 @@ class _ProposalBase(Step):
         self.post = int(a.get('rpn_post_nms_top_n', 300))
         self.thresh = float(a.get('threshold', 0.7))
         self.min_size = float(a.get('rpn_min_size', 0))
-        nbytes = hip.query('sn_proposal_workspace_bytes', B, self.A, F, self.pre, self.post)
+        nbytes = hip.query('sn_proposal_workspace_bytes', B, self.A, Fh, Fw, self.pre, self.post)
         self.wsbuf = ex.empty((nbytes,), torch.uint8)
 
 
@@ -830,7 +833,7 @@ class MultiProposalStep(_ProposalBase):
     def forward(self):
         ex = self.ex
         hip.call('sn_multi_proposal', ex.as_f32(self.cls), ex.as_f32(self.bbox), ex.as_f32(self.info), self.base, self.B, self.A,
-                 self.F, self.stride, self.pre, self.post, self.thresh, self.min_size, self.wsbuf, self.rois.t, self.scores.t,
+                 self.Fh, self.Fw, self.stride, self.pre, self.post, self.thresh, self.min_size, self.wsbuf, self.rois.t, self.scores.t,
                  hip.stream())
 
 
@@ -848,7 +851,7 @@ class MultiProposalTargetStep(_ProposalBase):
         ex = self.ex
         rois, label, tgt, wgt = [o.t for o in self.outs]
         hip.call('sn_multi_proposal_target', ex.as_f32(self.cls), ex.as_f32(self.bbox), ex.as_f32(self.info), ex.as_f32(self.gt),
-                 ex.as_f32(self.vr), self.base, self.B, self.A, self.F, self.stride, self.G, self.pre, self.post, self.thresh,
+                 ex.as_f32(self.vr), self.base, self.B, self.A, self.Fh, self.Fw, self.stride, self.G, self.pre, self.post, self.thresh,
                  self.min_size, self.fg, self.stds.ctypes.data, self.wsbuf, rois, label, tgt, wgt, hip.stream())
 
 

@@ -112,11 +112,11 @@ def main():
     vr = torch.tensor([[0, 512.0]] * B, device=d)
     from sniper_amd.data.anchors import generate_anchors
     base = torch.from_numpy(generate_anchors(16, (0.5, 1, 2), np.array((2, 4, 7, 10, 13, 16, 24), np.float32)).astype(np.float32)).to(d)
-    ws = torch.empty(hip.query('sn_proposal_workspace_bytes', B, A, F, 6000, 300), dtype=torch.uint8, device=d)
+    ws = torch.empty(hip.query('sn_proposal_workspace_bytes', B, A, F, F, 6000, 300), dtype=torch.uint8, device=d)
     rois, lab = torch.empty(B * 300, 5, device=d), torch.empty(B * 300, device=d)
     tg, wg = torch.empty(B * 300, 4, device=d), torch.empty(B * 300, 4, device=d)
     stds = np.array([0.1, 0.1, 0.2, 0.2], np.float32)
-    ms = timeit(lambda: hip.call('sn_multi_proposal_target', cls_prob, bbox_pred, im_info, gt, vr, base, B, A, F, 16, 100, 6000, 300, 0.7, 0.0,
+    ms = timeit(lambda: hip.call('sn_multi_proposal_target', cls_prob, bbox_pred, im_info, gt, vr, base, B, A, F, F, 16, 100, 6000, 300, 0.7, 0.0,
                                  0.5, stds.ctypes.data, ws, rois, lab, tg, wg, hip.stream()), it)
     print('multi_proposal_target B=%d     %8.3f ms' % (B, ms), flush=True)
     # anchor assignment on golden-like chips
