@@ -140,8 +140,10 @@ def test_autofocus_pipeline_end_to_end():
     all_boxes = imdb_detection_wrapper(net, cfg, _Imdb(81), roidb, [mx.gpu(0)], None, None)
     assert len(all_boxes) == 81 and len(all_boxes[1]) == 4
     for i in range(4):
-        n = sum(all_boxes[j][i].shape[0] for j in range(1, 81))
-        assert n <= 50 + 80                       # MAX_PER_IMAGE keeps ties at the threshold
+        sc = np.sort(np.hstack([all_boxes[j][i][:, 4] for j in range(1, 81)]))[::-1]
+        # MAX_PER_IMAGE (:203-209): everything kept scores at least the 50th best (ties at that score all stay --
+        # random weights make nearly every score tie)
+        assert len(sc) <= 50 or sc[-1] >= sc[49]
         for j in range(1, 81):
             d = all_boxes[j][i]
             assert d.shape[1] == 5 and np.isfinite(d).all()
