@@ -210,9 +210,8 @@ class Module(object):
         self.exe.forward_backward(self._feed(data_batch))
 
     def update(self):
-        dist = _dist()
-        if dist is not None:
-            dist.all_reduce(self.exe.grad_arena())  # sum over ranks == kvstore 'device' push/pull
+        from ..parallel import allreduce_gradients
+        allreduce_gradients(self.exe.grad_arena(), _dist())   # sum over ranks == kvstore 'device' push/pull
         sched = self.opt['lr_scheduler']
         lr = sched(self.exe.num_update + 1) if sched is not None else self.opt['lr']
         self.exe.update(lr, self.opt['wd'], self.opt['momentum'], self.opt['rescale_grad'])

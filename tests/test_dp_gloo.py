@@ -1,0 +1,64 @@
+"""CPU, world_size 2 over gloo: the data-parallel pieces -- rendezvous from the torchrun environment, rank slicing of a
+global batch, the bucketed gradient-arena all-reduce (sum, in place), and bench.py's max-over-ranks timing reduction.
+The kernels need a GPU; what is exercised here is everything that differs between N = 1 and N > 1."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world_size, port, out):
+    os.environ.update(WORLD_SIZE=str(world_size), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from sniper_amd import parallel
+    dist = parallel.init(backend='gloo')
+    assert dist is not None and dist.get_world_size() == world_size and parallel.world() == (world_size, rank, rank)
+    # every rank owns an independent chip minibatch: its gradients differ
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    n_coll = parallel.allreduce_gradients(g, dist, bucket_bytes=1024)          # 256 floats per bucket -> 4 collectives
+    want = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world_size))
+    ok_sum = bool(torch.equal(g, want)) and n_coll == 4
+    # a global batch is split rank-major
+    batch = np.arange(8 * 3).reshape(8, 3)
+    mine = parallel.rank_slice(batch, rank, world_size)
+    ok_slice = mine.shape == (4, 3) and mine[0, 0] == rank * 12
+    # bench.py's reduction: the job time is the slowest rank's
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok_time = abs(float(t) - 0.1 * world_size) < 1e-12
+    # Module's view of the shapes: per-rank batch = global / world
+    import sniper_amd.mx as mx
+    m = mx.mod.Module(mx.sym.Variable('x'), data_names=['x'], label_names=None)
+    ok_local = m.world == world_size and m._local((8, 3, 4, 4)) == (4, 3, 4, 4)
+    dist.barrier()
+    out[rank] = int(ok_sum) + 2 * int(ok_slice) + 4 * int(ok_time) + 8 * int(ok_local)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_gloo():
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, 'rank exited with %s' % p.exitcode
+    assert dict(out) == {0: 15, 1: 15}, dict(out)
+
+
+def test_single_process_is_a_no_op():
+    from sniper_amd import parallel
+    g = torch.ones(10)
+    assert parallel.allreduce_gradients(g, None) == 0 and torch.equal(g, torch.ones(10))
