@@ -131,6 +131,12 @@ class Executor(object):
         self.use_graphs = (for_training and os.environ.get('SNIPER_HIP_GRAPHS', '1') != '0' and
                            not any(type(st).__name__ == 'CustomStep' for st in self.steps))
         self.graph_warmup = 2
+        # Weight gradients run on a second HIP stream, concurrently with the data-gradient chain: both consume the same
+        # dY, the weight gradient is needed only by the optimizer, and most R101 layers have too few tiles to fill 256
+        # CUs on their own (a 3x3 256->256 weight gradient is 36 tiles before K-splitting).
+        self.side_stream = None
+        self.use_side_stream = for_training and os.environ.get('SNIPER_WGRAD_STREAM', '1') != '0' and self.device.type == 'cuda'
+        self._keepalive = []
         self._graph_fb = self._graph_up = None
         self._eager_fb = self._eager_up = 0
 
@@ -443,14 +449,38 @@ class Executor(object):
     def zero_grad(self):
         self.arena_grad.zero_()
 
+    def on_side(self, fn, keep=()):
+        """Run fn() (kernel launches through hip.call) on the side stream, ordered after everything enqueued so far on
+        the main stream.  `keep`: tensors fn reads that the caller is about to drop -- they are held until the join at
+        the end of backward so that the caching allocator cannot hand their memory to a main-stream kernel meanwhile."""
+        if not self.use_side_stream:
+            fn()
+            return
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side_stream.wait_event(ev)
+        self._keepalive.extend(keep)
+        with torch.cuda.stream(self.side_stream):
+            fn()
+        self._side_used = True
+
     def backward(self):
         self.zero_grad()
+        self._side_used = False
         for v in self.vals.values():
             v.grad = None
         for s in reversed(self.steps):
             s.backward()
         for v in self.vals.values():
             v.grad = None
+        if self._side_used:                       # join: the optimizer / all-reduce read the gradient arena
+            ev = torch.cuda.Event()
+            ev.record(self.side_stream)
+            torch.cuda.current_stream().wait_event(ev)
+        self._keepalive = []
 
     def _capture(self, fn, what):
         """Capture fn() into a hipGraph; on failure fall back to eager execution for good."""

@@ -317,10 +317,13 @@ class _GemmLike(Step):
             return
         dy, Op = self.dy_act()
         x = self.x_tensor()
-        if self.w.trainable:
-            self.launch_wgrad(dy, Op, x)
-        if self.b is not None and self.b.trainable:
-            hip.call('sn_bias_grad', dy, self.b.grad, self.N * self.Ho * self.Wo, self.O, Op, 0, hip.stream())
+        def param_grads():
+            if self.w.trainable:
+                self.launch_wgrad(dy, Op, x)
+            if self.b is not None and self.b.trainable:
+                hip.call('sn_bias_grad', dy, self.b.grad, self.N * self.Ho * self.Wo, self.O, Op, 0, hip.stream())
+        if self.w.trainable or (self.b is not None and self.b.trainable):
+            ex.on_side(param_grads, keep=(dy, x))
         if self.x.needs_grad:
             if self.x.fmt == 'act':
                 dx, acc = ex.grad_slot(self.x)
@@ -486,10 +489,13 @@ class DeformableConvolutionStep(Step):
         M, K = self.col.shape
         Op = _pad8(self.O)
         assert Op == self.O
-        if self.w.trainable:
-            _wgrad(ex, dy, self.col, self.w.grad, M, 1, 1, K, K, self.O, Op, 1, 1, 1, 0, 1)
-        if self.b is not None and self.b.trainable:
-            hip.call('sn_bias_grad', dy, self.b.grad, M, self.O, Op, 0, hip.stream())
+        def param_grads():
+            if self.w.trainable:
+                _wgrad(ex, dy, self.col, self.w.grad, M, 1, 1, K, K, self.O, Op, 1, 1, 1, 0, 1)
+            if self.b is not None and self.b.trainable:
+                hip.call('sn_bias_grad', dy, self.b.grad, M, self.O, Op, 0, hip.stream())
+        if self.w.trainable or (self.b is not None and self.b.trainable):
+            ex.on_side(param_grads, keep=(dy,))
         if self.x.needs_grad or self.off.needs_grad:
             dcol = ex.empty((M, K), F16)
             hip.call('sn_conv_dgrad', dy, self.wT_flat, None, dcol, M, 1, 1, K, K, Op, Op, K, 1, 1, 1, 0, 1, 0, hip.stream())
