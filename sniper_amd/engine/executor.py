@@ -487,7 +487,8 @@ class Executor(object):
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: the RCCL watchdog thread of a multi-GPU job may query events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 fn()
             return g
         except Exception as e:   # noqa: BLE001 -- any capture failure means "run eagerly", never "stop training"
