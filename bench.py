@@ -151,6 +151,37 @@ def _cpu_image_chips(i):
     return len(crops)
 
 
+def bench_inference(passes=2):
+    """BASELINE config C5: ResNet-101 AutoFocus inference, 3-scale coarse-to-fine FocusChip pyramid
+    ((480,512) -> (800,1280) -> (1400,2000), batches of 8 / 8 / 2), 8 synthetic 640x480 images, random-init weights.
+    One pass = GPU image preparation + forward + box decoding + FocusChips + multi-scale soft-NMS aggregation.
+    Throughput of the last pass (bound executors cached per batch shape, like a resident service)."""
+    import sniper_amd.mx as mx
+    from sniper_amd import config as cfgmod
+    from sniper_amd.inference import imdb_detection_wrapper
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+
+    class Imdb(object):
+        num_classes, classes, name, result_path = 81, None, 'synthetic', None
+    rs = np.random.RandomState(0)
+    base = [{'image': rs.randint(0, 256, (480, 640, 3)).astype(np.uint8), 'width': 640, 'height': 480, 'flipped': False,
+             'gt_overlaps': np.zeros((1, 81), np.float32)} for _ in range(8)]
+    cfg = cfgmod.res101_e2e_autofocus()
+    cache, dt, n_chips = {}, None, None
+    for _ in range(passes):
+        roidb = [dict(r) for r in base]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_chips = [int(np.asarray(r['inference_crops']).reshape(-1, 4).shape[0]) for r in roidb]
+    return {'metric': 'inf images/sec', 'value': round(len(base) / dt, 2), 'unit': 'images/s', 'seconds_per_pass': round(dt, 3),
+            'images': len(base), 'config': 'ResNet-101 AutoFocus inference, 3-scale FocusChip pyramid, batch 8 images (BASELINE '
+            'configs[4]); synthetic 640x480 images, random-init weights (FocusPixel maps of an untrained net select most of '
+            'every image: finest-scale chips per image %s)' % n_chips}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -158,6 +189,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=20, help='chips per GPU (BASELINE C2: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--inference', action='store_true', help='also measure BASELINE config C5 (inf images/sec) on rank 0')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -252,6 +284,8 @@ def main():
                        'chips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if args.inference and world == 1:
+            out['inference'] = bench_inference()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

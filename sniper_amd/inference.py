@@ -266,23 +266,30 @@ class Tester(object):
         return all_boxes
 
 
-def detect_scale_worker(arguments):
-    """One test scale: bind the test graph for that scale's batch shape and run the Tester (:411-436)."""
+def detect_scale_worker(arguments, module_cache=None):
+    """One test scale: bind the test graph for that scale's batch shape and run the Tester (:411-436).
+    module_cache (dict, optional): keeps the bound Module of each scale across calls (its executors are cached per
+    batch shape), which is what a long-running inference service -- and the throughput benchmark -- wants; the
+    reference rebuilds the Module per call."""
     [scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis] = arguments
     nGPUs = len(context)
-    sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
-    sym = sym_inst.get_symbol_rcnn(config, is_train=False)
     test_iter = MNIteratorTestAutoFocus(roidb=roidb, config=config, batch_size=nGPUs * nbatch, nGPUs=nGPUs, threads=32,
                                         pad_rois_to=400, crop_size=None, test_scale=scale)
-    mod = mx.mod.Module(symbol=sym, context=context, data_names=[k[0] for k in test_iter.provide_data_single], label_names=None)
-    mod.bind(test_iter.provide_data, test_iter.provide_label, for_training=False)
-    mod.init_params(arg_params=arg_params, aux_params=aux_params, allow_missing=arg_params is None)
+    mod = module_cache.get((tuple(scale), nbatch)) if module_cache is not None else None
+    if mod is None:
+        sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
+        sym = sym_inst.get_symbol_rcnn(config, is_train=False)
+        mod = mx.mod.Module(symbol=sym, context=context, data_names=[k[0] for k in test_iter.provide_data_single], label_names=None)
+        mod.bind(test_iter.provide_data, test_iter.provide_label, for_training=False)
+        mod.init_params(arg_params=arg_params, aux_params=aux_params, allow_missing=arg_params is None)
+        if module_cache is not None:
+            module_cache[(tuple(scale), nbatch)] = mod
     tester = Tester(mod, imdb, roidb, test_iter, cfg=config, batch_size=nbatch)
     return tester.get_detections(vis=False, evaluate=False, cache_name='dets_scale_{}x{}'.format(scale[0], scale[1]),
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
-def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False):
+def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None):
     """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
     AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips); detections of all scales
     are aggregated under TEST.VALID_RANGES with per-class NMS."""
@@ -290,7 +297,8 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
         r['inference_crops'] = np.array([[0, 0, r['width'], r['height']]])
     detections = []
     for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
-        dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis])
+        dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis],
+                                         module_cache)
         detections.append(dets)
         # chips of the next scale from this scale's FocusPixel maps (:497-499)
         if scale_i + 1 < len(config.TEST.SCALES) and config.TEST.DO_PRUNING[scale_i + 1]:

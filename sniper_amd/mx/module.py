@@ -197,10 +197,27 @@ class Module(object):
     def forward(self, data_batch, is_train=None):
         feed = self._feed(data_batch)
         if not self.for_training:
+            feed = {k: self._bucket(v) for k, v in feed.items()}
             shapes = {k: tuple(v.shape) for k, v in feed.items()}
             if any(tuple(self.exe.vals_shape(k)) != s for k, s in shapes.items()):
                 self.exe = self._exe_for(shapes)                       # rebind for this batch shape (MXNet reshapes too)
         self.exe.forward(feed, is_train=self.for_training if is_train is None else is_train)
+
+    @staticmethod
+    def _bucket(a, q=64):
+        """Test-time image batches are zero padded to the batch maximum anyway (MNIteratorTestAutoFocus._get_batch);
+        padding H, W further up to a multiple of 64 keeps the number of distinct bound shapes small.  im_info carries
+        the true sizes, so decoding and clipping are unaffected."""
+        t = a._data if hasattr(a, '_data') else a
+        if not (isinstance(t, torch.Tensor) and t.dim() == 4):
+            return a
+        H, W = int(t.shape[2]), int(t.shape[3])
+        Hb, Wb = -(-H // q) * q, -(-W // q) * q
+        if (Hb, Wb) == (H, W):
+            return a
+        out = torch.zeros((t.shape[0], t.shape[1], Hb, Wb), dtype=t.dtype, device=t.device)
+        out[:, :, :H, :W] = t
+        return nd.NDArray(out)
 
     def backward(self, out_grads=None):
         self.exe.backward()
