@@ -92,6 +92,12 @@ int sn_anchor_assign(const float *d_gt, const float *d_gt_cls, const uint8_t *d_
                      const uint32_t *d_keys, uint64_t seed, void *d_ws, float *d_label, float *d_bbox_target,
                      float *d_bbox_weight, float *d_gt_out, int32_t *d_counts, int8_t *d_label_pre, sn_stream_t stream);
 
+/* AutoFocus FocusPixel labels (gen_mask, lib/data_utils/data_workers.py:165-192) for the same chip batch: d_mask (B, F*F) f32
+ * in {1, -1, 0} = small object / don't care / background; thresholds TRAIN.AUTO_FOCUS_DC_LOW, _SMALL_THRESH, _DC_HIGH. */
+int sn_focus_mask(const float *d_gt, const int32_t *d_ngt, const double *d_crop, const float *d_scale, int B, int G, int F,
+                  int feat_stride, int im_h, int im_w, float dc_low, float small_thresh, float dc_high, float *d_mask,
+                  sn_stream_t stream);
+
 /* ------------------------------------------------------------------ NMS ----------------------- */
 /* Bitmask hard NMS (lib/nms/nms_kernel.cu:34-78 mask, :118-140 scan; IoU > thresh suppresses),
  * batched: d_boxes (B, N, dim) f32 sorted by descending score, rows >= d_n[b] ignored (d_n may be

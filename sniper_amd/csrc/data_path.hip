@@ -658,3 +658,64 @@ SN_EXPORT int sn_anchor_assign(const float *d_gt, const float *d_gt_cls, const u
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
+
+
+// ============================================================================================
+// AutoFocus FocusPixel labels: gen_mask (lib/data_utils/data_workers.py:165-192) for B chips.
+// Per chip the GT boxes get the same preparation as anchor_prep_kernel (:203-217: shift by the crop origin in
+// double, round(gt * scale) in float32, clip); every box -- the < 10 px ones included, gen_mask runs before
+// filter_boxes -- then paints the feature cells [int(x1/s), min(int(ceil(x2/s)) + 1, F)) x (same in y) with
+//   +1  dc_low < sqrt(w*h) < small        -1  small <= sqrt(w*h) < dc_high  or  sqrt(w*h) <= dc_low        (else nothing)
+// in box order, later boxes overwriting earlier ones.  One thread per cell walks the boxes in order and keeps the
+// last one that paints it: same result, no write races.
+// ============================================================================================
+__global__ __launch_bounds__(256) void focus_mask_kernel(const float *__restrict__ gt, const int32_t *__restrict__ ngt,
+                                                         const double *__restrict__ crop, const float *__restrict__ scale, int G,
+                                                         int F, int feat_stride, int im_h, int im_w, float dc_low, float small,
+                                                         float dc_high, float *__restrict__ out) {
+  __shared__ int sx1[kAnchorMaxG], sy1[kAnchorMaxG], sx2[kAnchorMaxG], sy2[kAnchorMaxG];
+  __shared__ signed char sflag[kAnchorMaxG];
+  const int b = blockIdx.x;
+  const int n = min(ngt[b], G);
+  for (int g = threadIdx.x; g < n; g += blockDim.x) {
+    const float *p = gt + ((size_t)b * G + g) * 4;
+    const double cx = crop[2 * b], cy = crop[2 * b + 1];
+    const float s = scale[b];
+    float x1 = (float)((double)p[0] - cx), y1 = (float)((double)p[1] - cy);
+    float x2 = (float)((double)p[2] - cx), y2 = (float)((double)p[3] - cy);
+    x1 = rintf(x1 * s); y1 = rintf(y1 * s); x2 = rintf(x2 * s); y2 = rintf(y2 * s);
+    const float wm = (float)(im_w - 1), hm = (float)(im_h - 1);
+    x1 = fmaxf(fminf(x1, wm), 0.f); y1 = fmaxf(fminf(y1, hm), 0.f);
+    x2 = fmaxf(fminf(x2, wm), 0.f); y2 = fmaxf(fminf(y2, hm), 0.f);
+    const float area = sqrtf((x2 - x1) * (y2 - y1));
+    int flag = 0;
+    if (area > dc_low && area < small) flag = 1;
+    else if (area >= small && area < dc_high) flag = -1;
+    else if (area <= dc_low) flag = -1;
+    const float fs = (float)feat_stride;
+    sx1[g] = (int)(x1 / fs);
+    sy1[g] = (int)(y1 / fs);
+    sx2[g] = min((int)ceilf(x2 / fs) + 1, F);
+    sy2[g] = min((int)ceilf(y2 / fs) + 1, F);
+    sflag[g] = (signed char)flag;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < F * F; c += blockDim.x) {
+    const int y = c / F, x = c - y * F;
+    float v = 0.f;
+    for (int g = 0; g < n; ++g)
+      if (sflag[g] != 0 && x >= sx1[g] && x < sx2[g] && y >= sy1[g] && y < sy2[g]) v = (float)sflag[g];
+    out[(size_t)b * F * F + c] = v;
+  }
+}
+
+SN_EXPORT int sn_focus_mask(const float *d_gt, const int32_t *d_ngt, const double *d_crop, const float *d_scale, int B, int G, int F,
+                            int feat_stride, int im_h, int im_w, float dc_low, float small_thresh, float dc_high, float *d_mask,
+                            sn_stream_t stream) {
+  SN_REQUIRE(d_gt && d_ngt && d_crop && d_scale && d_mask && B > 0 && G > 0 && G <= kAnchorMaxG && F > 0 && feat_stride > 0,
+             "sn_focus_mask: bad arguments (G <= %d)", kAnchorMaxG);
+  hipLaunchKernelGGL(focus_mask_kernel, dim3(B), dim3(256), 0, sn_stream(stream), d_gt, d_ngt, d_crop, d_scale, G, F, feat_stride,
+                     im_h, im_w, dc_low, small_thresh, dc_high, d_mask);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}

@@ -32,6 +32,7 @@ class AnchorAssigner(object):
 
     def __init__(self, cfg, chip_size=512):
         net, tr = cfg.network, cfg.TRAIN
+        self.cfg = cfg
         self.feat_stride = int(net.RPN_FEAT_STRIDE)
         self.F = chip_size // self.feat_stride
         self.chip_size = chip_size
@@ -93,6 +94,18 @@ class AnchorAssigner(object):
                  out['label'], out['bbox_target'], out['bbox_weight'], out['gt_boxes'], out['counts'], lp, hip.stream())
         if want_label_pre:
             out['label_pre'] = lp
+        return out
+
+    def focus_mask(self, chips):
+        """AutoFocus FocusPixel labels of the same chips (gen_mask, data_workers.py:165-192) -> (B, F*F) device fp32."""
+        tr = self.cfg.TRAIN
+        device = hip.require_gpu()
+        gt, cls, inchip, ngt, crop, scale = self._pack(chips)
+        B = len(chips)
+        out = torch.empty((B, self.F * self.F), dtype=torch.float32, device=device)
+        hip.call("sn_focus_mask", hip.dev(gt), hip.dev(ngt), hip.dev(crop), hip.dev(scale), B, self.MAX_GT, self.F, self.feat_stride,
+                 self.chip_size, self.chip_size, float(tr.AUTO_FOCUS_DC_LOW), float(tr.AUTO_FOCUS_SMALL_THRESH),
+                 float(tr.AUTO_FOCUS_DC_HIGH), out, hip.stream())
         return out
 
     def numpy_replay_keys(self, label_pre, rng=np.random):

@@ -50,7 +50,7 @@ class MNIteratorE2E(mx.io.DataIter):
         self.label_name = ['label', 'bbox_target', 'bbox_weight'] if config.TRAIN.ONLY_PROPOSAL else \
             ['label', 'bbox_target', 'bbox_weight', 'gt_boxes']
         if config.TRAIN.AUTO_FOCUS:
-            raise NotImplementedError('AUTO_FOCUS training labels (gen_mask) on the GPU: next row')
+            self.label_name.append('scale_label')      # FocusPixel labels (reference :28-29)
         if config.TRAIN.WITH_MASK:
             raise NotImplementedError('mask branch is out of scope (SURVEY.md 8(f).3)')
         self.chip_worker = chip_worker(config, crop_size[0])
@@ -176,6 +176,8 @@ class MNIteratorE2E(mx.io.DataIter):
         self.label = [mx.nd.NDArray(out['label']), mx.nd.NDArray(out['bbox_target']), mx.nd.NDArray(out['bbox_weight'])]
         if not self.cfg.TRAIN.ONLY_PROPOSAL:
             self.label.append(mx.nd.NDArray(out['gt_boxes']))
+        if self.cfg.TRAIN.AUTO_FOCUS:
+            self.label.append(mx.nd.NDArray(self.anchors.focus_mask(worker_data)))      # scale_label (B, F*F), :182-197,213-214
         batch = mx.io.DataBatch(data=self.data, label=self.label, pad=0, index=self.getindex(),
                                 provide_data=self.provide_data, provide_label=self.provide_label)
         batch.worker_data = worker_data   # the anchor-labelling inputs (bench.py re-runs the labelling per step)

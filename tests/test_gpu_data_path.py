@@ -216,3 +216,42 @@ def test_soft_nms_rows_bit_exact_vs_oracle():
     one = probs[4].copy()
     res = cpu_nms.cpu_soft_nms(one, 0.55, 0.3, 0.001, 2)          # reference signature
     assert np.array_equal(res, oracle.soft_nms(probs[4].copy(), 0.55, 0.3, 0.001, 2))
+
+
+def test_focus_mask_golden_bit_exact():
+    """AutoFocus FocusPixel labels (sn_focus_mask) against the masks the REFERENCE's anchor_worker produced
+    (tests/golden/focus_mask_v1.npz), all chips in one launch."""
+    import os
+    from golden_util import anchor_case, ref_cfg
+    from sniper_amd.data.anchors import AnchorAssigner
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'focus_mask_v1.npz'))
+    cfg = ref_cfg()
+    cfg.TRAIN.AUTO_FOCUS = True
+    cfg.TRAIN.AUTO_FOCUS_DC_LOW, cfg.TRAIN.AUTO_FOCUS_SMALL_THRESH, cfg.TRAIN.AUTO_FOCUS_DC_HIGH = [float(v) for v in g['thresholds']]
+    aa = AnchorAssigner(cfg, 512)
+    n = int(g['count'])
+    chips = [anchor_case(k)[0] for k in range(n)]
+    got = aa.focus_mask(chips).cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(got[k], g['mask_%02d' % k]), k
+
+
+def test_autofocus_training_step():
+    """TRAIN.AUTO_FOCUS: the iterator emits scale_label, the graph grows the FocusPixel head and its SoftmaxOutput,
+    a training step is finite and the new head receives gradient."""
+    import torch
+    from sniper_amd import config as cfgmod
+    from sniper_amd.train import Trainer
+    cfg = cfgmod.res101_e2e(batch_images=2)
+    cfg.TRAIN.AUTO_FOCUS = True
+    cfg.TRAIN.AUTO_FOCUS_DC_LOW, cfg.TRAIN.AUTO_FOCUS_SMALL_THRESH, cfg.TRAIN.AUTO_FOCUS_DC_HIGH = 5, 64, 90
+    tr = Trainer(batch_images=2, n_images=4, seed=0, cfg=cfg)
+    assert [k for k, _ in tr.iter.provide_label][-1] == 'scale_label' and dict(tr.iter.provide_label)['scale_label'] == (2, 1024)
+    lab = tr.batch.label[-1].asnumpy()
+    assert set(np.unique(lab).tolist()) <= {-1.0, 0.0, 1.0}
+    outs = tr.step()
+    torch.cuda.synchronize()
+    assert len(outs) == 6 and tuple(outs[2].shape) == (2, 2, 1024)
+    assert all(np.isfinite(o.asnumpy()).all() for o in outs)
+    p = tr.mod.exe.params['conv_new_out_weight']
+    assert p.trainable and float(p.master.abs().sum()) > 0

@@ -175,3 +175,24 @@ def test_soft_nms_known_answers():
     d[:, 4] = rs.uniform(0.1, 1, n)
     out = oracle.soft_nms(d, 0.55)
     assert np.array_equal(out[:, 4], np.sort(d[:, 4])[::-1])
+
+
+def test_focus_mask_golden():
+    """AutoFocus FocusPixel labels (gen_mask, data_workers.py:165-192): the oracle's restatement against masks produced by
+    the reference's own anchor_worker with TRAIN.AUTO_FOCUS (tests/golden/make_focus_golden.py)."""
+    import os
+    from golden_util import anchor_case, ref_cfg
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'focus_mask_v1.npz'))
+    lo, small, hi = [float(v) for v in g['thresholds']]
+    cfg = ref_cfg()
+    at = data_path.AnchorTarget(512, 16, cfg.network.ANCHOR_RATIOS, cfg.network.ANCHOR_SCALES, auto_focus=True, af_dc_low=lo,
+                                af_dc_high=hi, af_small=small)
+    n = int(g['count'])
+    seen = set()
+    for k in range(n):
+        args, seed, _ = anchor_case(k)
+        np.random.seed(seed)
+        out = at(*args)
+        assert np.array_equal(out[4], g['mask_%02d' % k]), k
+        seen |= set(np.unique(out[4]).tolist())
+    assert seen == {-1.0, 0.0, 1.0}
