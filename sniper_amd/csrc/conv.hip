@@ -193,10 +193,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // ds_write_b128 groups (8 chunks of one row) and the 16-lane ds_read_b128 groups (16 rows, chunk q / q+1).
 // Workgroup -> tile mapping is XCD-aware: the Nout/128 column tiles that share one 128-row A panel run back to back
 // on the SAME XCD (linear id % 8 = XCD), so the panel is fetched into one L2 once instead of once per column tile.
-template <bool DGRAD>
+// BM = 128 for launches that fill the chip; BM = 64 (wave tile 32 x 64, 48 KB LDS, 3 workgroups per CU) for the many
+// R101 layers whose 128-row tiling yields only ~1 workgroup per CU: those launches are latency-bound (each workgroup
+// waits ~1 us per K-step on its own two tiles in flight), so more, smaller workgroups per CU finish sooner even though
+// each reads its B panel for half the rows.
+template <bool DGRAD, int BM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams p, int mtiles, int ntiles) {
-  constexpr int BM = 128, BN = 128, BK = 64;
-  constexpr int MI = 4, NI = 4, AR = 4, BR = 4;   // 16-byte chunks per thread per tile: 128 rows x 8 chunks / 256
+  constexpr int BN = 128, BK = 64, WM = BM / 2;
+  constexpr int MI = BM / 32, NI = 4, AR = BM / 32, BR = 4;   // 16-byte chunks per thread per tile: rows x 8 chunks / 256
   __shared__ __attribute__((aligned(16))) half_t sA[2][BM * BK];
   __shared__ __attribute__((aligned(16))) half_t sB[2][BN * BK];
 
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
   // fragment rows wm*64 + i*16 + fr all share (row & 7) = fr & 7: one base per k-substep, rows by immediates
   const int fr = lane & 15, fq = lane >> 4;
   const int sw = fq ^ (fr & 7);
-  const int a_rd = (wm * 64 + fr) * BK, b_rd = (wn * 64 + fr) * BK;
+  const int a_rd = (wm * WM + fr) * BK, b_rd = (wn * 64 + fr) * BK;
   // The product is formed TRANSPOSED (weights as the MFMA A operand): D^T[n][m] puts 4 consecutive output channels
   // n = fq*4 + r of one pixel m = fr into each lane, so the epilogue stores 8 bytes per (i, jn) instead of 4 x 2.
   auto compute = [&](int buf) {
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
   const bool vec = (p.out_ps % 4 == 0) && (p.Nout % 4 == 0) && (!p.res || p.res_ps % 4 == 0);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
+    const int m = m0 + wm * WM + i * 16 + fr;
     if (m >= p.M) continue;
 #pragma unroll
     for (int jn = 0; jn < NI; ++jn) {
@@ -410,8 +414,16 @@ static int conv_launch(const ConvParams &p, hipStream_t s) {
     ConvParams q = p;
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
-    const int mtiles = sn_div_up(p.M, 128), ntiles = sn_div_up(p.Nout, 128);
-    hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, q, mtiles, ntiles);
+    const int ntiles = sn_div_up(p.Nout, 128);
+    const char *force = getenv("SNIPER_CONV_BM");
+    const bool small = force ? atoi(force) == 64 : sn_div_up(p.M, 128) * ntiles < 448;   // < ~1.75 workgroups per CU
+    if (small) {
+      const int mtiles = sn_div_up(p.M, 64);
+      hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD, 64>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, q, mtiles, ntiles);
+    } else {
+      const int mtiles = sn_div_up(p.M, 128);
+      hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD, 128>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, q, mtiles, ntiles);
+    }
   } else if (p.Nout <= 64) {
     dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 64));
     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, DGRAD>), grid, dim3(256), 0, s, p);
