@@ -35,7 +35,7 @@ def _pad8(n):
 class Val(object):
     """One tensor of the graph.  fmt 'act': fp16 channels-last, t has shape (N,H,W,C) (2-D logical
     tensors use H=W=1); fmt 'f32': fp32, reference order, t has the logical shape."""
-    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers')
+    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer')
 
     def __init__(self, name, shape, fmt):
         self.name, self.shape, self.fmt = name, tuple(shape), fmt
@@ -45,6 +45,7 @@ class Val(object):
         self.alt = None      # cached other-format copy (forward)
         self.stem = None     # (src f32 NCHW Val, scale, shift) for a BN-folded image input
         self.consumers = 0
+        self.producer = None  # the Step whose output this is
 
     def nhwc(self):
         s = self.shape

@@ -5,6 +5,8 @@ backward() turns the gradients of its outputs into gradients of its inputs / par
 Semantics of the fork-resident operators are documented in DESIGN.md and restated in oracle/nn.py;
 call sites: symbols/faster/resnet_mx_101_e2e.py, mobilenetv2_e2e.py.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -44,6 +46,7 @@ class Step(object):
         if alloc:
             v.t = ex.empty(v.nhwc(), F16) if fmt == 'act' else ex.empty(v.shape, F32)
         ex.vals[(id(self.node), i)] = v
+        v.producer = self
         return v
 
     def pname(self, slot):
@@ -386,8 +389,12 @@ class ConvolutionStep(_GemmLike):
             hip.call('sn_dwconv_fwd', x, self.w.w16, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.k[0], self.k[1],
                      self.s[0], self.p[0], self.d[0], hip.stream())
             return
-        hip.call('sn_conv_fwd', x, self.w.w16, bias, None, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0,
-                 self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0, 1 if self.out_f32 else 0, hip.stream())
+        res = getattr(self, 'fused_residual', None)
+        if res is not None:      # y = conv(x) + residual written straight into the consuming add's tensor (BinaryStep)
+            dst = self.fused_dst.t
+        hip.call('sn_conv_fwd', x, self.w.w16, bias, None if res is None else res.t, dst, self.N, self.H, self.W, self.C, self.C,
+                 self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0,
+                 1 if self.out_f32 else 0, hip.stream())
 
     def launch_dgrad(self, dy, Op, acc, dx):
         if self.depthwise:
@@ -619,9 +626,27 @@ class BinaryStep(Step):
         if not self.act and a.shape != b.shape:
             raise NotImplementedError('broadcasting in %s (%s)' % (self.node.op, self.node.name))
         self.code = {'_plus': 1, 'elemwise_add': 1, '_minus': 0, '_mul': 2}[self.node.op]
+        # residual fusion: `conv(x) + shortcut` (every ResNet bottleneck, resnet_mx_101_e2e.py:66-69) is computed by the
+        # convolution's epilogue.  The operand produced LAST is the one that can absorb the add (the other is ready by
+        # then); it must be a plain fp16 convolution whose only consumer is this node.
+        self.fused_conv = None
+        if self.act:
+            ex = self.ex
+            steps = ex.steps
+            order = lambda v: steps.index(v.producer) if v.producer in steps else -1
+            me, other = (a, b) if order(a) > order(b) else (b, a)
+            st = me.producer
+            cons = ex.consumers.get((id(st.node), 0), []) if st is not None else []
+            if (type(st).__name__ == 'ConvolutionStep' and not st.depthwise and not st.is_stem and not st.out_f32 and
+                    len(cons) == 1 and getattr(st, 'fused_residual', None) is None and me is not other and
+                    os.environ.get('SNIPER_FUSE_RESIDUAL', '1') != '0'):
+                st.fused_residual, st.fused_dst = other, self.y
+                self.fused_conv = st
 
     def forward(self):
         ex = self.ex
+        if self.fused_conv is not None:
+            return                   # written by the convolution's epilogue
         if self.act:
             n, h, w, c = self.y.nhwc()
             hip.call('sn_ew_f16', self.lhs.t, self.rhs.t, None, self.y.t, n * h * w, c, c, c, c, c, 1, hip.stream())

@@ -374,8 +374,10 @@ def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
     dev_vals = {}
     for st in ex.steps:
         y = getattr(st, 'y', None)
-        if y is None or y.t is None or (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)):
-            continue            # a BN fused with its activation holds the post-activation tensor: forced at the activation node
+        if y is None or y.t is None or (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)) or \
+                getattr(st, 'fused_residual', None) is not None:
+            continue            # a BN fused with its activation holds the post-activation tensor (forced at the activation
+            #                     node); a convolution fused with the residual add writes the sum (forced at the add node)
         if getattr(st, 'fused', False) is False and type(st).__name__ in ('ActivationStep', 'ClipStep') or \
                 type(st).__name__ not in ('ActivationStep', 'ClipStep'):
             pass

@@ -83,7 +83,8 @@ ov = {(mpt.name, i): ex.vals[(id(mpt), i)].t.cpu().numpy().reshape(ex.vals[(id(m
 names = list(rec.keys())
 force = {}
 for st in ex.steps:
-    if st.node.name in rec and not (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)):
+    if st.node.name in rec and not (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)) and \
+            getattr(st, 'fused_residual', None) is None:
         force[st.node.name] = rec[st.node.name][0]
 want, wgrads, probes = graph_cpu.run(sym, P, AUX, inp, overrides=ov, fork_ops=False, fp16_storage=True, probe=names, force=force)
 le = graph_cpu.run.local_err
