@@ -1,4 +1,5 @@
-"""Debug aid: per-node forward values and output gradients of the MobileNetV2 (C1) step, HIP engine vs oracle.graph_cpu."""
+"""Debug aid (lives under tests/ because it uses the oracle, which only test code may import): per-node forward values
+and output gradients of the MobileNetV2 (C1) step, HIP engine vs oracle.graph_cpu.  Run: python tests/debug_c1_nodes.py"""
 import os
 import sys
 
