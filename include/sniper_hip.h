@@ -205,6 +205,10 @@ int sn_ew_f16(const void *a, const void *b, const void *ref, void *y, long rows,
 /* fp32 element-wise: op 0 a-b, 1 a+b, 2 a*b, 3 a*scalar, 4 fill(scalar). */
 int sn_ew_f32(const float *a, const float *b, float *out, long n, int op, float scalar, sn_stream_t stream);
 int sn_maxpool_fwd(const void *x, void *y, int N, int H, int W, int C, int k, int stride, int pad, sn_stream_t stream);
+/* Pooling(pool_type='avg', global_pool=True) over a channels-last fp16 tensor x (N, HW, C) -> y (N, C) fp32 (the R-FCN
+ * vote over the position-sensitive bins, BASELINE config C4), and its gradient dx = dy / HW (fp16, overwritten). */
+int sn_avgpool_global_fwd(const void *x, float *y, int N, int HW, int C, sn_stream_t stream);
+int sn_avgpool_global_bwd(const float *dy, void *dx, int N, int HW, int C, sn_stream_t stream);
 /* out[b][c][r] = in[b][r][c] with dtype conversion (NHWC <-> NCHW). */
 int sn_transpose_batched(const void *in, void *out, int batch, int rows, int cols, long in_batch_stride, long out_batch_stride,
                          int in_ld, int out_ld, int in_dtype, int out_dtype, sn_stream_t stream);
@@ -240,6 +244,16 @@ size_t sn_dpsroi_bwd_workspace_bytes(int R);
 int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data, int d_data_f32,
                        float *d_trans, int R, int B, int H, int W, int C, int pooled, int sample_per_part, float spatial_scale,
                        float trans_std, void *ws, sn_stream_t stream);
+
+/* Position-sensitive variant (group_size G > 1: the R-FCN head of BASELINE config C4; msracver Deformable R-FCN's
+ * DeformablePSROIPooling(group_size=7)).  data (B,H,W,C = output_dim*G*G) fp16 in the operator's channel order
+ * c = (d*G + gh)*G + gw, out (R,P,P,output_dim) fp16; bin (ph,pw) of output channel d reads channel
+ * (d*G + floor(ph*G/P))*G + floor(pw*G/P).  trans (R,2,P,P) class-agnostic or NULL.  Backward as above (overwrites). */
+int sn_psroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int output_dim,
+                      int group_size, int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream);
+int sn_psroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data, int d_data_f32,
+                      float *d_trans, int R, int B, int H, int W, int output_dim, int group_size, int pooled, int sample_per_part,
+                      float spatial_scale, float trans_std, void *ws, sn_stream_t stream);
 
 /* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward:
  * d_data (N,H,W,C) fp16/fp32 and d_offset (same layout/dtype as offset) are OVERWRITTEN; either may be NULL. */

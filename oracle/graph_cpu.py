@@ -115,17 +115,18 @@ class _MakeLoss(torch.autograd.Function):
 
 class _DPSROIPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, data, rois, trans, P, S, scale, tstd):
+    def forward(ctx, data, rois, trans, P, S, scale, tstd, G):
         d, r = data.detach().double().numpy(), rois.detach().numpy().astype(np.float32)
         t = None if trans is None else trans.detach().numpy().astype(np.float32)
-        ctx.args = (d, r, t, P, S, scale, tstd)
-        return torch.from_numpy(onn.dpsroi_pool(d, r, t, P, S, scale, tstd)).float()
+        ctx.args = (d, r, t, P, S, scale, tstd, G)
+        return torch.from_numpy(onn.dpsroi_pool(d, r, t, P, S, scale, tstd, G)).float()
 
     @staticmethod
     def backward(ctx, g):
-        d, r, t, P, S, scale, tstd = ctx.args
-        dd, dt = onn.dpsroi_pool_backward(g.double().numpy(), d, r, t, P, S, scale, tstd)
-        return torch.from_numpy(dd).float(), None, (None if dt is None else torch.from_numpy(dt).float()), None, None, None, None
+        d, r, t, P, S, scale, tstd, G = ctx.args
+        dd, dt = onn.dpsroi_pool_backward(g.double().numpy(), d, r, t, P, S, scale, tstd, G)
+        return (torch.from_numpy(dd).float(), None, (None if dt is None else torch.from_numpy(dt).float()), None, None, None,
+                None, None)
 
 
 class _DeformIm2col(torch.autograd.Function):
@@ -209,7 +210,11 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
             y = x * ((x >= lo) & (x <= hi)).float() + (x.detach().clamp(lo, hi) - x.detach() * ((x >= lo) & (x <= hi)).float())
         elif op == 'Pooling':
             k = _tup(a['kernel'])
-            y = F.max_pool2d(ins[0], k, _tup(a.get('stride', 1)), _tup(a.get('pad', 0)))
+            if a.get('pool_type', 'max') == 'avg':
+                assert _bool(a.get('global_pool', False)) or k == tuple(ins[0].shape[2:])
+                y = ins[0].mean((2, 3), keepdim=True)
+            else:
+                y = F.max_pool2d(ins[0], k, _tup(a.get('stride', 1)), _tup(a.get('pad', 0)))
         elif op == 'Cast':
             y = ins[0]
         elif op == 'Concat':
@@ -262,7 +267,8 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
         elif op == 'DeformablePSROIPooling':
             no_trans = _bool(a.get('no_trans', False)) or 'trans' not in s
             y = _DPSROIPool.apply(s['data'], s['rois'].detach(), None if no_trans else s['trans'], int(a['pooled_size']),
-                                  int(a.get('sample_per_part', 1)), float(a['spatial_scale']), float(a.get('trans_std', 0.0)))
+                                  int(a.get('sample_per_part', 1)), float(a['spatial_scale']), float(a.get('trans_std', 0.0)),
+                                  int(a.get('group_size', 1)))
         elif op == 'DeformableConvolution':
             k = _tup(a['kernel'])
             col = _DeformIm2col.apply(s['data'], s['offset'], k, _tup(a.get('stride', 1))[0], _tup(a.get('pad', 0))[0],

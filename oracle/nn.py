@@ -110,9 +110,17 @@ def proposal_targets(rois, gt_boxes, valid_ranges, post_nms, fg_thresh=0.5, stds
 
 
 # ---------------------------------------------------------------------------------------------
-# DeformablePSROIPooling, group_size 1 (Deformable ConvNets v1; call site :286-293)
-# data (B,C,H,W), rois (R,5), trans (R,2,P,P) or None -> out (R,C,P,P), and its gradients.
+# DeformablePSROIPooling (Deformable ConvNets v1; call site :286-293 uses group_size 1; BASELINE config C4 swaps the
+# head for the position-sensitive R-FCN variant, group_size = pooled_size = 7).
+# data (B,C,H,W) with C = output_dim * G * G, rois (R,5), trans (R,2,P,P) or None -> out (R,output_dim,P,P).
+# Bin (ph,pw) of output channel d reads data channel (d*G + gh)*G + gw, gh = floor(ph*G/P), gw = floor(pw*G/P)
+# (G = 1: channel d itself).  Offsets are class-agnostic (one (2,P,P) field per RoI), part_size = pooled_size.
 # ---------------------------------------------------------------------------------------------
+def _ps_channels(D, G, P, ph, pw):
+    gh, gw = min(max(ph * G // P, 0), G - 1), min(max(pw * G // P, 0), G - 1)
+    return (np.arange(D) * G + gh) * G + gw
+
+
 def _roi_bins(roi, trans, r, ph, pw, P, S, scale, trans_std):
     f32 = np.float32
     rnd = lambda v: f32(np.floor(abs(v) + 0.5) * np.sign(v))  # C round(): half away from zero
@@ -126,17 +134,21 @@ def _roi_bins(roi, trans, r, ph, pw, P, S, scale, trans_std):
     return pw * bw + sw + tx * rw, ph * bh + sh + ty * rh, bw / S, bh / S, rw, rh
 
 
-def dpsroi_pool(data, rois, trans, P, S, scale, trans_std=0.0):
+def dpsroi_pool(data, rois, trans, P, S, scale, trans_std=0.0, group_size=1):
     B, C, H, W = data.shape
+    G = int(group_size)
+    assert C % (G * G) == 0
+    D = C // (G * G)
     R = rois.shape[0]
-    out = np.zeros((R, C, P, P), np.float64)
+    out = np.zeros((R, D, P, P), np.float64)
     for r in range(R):
         b = int(rois[r, 0])
         for ph in range(P):
             for pw in range(P):
                 ws, hs, sw_, sh_, _, _ = _roi_bins(rois[r], trans, r, ph, pw, P, S, scale, trans_std)
-                acc = np.zeros(C)
+                acc = np.zeros(D)
                 cnt = 0
+                ch = _ps_channels(D, G, P, ph, pw)
                 for ih in range(S):
                     for iw in range(S):
                         w, h = ws + iw * sw_, hs + ih * sh_
@@ -145,16 +157,18 @@ def dpsroi_pool(data, rois, trans, P, S, scale, trans_std=0.0):
                         w, h = min(max(w, 0.0), W - 1.0), min(max(h, 0.0), H - 1.0)
                         x0, x1, y0, y1 = int(np.floor(w)), int(np.ceil(w)), int(np.floor(h)), int(np.ceil(h))
                         dx, dy = w - x0, h - y0
-                        acc += ((1 - dx) * (1 - dy) * data[b, :, y0, x0] + dx * (1 - dy) * data[b, :, y0, x1] +
-                                (1 - dx) * dy * data[b, :, y1, x0] + dx * dy * data[b, :, y1, x1])
+                        acc += ((1 - dx) * (1 - dy) * data[b, ch, y0, x0] + dx * (1 - dy) * data[b, ch, y0, x1] +
+                                (1 - dx) * dy * data[b, ch, y1, x0] + dx * dy * data[b, ch, y1, x1])
                         cnt += 1
                 if cnt:
                     out[r, :, ph, pw] = acc / cnt
     return out
 
 
-def dpsroi_pool_backward(dout, data, rois, trans, P, S, scale, trans_std=0.0):
+def dpsroi_pool_backward(dout, data, rois, trans, P, S, scale, trans_std=0.0, group_size=1):
     B, C, H, W = data.shape
+    G = int(group_size)
+    D = C // (G * G)
     R = rois.shape[0]
     d_data = np.zeros(data.shape, np.float64)
     d_trans = None if trans is None else np.zeros(trans.shape, np.float64)
@@ -173,15 +187,16 @@ def dpsroi_pool_backward(dout, data, rois, trans, P, S, scale, trans_std=0.0):
                 if not pts:
                     continue
                 dv = dout[r, :, ph, pw] / len(pts)
+                ch = _ps_channels(D, G, P, ph, pw)
                 for w, h in pts:
                     x0, x1, y0, y1 = int(np.floor(w)), int(np.ceil(w)), int(np.floor(h)), int(np.ceil(h))
                     dx, dy = w - x0, h - y0
-                    d_data[b, :, y0, x0] += (1 - dx) * (1 - dy) * dv
-                    d_data[b, :, y0, x1] += dx * (1 - dy) * dv
-                    d_data[b, :, y1, x0] += (1 - dx) * dy * dv
-                    d_data[b, :, y1, x1] += dx * dy * dv
+                    d_data[b, ch, y0, x0] += (1 - dx) * (1 - dy) * dv
+                    d_data[b, ch, y0, x1] += dx * (1 - dy) * dv
+                    d_data[b, ch, y1, x0] += (1 - dx) * dy * dv
+                    d_data[b, ch, y1, x1] += dx * dy * dv
                     if trans is not None:
-                        U00, U01, U10, U11 = data[b, :, y0, x0], data[b, :, y0, x1], data[b, :, y1, x0], data[b, :, y1, x1]
+                        U00, U01, U10, U11 = data[b, ch, y0, x0], data[b, ch, y0, x1], data[b, ch, y1, x0], data[b, ch, y1, x1]
                         d_trans[r, 0, ph, pw] += np.sum((U11 * dy + U01 * (1 - dy) - U10 * dy - U00 * (1 - dy)) * dv) * trans_std * rw
                         d_trans[r, 1, ph, pw] += np.sum((U11 * dx + U10 * (1 - dx) - U01 * dx - U00 * (1 - dx)) * dv) * trans_std * rh
     return d_data, d_trans

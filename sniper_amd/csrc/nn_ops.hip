@@ -527,6 +527,47 @@ SN_EXPORT int sn_maxpool_fwd(const void *x, void *y, int N, int H, int W, int C,
   return SN_OK;
 }
 
+// Global average pooling (the R-FCN vote over the P x P position-sensitive bins, BASELINE config C4):
+// x (N, HW, C) fp16 channels-last -> y (N, C) fp32 = mean over the HW positions, and its gradient dx = dy / HW.
+__global__ __launch_bounds__(256) void avgpool_global_fwd_kernel(const half_t *__restrict__ x, float *__restrict__ y, long NC,
+                                                                 int HW, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NC) return;
+  const long n = i / C;
+  const int c = (int)(i - n * C);
+  const half_t *src = x + (size_t)n * HW * C + c;
+  float s = 0.f;
+  for (int k = 0; k < HW; ++k) s += (float)src[(size_t)k * C];
+  y[i] = s / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void avgpool_global_bwd_kernel(const float *__restrict__ dy, half_t *__restrict__ dx, long total,
+                                                                 int HW, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long n = i / ((long)HW * C);
+  dx[i] = (half_t)(dy[n * C + c] / (float)HW);
+}
+
+SN_EXPORT int sn_avgpool_global_fwd(const void *x, float *y, int N, int HW, int C, sn_stream_t stream) {
+  SN_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "sn_avgpool_global_fwd: bad arguments");
+  const long NC = (long)N * C;
+  hipLaunchKernelGGL(avgpool_global_fwd_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, sn_stream(stream),
+                     (const half_t *)x, y, NC, HW, C);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+SN_EXPORT int sn_avgpool_global_bwd(const float *dy, void *dx, int N, int HW, int C, sn_stream_t stream) {
+  SN_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0, "sn_avgpool_global_bwd: bad arguments");
+  const long total = (long)N * HW * C;
+  hipLaunchKernelGGL(avgpool_global_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sn_stream(stream), dy,
+                     (half_t *)dx, total, HW, C);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Layout / dtype conversion between the reference's NCHW tensors and internal NHWC.
 //   nhwc(src, pixel stride ps, dtype f16|f32) -> nchw (dst contiguous, dtype f16|f32) and back.

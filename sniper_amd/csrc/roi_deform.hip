@@ -394,6 +394,246 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// Position-sensitive variant (group_size G > 1; BASELINE config C4, the R-FCN head).  data (B,H,W,C) fp16 with
+// C = D*G*G in the operator's own channel order c = (d*G + gh)*G + gw; out (R,P,P,D) fp16; bin (ph,pw) of output
+// channel d reads channel (d*G + floor(ph*G/P))*G + floor(pw*G/P).  Offsets are class-agnostic (R,2,P,P).
+// The D channels of one bin are G*G apart in memory, so the gathers are 2-byte loads; the map is L2-resident.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ps_group(int p, int G, int P) {
+  const int g = p * G / P;
+  return g < 0 ? 0 : (g > G - 1 ? G - 1 : g);
+}
+
+__global__ __launch_bounds__(256) void psroi_ps_fwd_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
+                                                           const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
+                                                           int W, int C, int P, int S, int G, int D, float scale, float trans_std) {
+  const long total = (long)R * P * P * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    long t = i / D;
+    const int pw = (int)(t % P); t /= P;
+    const int ph = (int)(t % P);
+    const int r = (int)(t / P);
+    const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+    const int c = (d * G + ps_group(ph, G, P)) * G + ps_group(pw, G, P);
+    const half_t *img = data + (size_t)g.b * H * W * C + c;
+    float sum = 0.f;
+    int count = 0;
+    for (int ih = 0; ih < S; ++ih) {
+      for (int iw = 0; iw < S; ++iw) {
+        float w = sample_pos(g.wstart, iw, g.sub_w), h = sample_pos(g.hstart, ih, g.sub_h);
+        if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) continue;
+        w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
+        h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
+        const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+        const float dx = w - (float)x0, dy = h - (float)y0;
+        const float v00 = (float)img[((size_t)y0 * W + x0) * C], v01 = (float)img[((size_t)y0 * W + x1) * C];
+        const float v10 = (float)img[((size_t)y1 * W + x0) * C], v11 = (float)img[((size_t)y1 * W + x1) * C];
+        sum += (1.f - dx) * (1.f - dy) * v00 + dx * (1.f - dy) * v01 + (1.f - dx) * dy * v10 + dx * dy * v11;
+        ++count;
+      }
+    }
+    out[i] = (half_t)(count ? sum / (float)count : 0.f);
+  }
+}
+
+// Data gradient, tile-owned like dpsroi_bwd_data_kernel: a workgroup owns (4x4-cell tile, image, group (gh,gw), 256
+// output channels d) = the map channels (d*G+gh)*G+gw of that tile, and walks the (RoI, bin) items whose bin maps to
+// its group, 256 items per round (one per thread) compacted in order into the LDS entry list.
+__global__ __launch_bounds__(256) void psroi_ps_bwd_data_kernel(const half_t *__restrict__ dout, const float *__restrict__ rois,
+                                                                const float *__restrict__ trans, const int4 *__restrict__ win,
+                                                                void *__restrict__ d_data, int out_f32, int R, int H, int W, int C,
+                                                                int P, int S, int G, int D, float scale, float trans_std) {
+  __shared__ __attribute__((aligned(16))) float ent[256 * kEntStride];
+  __shared__ int roi_list[256];
+  __shared__ int bins[256];
+  __shared__ int wave_cnt[4], ent_cnt[4], nb_s;
+  const int PP = P * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int tiles_x = (W + 3) >> 2;
+  const int x0 = (int)(blockIdx.x % tiles_x) * 4, y0 = (int)(blockIdx.x / tiles_x) * 4;
+  const int b = blockIdx.y;
+  const int chunks = (D + 255) >> 8;
+  const int grp = blockIdx.z / chunks, d = (blockIdx.z % chunks) * 256 + tid;
+  const int gh = grp / G, gw = grp % G;
+  const bool active_c = d < D;
+  if (tid == 0) {
+    int n = 0;
+    for (int bin = 0; bin < PP; ++bin)
+      if (ps_group(bin / P, G, P) == gh && ps_group(bin % P, G, P) == gw) bins[n++] = bin;
+    nb_s = n;
+  }
+  __syncthreads();
+  const int nb = nb_s;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  if (nb > 0) {
+    for (int base = 0; base < R; base += 256) {
+      const int rr = base + tid;
+      bool hit = false;
+      if (rr < R) {
+        const int4 w = win[rr];
+        hit = w.w && w.x == b && (w.y & 0xffff) <= x0 + 3 && (w.y >> 16) >= x0 && (w.z & 0xffff) <= y0 + 3 && (w.z >> 16) >= y0;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = 0, total = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int n = wave_cnt[k];
+        off += k < wave ? n : 0;
+        total += n;
+      }
+      if (hit) roi_list[off + __popcll(m & lt)] = rr;
+      __syncthreads();
+      const int nitems = total * nb;
+      for (int it0 = 0; it0 < nitems; it0 += 256) {
+        const int item = it0 + tid;
+        bool act = false;
+        float Wx[4] = {0.f, 0.f, 0.f, 0.f}, Wy[4] = {0.f, 0.f, 0.f, 0.f};
+        float inv = 0.f;
+        int idx = 0;
+        if (item < nitems) {
+          const int r = roi_list[item / nb], bin = bins[item % nb];
+          const int ph = bin / P, pw = bin - ph * P;
+          const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+          int nvx = 0, nvy = 0;
+          for (int i = 0; i < S; ++i) {
+            float w = sample_pos(g.wstart, i, g.sub_w), h = sample_pos(g.hstart, i, g.sub_h);
+            if (!(w < -0.5f || w > (float)W - 0.5f)) {
+              ++nvx;
+              tent4(fminf(fmaxf(w, 0.f), (float)W - 1.f), x0, Wx);
+            }
+            if (!(h < -0.5f || h > (float)H - 0.5f)) {
+              ++nvy;
+              tent4(fminf(fmaxf(h, 0.f), (float)H - 1.f), y0, Wy);
+            }
+          }
+          const float sx = Wx[0] + Wx[1] + Wx[2] + Wx[3], sy = Wy[0] + Wy[1] + Wy[2] + Wy[3];
+          act = nvx * nvy > 0 && sx > 0.f && sy > 0.f;
+          inv = act ? 1.f / (float)(nvx * nvy) : 0.f;
+          idx = r * PP + bin;
+        }
+        const unsigned long long am = __ballot(act);
+        if (lane == 0) ent_cnt[wave] = __popcll(am);
+        __syncthreads();
+        int eoff = 0, n_e = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int n = ent_cnt[k];
+          eoff += k < wave ? n : 0;
+          n_e += n;
+        }
+        if (act) {
+          float *e = ent + (size_t)(eoff + __popcll(am & lt)) * kEntStride;
+          e[0] = __int_as_float(idx);
+          *reinterpret_cast<float4 *>(e + 4) = make_float4(Wx[0] * inv, Wx[1] * inv, Wx[2] * inv, Wx[3] * inv);
+          *reinterpret_cast<float4 *>(e + 8) = make_float4(Wy[0], Wy[1], Wy[2], Wy[3]);
+        }
+        __syncthreads();
+        tile_accumulate<half_t>(ent, n_e, dout, (size_t)D, d, active_c, acc);
+        __syncthreads();
+      }
+    }
+  }
+  if (active_c) tile_store(acc, d_data, out_f32, b, y0, x0, H, W, C, (d * G + gh) * G + gw);
+}
+
+// d_trans (R,2,P,P): one wave per (r, ph, pw); the lanes stride over the D output channels, shuffle reduction.
+__global__ __launch_bounds__(256) void psroi_ps_bwd_trans_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
+                                                                 const float *__restrict__ rois, const float *__restrict__ trans,
+                                                                 float *__restrict__ d_trans, int R, int H, int W, int C, int P,
+                                                                 int S, int G, int D, float scale, float trans_std) {
+  const long total = (long)R * P * P;
+  const long wv = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wv >= total) return;                                           // whole waves leave together
+  const int lane = threadIdx.x & 63;
+  const int pw = (int)(wv % P), ph = (int)((wv / P) % P), r = (int)(wv / ((long)P * P));
+  const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+  const int gh = ps_group(ph, G, P), gw = ps_group(pw, G, P);
+  const half_t *img = data + (size_t)g.b * H * W * C;
+  float gtx = 0.f, gty = 0.f;
+  int count = 0;
+  for (int ih = 0; ih < S; ++ih) {
+    for (int iw = 0; iw < S; ++iw) {
+      float w = sample_pos(g.wstart, iw, g.sub_w), h = sample_pos(g.hstart, ih, g.sub_h);
+      if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) continue;
+      ++count;
+      w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
+      h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
+      const int xa = (int)floorf(w), xb = (int)ceilf(w), ya = (int)floorf(h), yb = (int)ceilf(h);
+      const float dx = w - (float)xa, dy = h - (float)ya;
+      for (int d = lane; d < D; d += 64) {
+        const int c = (d * G + gh) * G + gw;
+        const float dv = (float)dout[(size_t)wv * D + d];
+        const float U00 = (float)img[((size_t)ya * W + xa) * C + c], U01 = (float)img[((size_t)ya * W + xb) * C + c];
+        const float U10 = (float)img[((size_t)yb * W + xa) * C + c], U11 = (float)img[((size_t)yb * W + xb) * C + c];
+        gtx += (U11 * dy + U01 * (1.f - dy) - U10 * dy - U00 * (1.f - dy)) * dv;
+        gty += (U11 * dx + U10 * (1.f - dx) - U01 * dx - U00 * (1.f - dx)) * dv;
+      }
+    }
+  }
+  const float k = count ? trans_std / (float)count : 0.f;
+  gtx *= k * g.roi_w;
+  gty *= k * g.roi_h;
+  for (int off = 32; off > 0; off >>= 1) {
+    gtx += __shfl_xor(gtx, off, 64);
+    gty += __shfl_xor(gty, off, 64);
+  }
+  if (lane == 0) {
+    d_trans[(((size_t)r * 2 + 0) * P + ph) * P + pw] = gtx;
+    d_trans[(((size_t)r * 2 + 1) * P + ph) * P + pw] = gty;
+  }
+}
+
+SN_EXPORT int sn_psroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W,
+                                int output_dim, int group_size, int pooled, int sample_per_part, float spatial_scale,
+                                float trans_std, sn_stream_t stream) {
+  SN_REQUIRE(data && rois && out && R > 0 && output_dim > 0 && group_size > 0 && pooled > 0 && sample_per_part > 0,
+             "sn_psroi_pool_fwd: bad arguments");
+  const int C = output_dim * group_size * group_size;
+  hipLaunchKernelGGL(psroi_ps_fwd_kernel, dim3((unsigned)blocks_for((long)R * pooled * pooled * output_dim)), dim3(256), 0,
+                     sn_stream(stream), (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part,
+                     group_size, output_dim, spatial_scale, trans_std);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+SN_EXPORT int sn_psroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data,
+                                int d_data_f32, float *d_trans, int R, int B, int H, int W, int output_dim, int group_size,
+                                int pooled, int sample_per_part, float spatial_scale, float trans_std, void *ws,
+                                sn_stream_t stream) {
+  SN_REQUIRE(dout && data && rois && d_data && ws && R > 0 && B > 0 && output_dim > 0 && group_size > 0 && pooled > 0 &&
+                 sample_per_part > 0, "sn_psroi_pool_bwd: bad arguments");
+  SN_REQUIRE(H < 65536 && W < 65536 && pooled * pooled <= 256, "sn_psroi_pool_bwd: H, W < 65536 and pooled <= 16 required");
+  SN_REQUIRE(!trans || d_trans, "sn_psroi_pool_bwd: d_trans required with trans");
+  const int C = output_dim * group_size * group_size;
+  const long gz = (long)group_size * group_size * sn_div_up(output_dim, 256);
+  SN_REQUIRE(gz <= 65535 && B <= 65535, "sn_psroi_pool_bwd: grid too large");
+  hipStream_t s = sn_stream(stream);
+  int4 *win = (int4 *)ws;
+  hipLaunchKernelGGL(dpsroi_window_kernel, dim3(sn_div_up(R, 256)), dim3(256), 0, s, rois, trans, win, R, H, W, pooled,
+                     sample_per_part, spatial_scale, trans_std);
+  SN_CHECK_LAUNCH();
+  const int tiles = sn_div_up(W, 4) * sn_div_up(H, 4);
+  hipLaunchKernelGGL(psroi_ps_bwd_data_kernel, dim3(tiles, B, (unsigned)gz), dim3(256), 0, s, (const half_t *)dout, rois, trans,
+                     (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, group_size, output_dim,
+                     spatial_scale, trans_std);
+  SN_CHECK_LAUNCH();
+  if (trans) {
+    const long waves = (long)R * pooled * pooled;
+    hipLaunchKernelGGL(psroi_ps_bwd_trans_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, s,
+                       (const half_t *)dout, (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part,
+                       group_size, output_dim, spatial_scale, trans_std);
+    SN_CHECK_LAUNCH();
+  }
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // DeformableConvolution sampling (DCN v1 bilinear): column buffer col (M, T, C) fp16 with
 // M = N*Ho*Wo output pixels, T = KH*KW taps, from data (N,H,W,C) fp16 and offset (N,Ho,Wo,2*T*DG)
 // fp32 (channel g*2T + 2*tap = dy, +1 = dx).  The contraction itself runs on the implicit-GEMM

@@ -250,6 +250,8 @@ class Executor(object):
         for node in self.nodes:
             if node.op is None:
                 fmt[(id(node), 0)] = 'f32'
+            elif node.op == 'Pooling' and node.attrs.get('pool_type', 'max') == 'avg':
+                fmt[(id(node), 0)] = 'f32'      # global average pooling writes fp32 (N,C,1,1) (ops.PoolingStep)
             elif node.op in _PRODUCES_ACT:
                 fmt[(id(node), 0)] = 'act'
             elif node.op == 'Cast':

@@ -523,10 +523,21 @@ class DeformableConvolutionStep(Step):
 # ---------------------------------------------------------------------------------------------
 @register('Pooling')
 class PoolingStep(Step):
+    """max pooling (the stem) and global average pooling (the vote of the position-sensitive R-FCN head,
+    BASELINE config C4: act (N,H,W,C) -> f32 (N,C,1,1))."""
+
     def setup(self):
         self.x = self.ins[0]
         a = self.a
-        if a.get('pool_type', 'max') != 'max' or _bool(a.get('global_pool', False)):
+        self.kind = a.get('pool_type', 'max')
+        self.glob = _bool(a.get('global_pool', False))
+        n, c, h, w = self.x.shape
+        if self.kind == 'avg' and (self.glob or _tup(a['kernel']) == (h, w) and _tup(a.get('pad', (0, 0))) == (0, 0)):
+            self.kind = 'gavg'
+            self.y = self.new_out('f32')
+            self.y.needs_grad = self.x.needs_grad
+            return
+        if self.kind != 'max' or self.glob:
             raise NotImplementedError('Pooling %s (%s)' % (a.get('pool_type'), self.node.name))
         self.k, self.s, self.p = _tup(a['kernel']), _tup(a.get('stride', (1, 1))), _tup(a.get('pad', (0, 0)))
         self.y = self.new_out('act')
@@ -534,11 +545,21 @@ class PoolingStep(Step):
 
     def forward(self):
         n, h, w, c = self.x.nhwc()
+        if self.kind == 'gavg':
+            hip.call('sn_avgpool_global_fwd', self.ex.as_act(self.x), self.y.t, n, h * w, c, hip.stream())
+            return
         hip.call('sn_maxpool_fwd', self.ex.as_act(self.x), self.y.t, n, h, w, c, self.k[0], self.s[0], self.p[0], hip.stream())
 
     def backward(self):
-        if self.y.grad is not None and self.x.needs_grad:
+        if self.y.grad is None or not self.x.needs_grad:
+            return
+        if self.kind != 'gavg':
             raise NotImplementedError('max-pool backward (the stem is frozen in every SNIPER config)')
+        n, h, w, c = self.x.nhwc()
+        dx = self.ex.empty((n, h, w, c), F16)
+        hip.call('sn_avgpool_global_bwd', self.y.grad, dx, n, h * w, c, hip.stream())
+        self.ex.add_grad(self.x, dx, 'act')
+        self.y.grad = None
 
 
 @register('Cast')
@@ -888,17 +909,24 @@ class MultiProposalTargetStep(_ProposalBase):
 
 @register('DeformablePSROIPooling')
 class DPSROIPoolStep(Step):
+    """group_size 1 (the SNIPER heads, :286-293): sn_dpsroi_pool_*; group_size G > 1 (position-sensitive R-FCN head,
+    BASELINE config C4): sn_psroi_pool_*, data channels (output_dim, G, G)."""
+
     def setup(self):
         ex, a = self.ex, self.a
         self.x, self.rois = self.data_in('data'), self.data_in('rois')
         self.no_trans = _bool(a.get('no_trans', False))
         self.trans = None if self.no_trans or 'trans' not in self.slots else self.data_in('trans')
         self.P, self.S = int(a['pooled_size']), int(a.get('sample_per_part', 1))
-        if int(a.get('group_size', 1)) != 1 or int(a.get('part_size', self.P)) != self.P:
-            raise NotImplementedError('DeformablePSROIPooling with group_size != 1 / part_size != pooled_size '
-                                      '(position-sensitive variant of BASELINE config C4: next row)')
-        if int(a['output_dim']) != self.x.shape[1]:
-            raise ValueError('%s: output_dim must equal the channel count when group_size == 1' % self.node.name)
+        self.G, self.D = int(a.get('group_size', 1)), int(a['output_dim'])
+        if int(a.get('part_size', 0) or self.P) != self.P:
+            raise NotImplementedError('%s: DeformablePSROIPooling with part_size != pooled_size' % self.node.name)
+        if self.D * self.G * self.G != self.x.shape[1]:
+            raise ValueError('%s: data must carry output_dim * group_size^2 = %d channels (got %d)' %
+                             (self.node.name, self.D * self.G * self.G, self.x.shape[1]))
+        if self.trans is not None and tuple(self.trans.shape[1:]) != (2, self.P, self.P):
+            raise NotImplementedError('%s: per-class offset fields (trans %s); class-agnostic (R,2,P,P) only' %
+                                      (self.node.name, (self.trans.shape,)))
         self.scale = float(a['spatial_scale'])
         self.tstd = float(a.get('trans_std', 0.0))
         self.y = self.new_out('act')
@@ -909,8 +937,13 @@ class DPSROIPoolStep(Step):
         ex = self.ex
         n, h, w, c = self.x.nhwc()
         R = self.rois.shape[0]
-        hip.call('sn_dpsroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), ex.as_f32(self.trans) if self.trans else None,
-                 self.y.t, R, h, w, c, self.P, self.S, self.scale, self.tstd, hip.stream())
+        trans = ex.as_f32(self.trans) if self.trans else None
+        if self.G == 1:
+            hip.call('sn_dpsroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), trans, self.y.t, R, h, w, c, self.P, self.S,
+                     self.scale, self.tstd, hip.stream())
+        else:
+            hip.call('sn_psroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), trans, self.y.t, R, h, w, self.D, self.G,
+                     self.P, self.S, self.scale, self.tstd, hip.stream())
 
     def backward(self):
         ex = self.ex
@@ -922,9 +955,13 @@ class DPSROIPoolStep(Step):
         d_trans = ex.empty(self.trans.shape, F32) if self.trans is not None else None
         if self.ws is None:
             self.ws = ex.empty((hip.query('sn_dpsroi_bwd_workspace_bytes', R),), torch.uint8)
-        hip.call('sn_dpsroi_pool_bwd', self.y.grad, ex.as_act(self.x), ex.as_f32(self.rois),
-                 ex.as_f32(self.trans) if self.trans else None, d16, 0, d_trans, R, n, h, w, c, self.P, self.S, self.scale,
-                 self.tstd, self.ws, hip.stream())
+        trans = ex.as_f32(self.trans) if self.trans else None
+        if self.G == 1:
+            hip.call('sn_dpsroi_pool_bwd', self.y.grad, ex.as_act(self.x), ex.as_f32(self.rois), trans, d16, 0, d_trans, R, n, h,
+                     w, c, self.P, self.S, self.scale, self.tstd, self.ws, hip.stream())
+        else:
+            hip.call('sn_psroi_pool_bwd', self.y.grad, ex.as_act(self.x), ex.as_f32(self.rois), trans, d16, 0, d_trans, R, n, h,
+                     w, self.D, self.G, self.P, self.S, self.scale, self.tstd, self.ws, hip.stream())
         if self.x.needs_grad:
             ex.add_grad(self.x, d16, 'act')
         if self.trans is not None and self.trans.needs_grad:

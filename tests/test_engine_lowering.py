@@ -81,3 +81,29 @@ def test_mobilenetv2_lowering_plan():
     assert np.array_equal(stem.to_reference(stem.to_internal(a)), a)
     dw = ex.params['seq-3-block1-depthwise-conv2d_weight']
     assert dw.int_shape == (384, 9, 1) and dw.wT16 is None
+
+
+def test_rfcn_lowering_plan():
+    """BASELINE C4 graph: position-sensitive R-FCN head (group_size 7) on the R101 trunk."""
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e_rfcn as rf
+    B = 2
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    net = rf.resnet_mx_101_e2e_rfcn(momentum=0.995)
+    sym = net.get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, 21 * 32 * 32),
+                  bbox_target=(B, 84, 32, 32), bbox_weight=(B, 84, 32, 32), gt_boxes=(B, 100, 5))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    ps = [s for s in ex.steps if type(s).__name__ == 'DPSROIPoolStep']
+    assert len(ps) == 4 and all(s.G == 7 and s.P == 7 for s in ps)
+    assert sorted(s.D for s in ps) == [2, 2, 4, 81]
+    assert sum(1 for s in ps if s.trans is not None) == 2
+    assert not any(type(s).__name__ == 'FullyConnectedStep' for s in ex.steps)
+    votes = [s for s in ex.steps if type(s).__name__ == 'PoolingStep' and s.kind == 'gavg']
+    assert len(votes) == 2 and all(s.y.fmt == 'f32' and s.y.needs_grad for s in votes)
+    assert ex.params['rfcn_cls_weight'].ref_shape == (49 * 81, 256, 1, 1)
+    assert ex.shapes[(id(sym._heads[-3][0]), 0)] == (B, 300, 81)          # cls_prob_reshape
+    net.infer_shape(shapes)
+    arg, aux = {}, {}
+    net.init_weight_rcnn(cfg, arg, aux)
+    assert float(np.abs(arg['rfcn_cls_offset_t_weight'].asnumpy()).max()) == 0.0
+    assert arg['rfcn_bbox_weight'].shape == (49 * 4, 256, 1, 1)

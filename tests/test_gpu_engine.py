@@ -332,7 +332,7 @@ def _init_params(sym, shapes, rs, bn_gamma=(0.5, 0.9), bn_beta=(0.3, 1.2)):
             P[name] = np.zeros(shp, np.float32)
         elif 'offset' in name:
             P[name] = (rs.standard_normal(shp) * 1e-3).astype(np.float32)     # non-zero: exercises the offset branches
-        elif any(name.startswith(h) for h in ('rpn_', 'conv_new_1', 'fc_new', 'cls_score', 'bbox_pred')):
+        elif any(name.startswith(h) for h in ('rpn_', 'conv_new_1', 'fc_new', 'cls_score', 'bbox_pred', 'rfcn_')):
             P[name] = (rs.standard_normal(shp) * 0.01).astype(np.float32)
         else:
             P[name] = (rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))).astype(np.float32)
@@ -480,3 +480,38 @@ def test_r101_c2_network_parity_vs_cpu_reference_ops():
     assert checked >= 250
 
 
+
+
+def test_r101_c4_rfcn_head_parity_vs_cpu_reference_ops():
+    """BASELINE config C4: the R101 trunk with the position-sensitive R-FCN head (group_size 7 deformable PS-RoI pooling
+    of 7*7*81 / 7*7*4 maps with pooled offsets, bin vote by global average pooling), 2 chips, teacher-forced against
+    oracle/graph_cpu.py like C1 / C2."""
+    import os
+    from sniper_amd import config as cfgmod
+    from sniper_amd.engine.executor import Executor
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e_rfcn as rf
+    from sniper_amd.train import fixed_param_names
+    B, A, F = 2, 21, 32
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    sym = rf.resnet_mx_101_e2e_rfcn(momentum=0.995).get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                  bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5))
+    os.environ['SNIPER_HIP_GRAPHS'] = '0'
+    try:
+        ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym))
+    finally:
+        os.environ.pop('SNIPER_HIP_GRAPHS', None)
+    rs = np.random.RandomState(14)
+    P, AUX = _init_params(sym, shapes, rs, bn_gamma=(0.5, 1.0), bn_beta=(-0.2, 0.4))
+    for k in P:
+        if 'offset_t' in k and k.endswith('_weight'):
+            P[k] = f16r(rs.standard_normal(P[k].shape) * 0.05)     # offsets of a fraction of a bin: the trans path matters
+    P['bn_data_gamma'][:] = 1.0
+    AUX['bn_data_moving_mean'][:] = 0.0
+    AUX['bn_data_moving_var'][:] = 1.0 - 2e-5
+    P['bn_data_beta'][:] = 0.0
+    inp = _train_inputs(rs, B, A, F)
+    checked, ov = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=2e-2)
+    assert checked >= 250
+    names = [n for n, p in ex.params.items() if p.trainable]
+    assert all(k in names for k in ('rfcn_cls_weight', 'rfcn_bbox_weight', 'rfcn_cls_offset_t_weight', 'rfcn_bbox_offset_t_bias'))

@@ -430,6 +430,68 @@ def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R, SC):
         assert torch.equal(d2, d_data)
 
 
+@pytest.mark.parametrize('B,D,G,P,H,W,R,SC', [(2, 5, 3, 3, 12, 12, 9, 16), (2, 81, 7, 7, 10, 14, 40, 16), (2, 8, 7, 7, 16, 16, 150, 16),
+                                              (1, 300, 2, 4, 9, 8, 20, 16)])
+def test_position_sensitive_pool_fwd_bwd_vs_oracle(B, D, G, P, H, W, R, SC):
+    """sn_psroi_pool_* (group_size G > 1, the R-FCN head of BASELINE config C4) against oracle/nn.py; D = 81 and 8 are
+    the class / box map depths, (G, P) = (2, 4) covers several bins per group and D > 256 the channel chunks."""
+    hip = _hip()
+    rs = np.random.RandomState(19)
+    S = 4
+    C = D * G * G
+    data = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = rs.randint(0, B, R)
+    c = rs.uniform(20, SC * min(H, W) - 20, (R, 2))
+    wh = rs.uniform(4, 120, (R, 2))
+    rois[:, 1:3], rois[:, 3:5] = c - wh / 2, c + wh / 2
+    rois[0, 1:] = [-30, -20, 40, 50]
+    rois[1, 1:] = [0, 0, SC * W - 1, SC * H - 1]
+    rois[2, 1:] = [33, 47, 34, 48]
+    trans = (rs.standard_normal((R, 2, P, P)) * 0.5).astype(np.float32)
+    dd = torch.from_numpy(np.ascontiguousarray(data.transpose(0, 2, 3, 1))).to(dev()).half()
+    td = lambda z: torch.from_numpy(z).to(dev())
+    ws = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=dev())
+    for tr, tstd in ((None, 0.0), (trans, 0.1)):
+        out = torch.empty((R, P, P, D), dtype=torch.float16, device=dev())
+        hip.call('sn_psroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, D, G, P, S, 1.0 / SC, tstd,
+                 hip.stream())
+        want = onn.dpsroi_pool(f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC, tstd, group_size=G)
+        assert_close(out.float().cpu().numpy().transpose(0, 3, 1, 2), want, 1e-2, 1e-2, 'psroi fwd')
+        dout = rs.standard_normal((R, D, P, P)).astype(np.float32)
+        dod = torch.from_numpy(np.ascontiguousarray(dout.transpose(0, 2, 3, 1))).to(dev()).half()
+        wd, wtr = onn.dpsroi_pool_backward(f16r(dout).astype(np.float64), f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC,
+                                           tstd, group_size=G)
+        for f32 in (1, 0):
+            d_data = torch.full((B, H, W, C), 7.0, dtype=torch.float32 if f32 else torch.float16, device=dev())
+            d_trans = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
+            hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d_data, f32,
+                     d_trans if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, ws, hip.stream())
+            tol = 1e-3 if f32 else 1e-2
+            assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, tol, tol * np.abs(wd).max(), 'psroi d_data')
+            if tr is not None:
+                assert_close(d_trans.cpu().numpy(), wtr, 1e-3, 1e-3 * np.abs(wtr).max(), 'psroi d_trans')
+        d2 = torch.empty_like(d_data)
+        hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d2, 0,
+                 d_trans if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, ws, hip.stream())
+        assert torch.equal(d2, d_data)
+
+
+def test_global_average_pool():
+    hip = _hip()
+    rs = np.random.RandomState(23)
+    N, HW, C = 37, 49, 81
+    x = rs.standard_normal((N, HW, C)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev()).half()
+    y = torch.empty((N, C), dtype=torch.float32, device=dev())
+    hip.call('sn_avgpool_global_fwd', xd, y, N, HW, C, hip.stream())
+    assert_close(y.cpu().numpy(), f16r(x).mean(1), 1e-5, 1e-5, 'global avg pool')
+    dy = rs.standard_normal((N, C)).astype(np.float32)
+    dx = torch.full((N, HW, C), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_avgpool_global_bwd', torch.from_numpy(dy).to(dev()), dx, N, HW, C, hip.stream())
+    assert_close(dx.float().cpu().numpy(), np.broadcast_to(dy[:, None, :] / HW, (N, HW, C)), 1e-3, 1e-3, 'global avg pool bwd')
+
+
 @pytest.mark.parametrize('N,C,H,W,DG', [(2, 64, 7, 6, 4), (2, 512, 9, 11, 4), (1, 64, 5, 5, 1)])
 def test_deformable_sampling_vs_oracle(N, C, H, W, DG):
     hip = _hip()

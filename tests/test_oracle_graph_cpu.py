@@ -70,3 +70,37 @@ def test_graph_cpu_loss_gradient_rules():
     g_y += 0.5                                        # MakeLoss
     mask = (xv >= 0) & (xv <= 6)                      # clip: closed interval
     assert np.allclose(grads['w_weight'], g_y * mask * xv, atol=1e-6)
+
+
+def test_position_sensitive_pooling_is_the_diagonal_of_group1_pooling():
+    """oracle/nn.py dpsroi_pool(group_size=G): bin (ph,pw) of output channel d must equal the group_size-1 pooling of map
+    channel (d*G+ph)*G+pw at the same bin -- forward, data gradient and offset gradient (BASELINE config C4)."""
+    from oracle import nn as onn
+    rs = np.random.RandomState(3)
+    B, D, G, H, W, R, S = 2, 3, 3, 9, 11, 5, 2
+    P = G
+    C = D * G * G
+    data = rs.standard_normal((B, C, H, W))
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = rs.randint(0, B, R)
+    x1, y1 = rs.uniform(-10, 120, R), rs.uniform(-10, 90, R)
+    rois[:, 1], rois[:, 2], rois[:, 3], rois[:, 4] = x1, y1, x1 + rs.uniform(8, 90, R), y1 + rs.uniform(8, 70, R)
+    trans = rs.uniform(-1, 1, (R, 2, P, P)).astype(np.float32)
+    diag = np.zeros((C, P, P), bool)
+    for d in range(D):
+        for ph in range(P):
+            for pw in range(P):
+                diag[(d * G + ph) * G + pw, ph, pw] = True
+    for tr in (None, trans):
+        out = onn.dpsroi_pool(data, rois, tr, P, S, 1.0 / 8, 0.1, group_size=G)
+        full = onn.dpsroi_pool(data, rois, tr, P, S, 1.0 / 8, 0.1)
+        assert out.shape == (R, D, P, P)
+        assert np.allclose(out.reshape(R, -1), full[:, diag].reshape(R, D, P, P).reshape(R, -1), atol=1e-12)
+        dout = rs.standard_normal(out.shape)
+        dfull = np.zeros(full.shape)
+        dfull[:, diag] = dout.reshape(R, -1)
+        dd, dt = onn.dpsroi_pool_backward(dout, data, rois, tr, P, S, 1.0 / 8, 0.1, group_size=G)
+        dd1, dt1 = onn.dpsroi_pool_backward(dfull, data, rois, tr, P, S, 1.0 / 8, 0.1)
+        assert np.allclose(dd, dd1, atol=1e-12)
+        assert (dt is None and dt1 is None) or np.allclose(dt, dt1, atol=1e-12)
+    assert np.abs(out).max() > 0 and np.abs(dd).max() > 0 and np.abs(dt).max() > 0
