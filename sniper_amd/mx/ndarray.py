@@ -215,16 +215,28 @@ def concatenate(arrays, axis=0):
 
 
 def save(fname, data):
-    """Documented container (MXNet's binary .params format lives in the absent fork):
-    a numpy .npz written under the exact name MXNet would use, keys 'arg:name' / 'aux:name'."""
+    """mx.nd.save: MXNet's binary NDArray-list container (sniper_amd/mx/params_io.py), so that checkpoints written by
+    `mx.model.save_checkpoint` (resnet_mx_101_e2e.py:14) are readable by MXNet tooling and vice versa."""
+    from . import params_io
     if isinstance(data, dict):
         arrs = {k: v.asnumpy() for k, v in data.items()}
     else:
-        arrs = {'%d' % i: v.asnumpy() for i, v in enumerate(data)}
+        arrs = [v.asnumpy() for v in (data if isinstance(data, (list, tuple)) else [data])]
     with open(fname, 'wb') as fh:
-        np.savez(fh, **arrs)
+        fh.write(params_io.dumps(arrs))
 
 
 def load(fname):
-    with np.load(fname, allow_pickle=False) as z:
+    """mx.nd.load (lib/train_utils/utils.py:56): MXNet binary files of every record version; `.npz` containers written
+    by earlier builds of this package are still accepted."""
+    from . import params_io
+    with open(fname, 'rb') as fh:
+        buf = fh.read()
+    if params_io.is_mxnet_file(buf[:8]):
+        d = params_io.loads(buf)
+        if isinstance(d, dict):
+            return {k: NDArray(v) for k, v in d.items()}
+        return [NDArray(v) for v in d]
+    import io
+    with np.load(io.BytesIO(buf), allow_pickle=False) as z:
         return {k: NDArray(z[k]) for k in z.files}
