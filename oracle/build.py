@@ -3,9 +3,12 @@
 Two artefacts:
 
 * ``oracle/libsniper_oracle.so`` -- our plain-C restatement (``sniper_oracle.c``).
-* ``oracle/_ref/{chips,bbox}*.so`` -- the reference's *own* native code (``lib/chips/cchips.cpp``
-  + ``lib/chips/chips.pyx``, ``lib/bbox/bbox.pyx``) compiled from the sources where they lie
-  under ``/root/reference``.  No reference source is copied into this repository: Cython's
+* ``oracle/_ref/{chips,bbox,cpu_nms}*.so`` -- the reference's *own* native code (``lib/chips/cchips.cpp``
+  + ``lib/chips/chips.pyx``, ``lib/bbox/bbox.pyx``, ``lib/nms/cpu_nms.pyx``) compiled from the sources where they lie
+  under ``/root/reference``.  ``cpu_nms.pyx`` does not compile under Cython 3 as written (``np.int_t`` /
+  ``np.float`` are gone): it is read from the reference, four type spellings on lines 112-124 are
+  replaced IN A SCRATCH COPY (see ``_CPU_NMS_PATCH``; ``cpu_soft_nms``, lines 17-110, is compiled untouched), and
+  only the shared object is kept.  No reference source is copied into this repository: Cython's
   generated C/C++ goes to a scratch directory outside the repo, only the shared objects land in
   ``oracle/_ref/`` (git-ignored, but shipped to the GPU box).  Built only when the reference
   checkout is present; the GPU box uses the prebuilt files.
@@ -75,9 +78,43 @@ def build_reference(force=False):
     return REF_OUT
 
 
+# (line, old, new): the hard-NMS function's buffer types.  `order` is produced by `.astype('i')` (int32), so its buffer
+# is declared int32 (the original `np.int_t` = C long would refuse that array on LP64); `suppressed` keeps a
+# pointer-sized integer.  Nothing inside cpu_soft_nms (lines 17-110) is touched.
+_CPU_NMS_PATCH = ((112, 'np.float thresh', 'float thresh'), (120, 'np.int_t', 'np.int32_t'), (123, 'np.int_t', 'np.intp_t'),
+                  (124, 'np.int)', 'np.intp)'))
+
+
+def build_reference_cpu_nms(force=False):
+    """oracle/_ref/cpu_nms*.so from lib/nms/cpu_nms.pyx (cpu_soft_nms verbatim, cpu_nms with _CPU_NMS_PATCH)."""
+    if not have_reference():
+        return None
+    import numpy
+
+    os.makedirs(REF_OUT, exist_ok=True)
+    out = os.path.join(REF_OUT, "cpu_nms" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not force and os.path.exists(out):
+        return out
+    with open(os.path.join(REF, "lib", "nms", "cpu_nms.pyx")) as fh:
+        lines = fh.read().split("\n")
+    for ln, old, new in _CPU_NMS_PATCH:
+        assert old in lines[ln - 1], (ln, lines[ln - 1])
+        lines[ln - 1] = lines[ln - 1].replace(old, new)
+    with tempfile.TemporaryDirectory(prefix="sniper_ref_build_") as tmp:
+        pyx = os.path.join(tmp, "cpu_nms.pyx")
+        with open(pyx, "w") as fh:
+            fh.write("\n".join(lines))
+        gen_c = os.path.join(tmp, "cpu_nms.c")
+        _run([sys.executable, "-m", "cython", "-2", "-o", gen_c, pyx])
+        _run(["gcc", "-O2", "-shared", "-fPIC", "-w", "-I", sysconfig.get_paths()["include"], "-I", numpy.get_include(), gen_c,
+              "-o", out])
+    return out
+
+
 def build_all(force=False):
     build_restatement(force)
     build_reference(force)
+    build_reference_cpu_nms(force)
 
 
 if __name__ == "__main__":

@@ -255,9 +255,16 @@ ORC_API int orc_cpu_nms_f32(const float *dets, int n, const int *order, float th
  * cpu_soft_nms.  lib/nms/cpu_nms.pyx:17-110.  In-place selection sort by score with
  * score decay; boxes is (N,5) float32 and is mutated exactly like the reference; the
  * return value is the surviving N (rows [0,N) are the result).
- * All temporaries are C float except the gaussian weight: np.exp(-(ov*ov)/sigma) is
- * evaluated in double on the float product (ov*ov) / sigma (float / float -> float,
- * promoted), then narrowed to float when stored in `weight` (cpu_nms.pyx:25,86).
+ * Temporaries are C float, with the promotions Cython emits: an integer literal next to a C float becomes the
+ * DOUBLE literal 1.0 (the reference's own pre-generated lib/nms/cpu_nms.c:2946-3036 shows the same code Cython 3
+ * produces), so `(x2 - x1 + 1)` is float-subtract, then double-add, and products / sums of such terms are double
+ * until they are stored in a float variable.  For area, iw, ih and the linear weight the double detour rounds to the
+ * same float as float arithmetic would (exact sums / products of 24-bit values); for
+ *     ua = float((tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih)
+ * it does not: the three-term sum is formed in double and rounded once.  Pinned bit for bit against the
+ * reference's compiled cpu_nms.pyx by tests/test_oracle_vs_ref.py and tests/golden/nms_v1.npz.
+ * The gaussian weight: np.exp(-(ov*ov)/sigma) is evaluated in double on the float quotient, then narrowed to float
+ * when stored in `weight` (cpu_nms.pyx:25,86).
  * ---------------------------------------------------------------------------------- */
 ORC_API int orc_soft_nms_f32(float *boxes, int N, float sigma, float Nt, float threshold, unsigned method) {
   for (int i = 0; i < N; ++i) {
@@ -283,16 +290,16 @@ ORC_API int orc_soft_nms_f32(float *boxes, int N, float sigma, float Nt, float t
     int pos = i + 1;
     while (pos < N) {
       float x1 = boxes[5 * pos], y1 = boxes[5 * pos + 1], x2 = boxes[5 * pos + 2], y2 = boxes[5 * pos + 3];
-      float area = (x2 - x1 + 1) * (y2 - y1 + 1);
-      float iw = fminf_(tx2, x2) - fmaxf_(tx1, x1) + 1;
+      float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+      float iw = (float)((double)(fminf_(tx2, x2) - fmaxf_(tx1, x1)) + 1.0);
       if (iw > 0) {
-        float ih = fminf_(ty2, y2) - fmaxf_(ty1, y1) + 1;
+        float ih = (float)((double)(fminf_(ty2, y2) - fmaxf_(ty1, y1)) + 1.0);
         if (ih > 0) {
-          float ua = (float)((tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih);
+          float ua = (float)(((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0) + (double)area - (double)(iw * ih));
           float ov = iw * ih / ua;
           float weight;
           if (method == 1)
-            weight = ov > Nt ? 1 - ov : 1;
+            weight = ov > Nt ? (float)(1.0 - (double)ov) : 1;
           else if (method == 2)
             weight = (float)exp((double)(-(ov * ov) / sigma));
           else

@@ -260,12 +260,15 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(float *__restric
     for (int q = lo2; q < hi2; ++q) {
       const float x1 = bx[q * 5], y1 = bx[q * 5 + 1], x2 = bx[q * 5 + 2], y2 = bx[q * 5 + 3];
       bool keep = true;
-      const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
+      // Cython turns the `+ 1` beside C floats into the double literal 1.0 (the reference's own generated
+      // lib/nms/cpu_nms.c:2946-3036): differences are float, the `+ 1.0`, the products and the three-term sum of `ua` are
+      // double, rounded once when stored in a float variable.  iw / ih / the linear weight round like float arithmetic.
+      const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
       const float iw = fminf(tx2, x2) - fmaxf(tx1, x1) + 1;
       if (iw > 0) {
         const float ih = fminf(ty2, y2) - fmaxf(ty1, y1) + 1;
         if (ih > 0) {
-          const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
+          const float ua = (float)(((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0) + (double)area - (double)(iw * ih));
           const float ov = iw * ih / ua;
           float weight;
           if (method == 1) weight = ov > Nt ? 1 - ov : 1;

@@ -218,6 +218,26 @@ def test_soft_nms_rows_bit_exact_vs_oracle():
     assert np.array_equal(res, oracle.soft_nms(probs[4].copy(), 0.55, 0.3, 0.001, 2))
 
 
+def test_soft_and_hard_nms_reference_golden_bit_exact():
+    """soft_nms_kernel and the bitmask cpu_nms against outputs of the REFERENCE's compiled lib/nms/cpu_nms.pyx
+    (tests/golden/nms_v1.npz, generated by tests/golden/make_nms_golden.py): identical rows, order and float32 scores."""
+    import os
+    from sniper_amd.ext import cpu_nms
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms_v1.npz'))
+    n = int(z['soft_n'])
+    groups = {}
+    for i in range(n):
+        groups.setdefault(tuple(z['soft_par_%d' % i].tolist()), []).append(i)
+    for (sigma, Nt, thr, method), ids in groups.items():
+        got = cpu_nms.soft_nms_batch([z['soft_in_%d' % i].copy() for i in ids], sigma=sigma, Nt=Nt, threshold=thr, method=int(method))
+        for i, g in zip(ids, got):
+            want = z['soft_out_%d' % i]
+            assert g.shape == want.shape and np.array_equal(g, want), (i, method, thr, g.shape, want.shape)
+    for i in range(int(z['hard_n'])):
+        keep = cpu_nms.cpu_nms(z['hard_in_%d' % i], float(z['hard_thr_%d' % i]))
+        assert list(keep) == z['hard_keep_%d' % i].tolist(), i
+
+
 def test_focus_mask_golden_bit_exact():
     """AutoFocus FocusPixel labels (sn_focus_mask) against the masks the REFERENCE's anchor_worker produced
     (tests/golden/focus_mask_v1.npz), all chips in one launch."""

@@ -177,6 +177,26 @@ def test_soft_nms_known_answers():
     assert np.array_equal(out[:, 4], np.sort(d[:, 4])[::-1])
 
 
+def _nms_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms_v1.npz'))
+
+
+def test_soft_and_hard_nms_reference_golden():
+    """tests/golden/nms_v1.npz holds inputs and outputs of the REFERENCE's compiled lib/nms/cpu_nms.pyx
+    (tests/golden/make_nms_golden.py): 48 soft-NMS problems (3 methods, ties, duplicates, removals, n = 0..1000) and 10
+    hard cpu_nms problems.  Rows, order and float32 scores must be identical."""
+    z = _nms_golden()
+    for i in range(int(z['soft_n'])):
+        d = z['soft_in_%d' % i]
+        sigma, Nt, thr, method = z['soft_par_%d' % i]
+        want = z['soft_out_%d' % i]
+        got = oracle.soft_nms(d.copy(), sigma, Nt, thr, int(method)) if d.shape[0] else d
+        assert got.shape == want.shape and np.array_equal(got, want), i
+    for i in range(int(z['hard_n'])):
+        assert np.array_equal(oracle.cpu_nms(z['hard_in_%d' % i], float(z['hard_thr_%d' % i])), z['hard_keep_%d' % i]), i
+
+
 def test_focus_mask_golden():
     """AutoFocus FocusPixel labels (gen_mask, data_workers.py:165-192): the oracle's restatement against masks produced by
     the reference's own anchor_worker with TRAIN.AUTO_FOCUS (tests/golden/make_focus_golden.py)."""

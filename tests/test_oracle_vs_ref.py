@@ -143,3 +143,27 @@ def test_chip_extractor_box_assigner_anchor_worker(ref):
             assert np.array_equal(g[3], np.asarray(w[3], np.float32))
             n_chips += 1
     assert n_chips > 100
+
+
+def test_soft_and_hard_nms_match_cpu_nms_pyx():
+    """oracle soft-NMS / cpu_nms restatements against the reference's own lib/nms/cpu_nms.pyx, compiled by oracle/build.py
+    (cpu_soft_nms verbatim).  Found by this test: Cython promotes the `+ 1` beside C floats to a double literal, so `ua` is a
+    double sum rounded once -- float arithmetic is off by one ulp in ~40 % of the decayed scores."""
+    import sys
+    sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'golden'))
+    from make_nms_golden import load_ref_cpu_nms, problem
+    refnms = load_ref_cpu_nms()
+    rs = np.random.RandomState(5)
+    checked = 0
+    for n in (1, 3, 25, 120, 500):
+        for method in (0, 1, 2):
+            for thr, quant in ((0.001, None), (0.02, 25)):
+                d = problem(rs, n, quant)
+                want = np.asarray(refnms.cpu_soft_nms(d.copy(), 0.55, 0.3, thr, method), np.float32)
+                got = oracle.soft_nms(d.copy(), 0.55, 0.3, thr, method)
+                assert got.shape == want.shape and np.array_equal(got, want), (n, method, thr)
+                checked += 1
+        for thr in (0.3, 0.5, 0.7):
+            d = problem(rs, n, 40)
+            assert list(oracle.cpu_nms(d, thr)) == list(refnms.cpu_nms(d.copy(), thr)), (n, thr)
+    assert checked == 30
