@@ -272,6 +272,11 @@ int sn_sgd_mom_update_dev(float *w32, const float *grad, float *mom, void *w16, 
                           float wd_mult, sn_stream_t stream);
 /* fp32 [O][T][I] -> fp16 [I][T][O_pad] (weights for sn_conv_dgrad; O_pad = O rounded up to 8, zero filled). */
 int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, int T, int I, int O_pad, sn_stream_t stream);
+/* The same transposition for MANY weights in one launch (the optimizer step re-emits every data-gradient copy).  desc is a
+ * device array of n_desc 48-byte records {const float *src; void *dst; int O, T, I, O_pad, tile0, tiles_o, tiles_i, pad}
+ * with tiles_o = ceil(O_pad / 64), tiles_i = ceil(I / 64), tile0 = running sum of T * tiles_o * tiles_i (ascending);
+ * total_tiles = the final sum. */
+int sn_weight_transpose_batched(const void *desc, int n_desc, int total_tiles, sn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -830,6 +830,50 @@ SN_EXPORT int sn_weight_transpose(const float *w_oti, void *wt_ito_f16, int O, i
   return SN_OK;
 }
 
+// All transposed copies of a step in ONE launch: 64 x 64 tiles through LDS (coalesced 256-B reads of the fp32 masters,
+// 128-B writes of the fp16 copies) instead of one strided-read launch per weight (120 launches, 0.87 ms per R101 step).
+// desc[k] = {src, dst, O, T, I, Opad, tile0, tiles_o, tiles_i}; weight k owns tiles [tile0, tile0 + T*tiles_o*tiles_i).
+struct WtDesc {
+  const float *src;
+  half_t *dst;
+  int O, T, I, Opad, tile0, tiles_o, tiles_i, pad_;
+};
+static_assert(sizeof(WtDesc) == 48, "WtDesc layout is part of the C ABI (sn_weight_transpose_batched)");
+
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const WtDesc *__restrict__ desc, int nd) {
+  __shared__ float sm[64][65];
+  const int tile = blockIdx.x;
+  int lo = 0, hi = nd - 1;                 // last descriptor with tile0 <= tile
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+  }
+  const WtDesc d = desc[lo];
+  const int local = tile - d.tile0, per_t = d.tiles_o * d.tiles_i;
+  const int t = local / per_t, rem = local - t * per_t;
+  const int o0 = (rem / d.tiles_i) * 64, i0 = (rem % d.tiles_i) * 64;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int o = o0 + r + 4 * k, ci = i0 + c;
+    sm[r + 4 * k][c] = (o < d.O && ci < d.I) ? d.src[((size_t)o * d.T + t) * d.I + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int ci = i0 + r + 4 * k, o = o0 + c;
+    if (ci < d.I && o < d.Opad) d.dst[((size_t)ci * d.T + t) * d.Opad + o] = (half_t)sm[c][r + 4 * k];
+  }
+}
+
+SN_EXPORT int sn_weight_transpose_batched(const void *desc, int n_desc, int total_tiles, sn_stream_t stream) {
+  SN_REQUIRE(desc && n_desc > 0 && total_tiles > 0, "sn_weight_transpose_batched: bad arguments");
+  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, sn_stream(stream), (const WtDesc *)desc,
+                     n_desc);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
 // generic fp32 element-wise helpers for the small loss-side tensors: out = a (op) b
 // op 0: a - b, 1: a + b, 2: a * b, 3: a * scalar, 4: fill(scalar)
 __global__ __launch_bounds__(256) void ew_f32_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out,

@@ -100,6 +100,91 @@ __global__ __launch_bounds__(1024) void bitonic_sort_kernel(unsigned long long *
   }
 }
 
+// K2': only the `pre` best keys are ever used (pre_nms_top_n = 6000 of 21 504 anchors), and keys are unique (the anchor
+// index sits in the low word), so "the first K of the full sort" == "the K smallest keys, sorted":
+//   1. radix select, 8 bits per pass from the top: LDS histogram of the digit over the keys that match the decided prefix
+//      -> the K-th smallest key exactly (passes stop as soon as the boundary bucket is taken whole);
+//   2. compaction of the keys <= that key into LDS (any order), padded with ~0 to a power of two;
+//   3. bitonic sort of those <= 16 384 keys in LDS; the first K go back to keys[0..K).
+// One workgroup per image, every pass reads the image's keys (L2-resident, coalesced); 907 us -> see profiles/.
+constexpr int kSelThreads = 1024;
+__global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned long long *__restrict__ keys, int n, int K, int P2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sel_buf[];   // [P2]
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix, s_mask;
+  __shared__ int s_need, s_cnt, s_done;
+  unsigned long long *k = keys + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_need = K; s_cnt = 0; s_done = 0; }
+  __syncthreads();
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    if (s_done) break;
+    const unsigned long long prefix = s_prefix, mask = s_mask;
+    for (int i = tid; i < n; i += kSelThreads) {
+      const unsigned long long key = k[i];
+      const bool in = (key & mask) == prefix;
+      const unsigned d = (unsigned)(key >> shift) & 255u;
+      // scores cluster in a few exponent buckets: when the whole wave agrees, one atomic instead of 64 serialised ones
+      const unsigned long long act = __ballot(in);
+      if (act) {
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned d0 = (unsigned)__shfl((int)d, leader, 64);
+        const bool same = __ballot(in && d == d0) == act;
+        if (same) {
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d0], (unsigned)__popcll(act));
+        } else if (in) {
+          atomicAdd(&hist[d], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int need = s_need, d = 0;
+      unsigned cum = 0;
+      for (; d < 256; ++d) {
+        if (cum + hist[d] >= (unsigned)need) break;
+        cum += hist[d];
+      }
+      s_need = need - (int)cum;
+      s_prefix = prefix | ((unsigned long long)d << shift);
+      s_mask = mask | (0xFFull << shift);
+      if (hist[d] == (unsigned)(need - (int)cum)) {     // the whole boundary bucket is selected: largest key of it decides
+        s_done = 1;
+        s_prefix |= (shift ? ((1ull << shift) - 1ull) : 0ull);   // every key with this prefix is <= prefix | low ones
+        s_mask = ~0ull;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const unsigned long long kth = s_prefix;     // keys <= kth are exactly the K smallest
+  for (int i = tid; i < P2; i += kSelThreads) sel_buf[i] = ~0ull;
+  __syncthreads();
+  for (int i = tid; i < n; i += kSelThreads) {
+    const unsigned long long key = k[i];
+    if (key <= kth) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < P2) sel_buf[pos] = key;
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= P2; size <<= 1) {
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P2 >> 1); t += kSelThreads) {
+        const int lo = 2 * t - (t & (j - 1));
+        const int hi = lo + j;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = sel_buf[lo], c = sel_buf[hi];
+        if ((a > c) == up) { sel_buf[lo] = c; sel_buf[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < K; i += kSelThreads) k[i] = sel_buf[i];
+}
+
 // K3: gather the top `pre` boxes in score order -> sorted (B, pre, 5) = x1,y1,x2,y2,score; nvalid[b]
 __global__ __launch_bounds__(256) void proposal_gather_kernel(const float *__restrict__ boxes_all, const unsigned long long *__restrict__ keys,
                                                               int total, int sort_n, int pre, float *__restrict__ sorted,
@@ -206,7 +291,18 @@ static int proposal_common(const float *cls_prob, const float *bbox_pred, const 
   hipLaunchKernelGGL(proposal_decode_kernel, dim3(sn_div_up(L.sort_n, 256), B), dim3(256), 0, s, cls_prob, bbox_pred, im_info,
                      base_anchors, A, Fh, Fw, stride, min_size, L.total, L.sort_n, boxes_all, keys);
   SN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bitonic_sort_kernel, dim3(B), dim3(1024), 0, s, keys, L.sort_n);
+  const int P2 = next_pow2(L.pre);
+  if (P2 <= 16384 && L.pre < L.sort_n && !getenv("SNIPER_FULL_SORT")) {
+    static bool attr_done = false;       // > 64 KB of dynamic LDS needs the opt-in once per process
+    if (!attr_done) {
+      SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 16384 * 8));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(topk_select_sort_kernel, dim3(B), dim3(kSelThreads), (size_t)P2 * 8, s, keys, L.sort_n, L.pre, P2);
+  } else {
+    hipLaunchKernelGGL(bitonic_sort_kernel, dim3(B), dim3(1024), 0, s, keys, L.sort_n);
+  }
   SN_CHECK_LAUNCH();
   hipLaunchKernelGGL(proposal_gather_kernel, dim3(sn_div_up(L.pre, 256), B), dim3(256), 0, s, boxes_all, keys, L.total, L.sort_n,
                      L.pre, sorted, nvalid);

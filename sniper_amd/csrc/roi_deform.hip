@@ -50,7 +50,59 @@ __device__ __forceinline__ RoiGeom roi_geom(const float *__restrict__ rois, cons
   return g;
 }
 
-__device__ __forceinline__ float sample_pos(float start, int i, float sub);
+__device__ __forceinline__ float sample_pos(float start, int i, float sub) { return __fmaf_rn((float)i, sub, start); }
+
+// x-/y-samples of one bin: clamped coordinates of the valid ones and the cell range they touch.  A sample (ih, iw) counts
+// iff its x AND its y are valid, so the S x S grid factorises: out = sum_y sum_x Wy(y) Wx(x) data[y][x] / (nvx nvy) with
+// Wx(x) = sum over the valid x-samples of the bilinear tent max(0, 1 - |x - w|) -- every cell of the window is read ONCE
+// instead of once per sample corner (S*S*4 = 64 gathers per bin shrink to the 4..36 distinct cells: the forward was
+// bound by L2 gather traffic, 9.6 GB per call at R = 6000).
+constexpr int kMaxS = 8;
+struct AxisSamples {
+  float p[kMaxS];   // clamped coordinate of sample i (meaningful where bit i of `mask` is set)
+  unsigned mask;
+  int n, lo, hi;
+};
+__device__ __forceinline__ AxisSamples axis_samples(float start, float sub, int S, int dim) {
+  AxisSamples a;
+  a.n = 0;
+  a.mask = 0u;
+  float mn = 1e30f, mx = -1e30f;
+#pragma unroll
+  for (int i = 0; i < kMaxS; ++i) {
+    float w = sample_pos(start, i, sub);
+    const bool ok = i < S && !(w < -0.5f || w > (float)dim - 0.5f);
+    w = fminf(fmaxf(w, 0.f), (float)dim - 1.f);
+    a.p[i] = w;
+    if (ok) {
+      a.mask |= 1u << i;
+      ++a.n;
+      mn = fminf(mn, w);
+      mx = fmaxf(mx, w);
+    }
+  }
+  a.lo = a.n ? (int)floorf(mn) : 0;
+  a.hi = a.n ? (int)ceilf(mx) : -1;
+  return a;
+}
+__device__ __forceinline__ float tent_sum(const AxisSamples &a, int x) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxS; ++i)
+    if ((a.mask >> i) & 1u) s += fmaxf(0.f, 1.f - fabsf((float)x - a.p[i]));
+  return s;
+}
+// d/dw of the tent sum: +1 on the sample's upper cell, -1 on its lower cell (nothing when the sample sits on a cell)
+__device__ __forceinline__ float tent_dsum(const AxisSamples &a, int x) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxS; ++i)
+    if ((a.mask >> i) & 1u) {
+      const int lo = (int)floorf(a.p[i]), hi = (int)ceilf(a.p[i]);
+      s += (hi != lo) ? ((x == hi ? 1.f : 0.f) - (x == lo ? 1.f : 0.f)) : 0.f;
+    }
+  return s;
+}
 
 __global__ __launch_bounds__(256) void dpsroi_fwd_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
                                                          const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
@@ -64,28 +116,24 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_kernel(const half_t *__restric
     const int ph = (int)(t % P);
     const int r = (int)(t / P);
     const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+    const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
     const half_t *img = data + (size_t)g.b * H * W * C + ch;
     float sum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) sum[j] = 0.f;
-    int count = 0;
-    for (int ih = 0; ih < S; ++ih) {
-      for (int iw = 0; iw < S; ++iw) {
-        float w = sample_pos(g.wstart, iw, g.sub_w), h = sample_pos(g.hstart, ih, g.sub_h);
-        if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) continue;
-        w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
-        h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
-        const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
-        const float dx = w - (float)x0, dy = h - (float)y0;
-        const half8 v00 = *reinterpret_cast<const half8 *>(img + ((size_t)y0 * W + x0) * C);
-        const half8 v01 = *reinterpret_cast<const half8 *>(img + ((size_t)y0 * W + x1) * C);
-        const half8 v10 = *reinterpret_cast<const half8 *>(img + ((size_t)y1 * W + x0) * C);
-        const half8 v11 = *reinterpret_cast<const half8 *>(img + ((size_t)y1 * W + x1) * C);
-        const float w00 = (1.f - dx) * (1.f - dy), w01 = dx * (1.f - dy), w10 = (1.f - dx) * dy, w11 = dx * dy;
+    const int count = ax.n * ay.n;
+    if (count) {
+      for (int y = ay.lo; y <= ay.hi; ++y) {
+        const float wy = tent_sum(ay, y);
+        if (wy == 0.f) continue;
+        const half_t *row = img + (size_t)y * W * C;
+        for (int x = ax.lo; x <= ax.hi; ++x) {
+          const float wgt = wy * tent_sum(ax, x);
+          if (wgt == 0.f) continue;
+          const half8 v = *reinterpret_cast<const half8 *>(row + (size_t)x * C);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          sum[j] += w00 * (float)v00[j] + w01 * (float)v01[j] + w10 * (float)v10[j] + w11 * (float)v11[j];
-        ++count;
+          for (int j = 0; j < 8; ++j) sum[j] += wgt * (float)v[j];
+        }
       }
     }
     const float inv = count ? 1.f / (float)count : 0.f;
@@ -107,8 +155,6 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_kernel(const half_t *__restric
 //                the 4x4 sample grid factorises) -> compacted entry list in LDS;
 //       phase B: every thread (channel) walks the entries: one 2-byte load of dout, 16 FMAs.
 //   dpsroi_bwd_trans_kernel: d_trans is a gather (like the forward), reduced over the channels with shuffles.
-__device__ __forceinline__ float sample_pos(float start, int i, float sub) { return __fmaf_rn((float)i, sub, start); }
-
 // adds the bilinear weights of the (already clamped) coordinate w onto the 4 tile cells t0..t0+3
 __device__ __forceinline__ void tent4(float w, int t0, float W4[4]) {
   const int a = (int)floorf(w), b = (int)ceilf(w);
@@ -292,7 +338,9 @@ __global__ __launch_bounds__(256) void dpsroi_bwd_data_kernel(const half_t *__re
 }
 
 // d_trans (R,2,P,P): one thread per (r, ph, pw, 8-channel chunk), segmented shuffle reduction over the C/8 lanes
-// that share a bin, one plain store per (r,ph,pw,xy).
+// that share a bin, one plain store per (r,ph,pw,xy).  Same window factorisation as the forward:
+//   d out / d tx = roi_w * trans_std / count * sum_y sum_x Wy(y) DWx(x) data[y][x],  DWx = +1 / -1 on a sample's upper / lower cell
+// (and x <-> y for ty), so each cell of the window is read once for both derivatives.
 __global__ __launch_bounds__(256) void dpsroi_bwd_trans_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                const float *__restrict__ rois, const float *__restrict__ trans,
                                                                float *__restrict__ d_trans, int R, int H, int W, int C, int P, int S,
@@ -308,29 +356,26 @@ __global__ __launch_bounds__(256) void dpsroi_bwd_trans_kernel(const half_t *__r
   const int ph = (int)(t % P);
   const int r = (int)(t / P);
   const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-  const size_t img_off = (size_t)g.b * H * W * C + ch;
+  const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+  const half_t *img = data + (size_t)g.b * H * W * C + ch;
   const half8 go = *reinterpret_cast<const half8 *>(dout + ii * 8);
   float gtx = 0.f, gty = 0.f;
-  int count = 0;
-  for (int ih = 0; ih < S; ++ih) {
-    for (int iw = 0; iw < S; ++iw) {
-      float w = sample_pos(g.wstart, iw, g.sub_w), h = sample_pos(g.hstart, ih, g.sub_h);
-      if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) continue;
-      ++count;
-      w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
-      h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
-      const int xa = (int)floorf(w), xb = (int)ceilf(w), ya = (int)floorf(h), yb = (int)ceilf(h);
-      const float dx = w - (float)xa, dy = h - (float)ya;
-      const half8 u00 = *reinterpret_cast<const half8 *>(data + img_off + ((size_t)ya * W + xa) * C);
-      const half8 u01 = *reinterpret_cast<const half8 *>(data + img_off + ((size_t)ya * W + xb) * C);
-      const half8 u10 = *reinterpret_cast<const half8 *>(data + img_off + ((size_t)yb * W + xa) * C);
-      const half8 u11 = *reinterpret_cast<const half8 *>(data + img_off + ((size_t)yb * W + xb) * C);
+  const int count = ax.n * ay.n;
+  if (count) {
+    for (int y = ay.lo; y <= ay.hi; ++y) {
+      const float wy = tent_sum(ay, y), dwy = tent_dsum(ay, y);
+      if (wy == 0.f && dwy == 0.f) continue;
+      const half_t *row = img + (size_t)y * W * C;
+      for (int x = ax.lo; x <= ax.hi; ++x) {
+        const float wx = tent_sum(ax, x), dwx = tent_dsum(ax, x);
+        const float kx = wy * dwx, ky = dwy * wx;
+        if (kx == 0.f && ky == 0.f) continue;
+        const half8 u = *reinterpret_cast<const half8 *>(row + (size_t)x * C);
+        float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float dv = (float)go[j];
-        const float U00 = (float)u00[j], U01 = (float)u01[j], U10 = (float)u10[j], U11 = (float)u11[j];
-        gtx += (U11 * dy + U01 * (1.f - dy) - U10 * dy - U00 * (1.f - dy)) * dv;
-        gty += (U11 * dx + U10 * (1.f - dx) - U01 * dx - U00 * (1.f - dx)) * dv;
+        for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
+        gtx += kx * dot;
+        gty += ky * dot;
       }
     }
   }
@@ -354,7 +399,8 @@ static long blocks_for(long total) {
 
 SN_EXPORT int sn_dpsroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int C,
                                  int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream) {
-  SN_REQUIRE(data && rois && out && R > 0 && C % 8 == 0 && pooled > 0 && sample_per_part > 0, "sn_dpsroi_pool_fwd: bad arguments");
+  SN_REQUIRE(data && rois && out && R > 0 && C % 8 == 0 && pooled > 0 && sample_per_part > 0 && sample_per_part <= kMaxS,
+             "sn_dpsroi_pool_fwd: bad arguments (sample_per_part <= %d)", kMaxS);
   hipLaunchKernelGGL(dpsroi_fwd_kernel, dim3((unsigned)blocks_for((long)R * pooled * pooled * (C / 8))), dim3(256), 0,
                      sn_stream(stream), (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part,
                      spatial_scale, trans_std);
@@ -369,7 +415,8 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
                                  int sample_per_part, float spatial_scale, float trans_std, void *ws, sn_stream_t stream) {
   SN_REQUIRE(dout && data && rois && d_data && ws && R > 0 && B > 0 && C > 0 && pooled > 0 && sample_per_part > 0,
              "sn_dpsroi_pool_bwd: bad arguments");
-  SN_REQUIRE(H < 65536 && W < 65536 && pooled * pooled <= 256, "sn_dpsroi_pool_bwd: H, W < 65536 and pooled <= 16 required");
+  SN_REQUIRE(H < 65536 && W < 65536 && pooled * pooled <= 256 && sample_per_part <= kMaxS,
+             "sn_dpsroi_pool_bwd: H, W < 65536, pooled <= 16 and sample_per_part <= %d required", kMaxS);
   SN_REQUIRE(!trans || d_trans, "sn_dpsroi_pool_bwd: d_trans required with trans");
   hipStream_t s = sn_stream(stream);
   int4 *win = (int4 *)ws;

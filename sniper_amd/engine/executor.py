@@ -120,6 +120,7 @@ class Executor(object):
         self.ws = hip.Workspace()
         self._const = {}
         self._bn_cache_valid = False
+        self._wt_tables = {}
         self.num_update = 0
         self._lower()
         self._alloc_params()
@@ -402,16 +403,49 @@ class Executor(object):
                 continue
             if not (only_trainable and p.trainable):  # trainable w16 is written by the SGD kernel
                 hip.call('sn_copy2d', p.master, p.w16, 1, p.numel, p.numel, p.numel, 1, 0, hip.stream())
-            if p.wT16 is not None:
-                o, t, i = p.int_shape
-                if p.kind == 'fc':
-                    # an FC over a pooled (h, w, c) tensor is a 1x1 GEMM whose K index is the flat (hw, c) feature:
-                    # its data gradient needs W^T as [hw*C + c][O], not the convolution's [c][tap][O]
-                    t, i = 1, t * i
-                hip.call('sn_weight_transpose', p.master, p.wT16, o, t, i, _pad8(o), hip.stream())
+        self._transpose_weights(only_trainable)
         self._bn_cache_valid = False
         for s in self.steps:
             s.params_changed(only_trainable)
+
+    def transpose_jobs(self, only_trainable):
+        """(master, dst, O, T, I) of every transposed data-gradient copy: the parameters' own plus what the steps add."""
+        jobs = []
+        for p in self.params.values():
+            if p.wT16 is None or (only_trainable and not p.trainable):
+                continue
+            o, t, i = p.int_shape
+            if p.kind == 'fc':
+                # an FC over a pooled (h, w, c) tensor is a 1x1 GEMM whose K index is the flat (hw, c) feature:
+                # its data gradient needs W^T as [hw*C + c][O], not the convolution's [c][tap][O]
+                t, i = 1, t * i
+            jobs.append((p.master, p.wT16, o, t, i))
+        for s in self.steps:
+            jobs.extend(s.transpose_jobs(only_trainable))
+        return jobs
+
+    def _transpose_weights(self, only_trainable):
+        """One sn_weight_transpose_batched launch over a device-resident descriptor table (built once per variant: the
+        buffers never move, and the optimizer graph captures the launch)."""
+        key = bool(only_trainable)
+        tab = self._wt_tables.get(key)
+        if tab is None:
+            jobs = self.transpose_jobs(only_trainable)
+            rec = np.zeros(len(jobs), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('O', '<i4'), ('T', '<i4'), ('I', '<i4'),
+                                                     ('Opad', '<i4'), ('tile0', '<i4'), ('tiles_o', '<i4'), ('tiles_i', '<i4'),
+                                                     ('pad', '<i4')]))
+            assert rec.dtype.itemsize == 48
+            tile0 = 0
+            for k, (src, dst, o, t, i) in enumerate(jobs):
+                opad = _pad8(o)
+                to, ti = (opad + 63) // 64, (i + 63) // 64
+                rec[k] = (src.data_ptr(), dst.data_ptr(), o, t, i, opad, tile0, to, ti, 0)
+                tile0 += t * to * ti
+            dev = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device) if len(jobs) else None
+            tab = self._wt_tables[key] = (dev, len(jobs), tile0, jobs)      # jobs kept: they own the tensors behind the pointers
+        dev, n, tiles, _ = tab
+        if n:
+            hip.call('sn_weight_transpose_batched', dev, n, tiles, hip.stream())
 
     # ------------------------------------------------------------------------------------------
     # run

@@ -69,6 +69,10 @@ class Step(object):
     def params_changed(self, only_trainable=False):
         pass
 
+    def transpose_jobs(self, only_trainable=False):
+        """extra (master, dst, O, T, I) transposed weight copies this step needs (Executor.transpose_jobs)"""
+        return []
+
 
 # ---------------------------------------------------------------------------------------------
 # BatchNorm (+ fused ReLU when the only consumer is Activation(relu))
@@ -471,12 +475,13 @@ class DeformableConvolutionStep(Step):
         self.col = ex.empty((self.N * self.Ho * self.Wo, self.T * self.C), F16)
         self.wT_flat = None
 
-    def params_changed(self, only_trainable=False):
-        if self.ex.for_training:
-            o = self.O
-            if self.wT_flat is None:
-                self.wT_flat = self.ex.zeros((self.T * self.C, 1, _pad8(o)), F16)
-            hip.call('sn_weight_transpose', self.w.master, self.wT_flat, o, 1, self.T * self.C, _pad8(o), hip.stream())
+    def transpose_jobs(self, only_trainable=False):
+        """the deformable convolution's data gradient is a 1x1 GEMM over the (tap, channel) column: W^T as [T*C][O]"""
+        if not self.ex.for_training or (only_trainable and not self.w.trainable):
+            return []
+        if self.wT_flat is None:
+            self.wT_flat = self.ex.zeros((self.T * self.C, 1, _pad8(self.O)), F16)
+        return [(self.w.master, self.wT_flat, self.O, 1, self.T * self.C)]
 
     def forward(self):
         ex = self.ex

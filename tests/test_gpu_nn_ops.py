@@ -339,6 +339,35 @@ def test_sgd_and_weight_transpose():
     assert torch.equal(wp[..., :O], wt) and float(wp[..., O:].abs().sum()) == 0
 
 
+def test_weight_transpose_batched_equals_single():
+    """sn_weight_transpose_batched (one launch, LDS-tiled) against sn_weight_transpose per weight: ragged O / I, taps, O_pad."""
+    hip = _hip()
+    rs = np.random.RandomState(31)
+    shapes = [(256, 9, 256), (42, 1, 512), (1024, 1, 64), (81, 49, 24), (7, 3, 200), (512, 9, 3072 // 8)]
+    srcs = [torch.from_numpy(rs.standard_normal(sh).astype(np.float32)).to(dev()) for sh in shapes]
+    pad8 = lambda n: (n + 7) // 8 * 8
+    want, dsts = [], []
+    rec = np.zeros(len(shapes), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('O', '<i4'), ('T', '<i4'), ('I', '<i4'), ('Opad', '<i4'),
+                                                ('tile0', '<i4'), ('tiles_o', '<i4'), ('tiles_i', '<i4'), ('pad', '<i4')]))
+    tile0 = 0
+    for k, ((o, t, i), src) in enumerate(zip(shapes, srcs)):
+        w = torch.full((i, t, pad8(o)), 7.0, dtype=torch.float16, device=dev())
+        hip.call('sn_weight_transpose', src, w, o, t, i, pad8(o), hip.stream())
+        want.append(w)
+        d = torch.full((i, t, pad8(o)), 7.0, dtype=torch.float16, device=dev())
+        dsts.append(d)
+        to, ti = (pad8(o) + 63) // 64, (i + 63) // 64
+        rec[k] = (src.data_ptr(), d.data_ptr(), o, t, i, pad8(o), tile0, to, ti, 0)
+        tile0 += t * to * ti
+    desc = torch.from_numpy(rec.view(np.uint8).copy()).to(dev())
+    hip.call('sn_weight_transpose_batched', desc, len(shapes), tile0, hip.stream())
+    torch.cuda.synchronize()
+    for (o, t, i), w, d, src in zip(shapes, want, dsts, srcs):
+        assert torch.equal(w, d), (o, t, i)
+        assert torch.equal(d[:, :, :o].float(), src.half().float().permute(2, 1, 0))
+        assert float(d[:, :, o:].abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize('Fh,Fw', [(16, 16), (12, 20)])
 def test_multi_proposal_target_vs_oracle(Fh, Fw):
     """Square training chips and the non-square feature maps of test images."""
@@ -385,6 +414,42 @@ def test_multi_proposal_target_vs_oracle(Fh, Fw):
              rois2, sc, hip.stream())
     assert torch.equal(rois2, rois)
     assert_close(sc.cpu().numpy(), want_scores, 1e-6, 1e-6, 'roi scores')
+
+
+@pytest.mark.parametrize('A,Fh,Fw,pre,quant', [(21, 32, 32, 6000, 0), (21, 32, 32, 6000, 64), (15, 16, 16, 6000, 8), (21, 40, 56, 6000, 0),
+                                                (3, 4, 5, 20, 4)])
+def test_proposal_topk_select_equals_full_sort(A, Fh, Fw, pre, quant, monkeypatch):
+    """The proposal ordering (radix select of the pre_nms_top_n best keys + LDS sort) must produce exactly the RoIs of the
+    full sort: R101 training size, heavily tied scores (quantised probabilities, min_size rejections -> score -1),
+    pre >= total (MobileNetV2: every anchor selected), a non-square test-image map, a tiny map."""
+    hip = _hip()
+    rs = np.random.RandomState(A * Fh + quant)
+    B, stride, post = 3, 16, 300
+    p1 = rs.uniform(0, 1, (B, 1, A * Fh, Fw))
+    if quant:
+        p1 = np.round(p1 * quant) / quant
+    cls_prob = np.concatenate((1 - p1, p1), 1).astype(np.float32)
+    bbox_pred = (rs.standard_normal((B, 4 * A, Fh, Fw)) * 0.5).astype(np.float32)
+    im_info = np.array([[Fh * 16, Fw * 16, 1.0]] * B, np.float32)
+    from sniper_amd.data.anchors import generate_anchors
+    scales = (2, 4, 7, 10, 13, 16, 24)[:A // 3]
+    base = generate_anchors(stride, [0.5, 1, 2], np.array(scales, np.float32)).astype(np.float32)
+    td = lambda z: torch.from_numpy(np.ascontiguousarray(z)).to(dev())
+    post = min(post, pre, A * Fh * Fw)
+    ws = torch.empty(hip.query('sn_proposal_workspace_bytes', B, A, Fh, Fw, pre, post), dtype=torch.uint8, device=dev())
+    outs = []
+    for full in ('1', None):
+        if full:
+            monkeypatch.setenv('SNIPER_FULL_SORT', full)
+        else:
+            monkeypatch.delenv('SNIPER_FULL_SORT', raising=False)
+        rois, sc = torch.empty((B * post, 5), device=dev()), torch.empty((B * post,), device=dev())
+        hip.call('sn_multi_proposal', td(cls_prob), td(bbox_pred), td(im_info), td(base), B, A, Fh, Fw, stride, pre, post, 0.7, 24.0, ws,
+                 rois, sc, hip.stream())
+        torch.cuda.synchronize()
+        outs.append((rois.clone(), sc.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][1].max()) > 0
 
 
 @pytest.mark.parametrize('B,C,H,W,R,SC', [(2, 64, 12, 12, 9, 16), (3, 256, 10, 14, 40, 16), (2, 128, 16, 16, 600, 32)])
