@@ -60,7 +60,8 @@ def test_r101_test_and_rpn_graphs():
 
 
 @pytest.mark.ref
-def test_same_graph_as_reference_symbol_file():
+@pytest.mark.parametrize('name', ['resnet_mx_101_e2e', 'resnet_mx_50_e2e'])
+def test_same_graph_as_reference_symbol_file(name):
     import sniper_amd.mx as mx
     mx.alias_as('mxnet')
     for p in ('/root/reference', '/root/reference/lib', '/root/reference/symbols/faster'):
@@ -68,12 +69,13 @@ def test_same_graph_as_reference_symbol_file():
             sys.path.insert(0, p)
     import importlib
     sys.dont_write_bytecode = True
-    refmod = importlib.import_module('resnet_mx_101_e2e')
+    refmod = importlib.import_module(name)
+    ourmod = importlib.import_module('sniper_amd.symbols.faster.' + name)
     B = 2
     for train in (True, False):
         cfg = _cfg(B)
-        a = refmod.resnet_mx_101_e2e(n_proposals=400, momentum=0.995, test_nbatch=B)
-        b = ours.resnet_mx_101_e2e(n_proposals=400, momentum=0.995, test_nbatch=B)
+        a = getattr(refmod, name)(n_proposals=400, momentum=0.995, test_nbatch=B)
+        b = getattr(ourmod, name)(n_proposals=400, momentum=0.995, test_nbatch=B)
         from sniper_amd.mx import symbol as _symmod
         _symmod._counter().clear()          # auto-names (blockgrad0, _plus0, pooling0 ...) count per graph build
         sa = a.get_symbol_rcnn(cfg, is_train=train)

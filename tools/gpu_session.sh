@@ -31,6 +31,8 @@ if [[ $WHAT == all || $WHAT == bench ]]; then
   find "$ROOT/gpurun_out/prof_bench" -name "*stats*" | head
   F=$(find "$ROOT/gpurun_out/prof_bench" -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && head -40 "$F"
+  T=$(find "$ROOT/gpurun_out/prof_bench" -name "*kernel_trace.csv" | head -1)
+  [ -n "$T" ] && python "$ROOT/tools/trace_gaps.py" "$T" "$ROOT/gpurun_out/trace_gaps.json" --lo 0.45 --hi 0.75
   # the raw kernel trace is large; keep only the stats
   find "$ROOT/gpurun_out/prof_bench" -name "*kernel_trace.csv" -size +20M -delete
 fi
