@@ -141,6 +141,23 @@ def infer_node(node, ins, shapes_of_var):
         post = int(a.get('rpn_post_nms_top_n', 300))
         r = cp[0] * post
         return [(r, 5), (r,), (r, 4), (r, 4)], par
+    if op == 'MultiProposalTargetMask':     # + the mask RoIs of every chip and the gt_boxes row each one matched
+        cp = ins[0]
+        post, nm = int(a.get('rpn_post_nms_top_n', 300)), int(a.get('num_mask_rois', 50))
+        r = cp[0] * post
+        return [(r, 5), (r,), (r, 4), (r, 4), (cp[0] * nm, 5), (cp[0] * nm,)], par
+    if op == 'MaskRcnnTarget':
+        r = ins[pos['rois']]
+        ms = int(a.get('mask_size', 28))
+        return [(r[0], ms, ms), (r[0],)], par
+    if op == 'pick':
+        x = ins[pos['data']]
+        axis = int(a.get('axis', -1)) % len(x)
+        keep = _bool(a.get('keepdims', False))
+        out = tuple(1 if i == axis else d for i, d in enumerate(x)) if keep else tuple(d for i, d in enumerate(x) if i != axis)
+        if 'index' in pos and ins[pos['index']] is None:
+            par[pos['index']] = tuple(d for i, d in enumerate(x) if i != axis)
+        return [out], par
     if op == 'Custom':
         from ..mx import operator as _operator
         prop = _operator.get_prop(a.get('op_type'), a)

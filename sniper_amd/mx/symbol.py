@@ -87,12 +87,16 @@ _OPS = {
     'DeformablePSROIPooling': (['data', 'rois', 'trans'], [], 1),
     'MultiProposal': (['cls_prob', 'bbox_pred', 'im_info'], [], 2),
     'MultiProposalTarget': (['cls_prob', 'bbox_pred', 'im_info', 'gt_boxes', 'valid_ranges', 'crowd_boxes'], [], 4),
-    'MultiProposalTargetMask': (['cls_prob', 'bbox_pred', 'im_info', 'gt_boxes', 'valid_ranges', 'gt_masks'], [], 5),
+    # mask branch (symbols/faster/resnet_mx_101_e2e_mask.py:317-318,392-399)
+    'MultiProposalTargetMask': (['cls_prob', 'bbox_pred', 'im_info', 'gt_boxes', 'valid_ranges'], [], 6),
+    'MaskRcnnTarget': (['rois', 'mask_polys', 'mask_ids'], [], 2),
     'pick': (['data', 'index'], [], 1),
 }
 _OUT_NAMES = {
     'MultiProposal': ['output', 'score'],
     'MultiProposalTarget': ['output', 'label', 'bbox_target', 'bbox_weight'],
+    'MultiProposalTargetMask': ['output', 'label', 'bbox_target', 'bbox_weight', 'mask_rois', 'mask_ids'],
+    'MaskRcnnTarget': ['mask_targets', 'mask_cls'],
 }
 _PARAM_INPUTS = {'weight', 'bias', 'gamma', 'beta'}
 _HINTS = {'_plus': '_plus', '_minus': '_minus', '_mul': '_mul', 'elemwise_add': 'elemwise_add'}
@@ -292,7 +296,7 @@ def _create(op, pos_inputs, kwargs):
         if k in given:
             inputs.append(_single(given[k], op))
             continue
-        if k == 'bias' and _bool(attrs.get('no_bias', op == 'DeformableConvolution' and False)):
+        if k == 'bias' and _bool(attrs.get('no_bias', op == 'Deconvolution')):    # MXNet: Deconvolution defaults to no_bias
             continue
         if k in _PARAM_INPUTS:
             v = Variable('%s_%s' % (name, k))
@@ -318,7 +322,7 @@ def _create(op, pos_inputs, kwargs):
     for k in in_names:
         if k in given:
             slots.append(k)
-        elif k == 'bias' and _bool(attrs.get('no_bias', False)):
+        elif k == 'bias' and _bool(attrs.get('no_bias', op == 'Deconvolution')):
             continue
         elif k in _PARAM_INPUTS:
             slots.append(k)

@@ -111,12 +111,17 @@ class resnet_mx_101_e2e(Symbol):
         return cls, box
 
     def _trunk(self, cfg, data):
+        """-> (C4 features, concat(C4, C5) [fp32])"""
         feat = self.resnetc4(data, fp16=cfg.TRAIN.fp16)
         top = self.resnetc5(feat, deform=True)
         cat = mx.sym.Concat(feat, top, name='cat4')
         if cfg.TRAIN.fp16:
             cat = mx.sym.Cast(data=cat, dtype=np.float32)
-        return cat
+        return feat, cat
+
+    def _rpn(self, feat, cat, num_anchors):
+        """the RPN reads the concatenated map here (:254); the mask variant reads C4 (resnet_mx_101_e2e_mask.py:291)"""
+        return self.get_rpn(cat, num_anchors)
 
     def _scale(self, cfg):
         return float(cfg.TRAIN.scale) if cfg.TRAIN.fp16 else 1.0
@@ -135,6 +140,15 @@ class resnet_mx_101_e2e(Symbol):
                     rpn_min_size=cfg.TEST.RPN_MIN_SIZE, threshold=cfg.TEST.RPN_NMS_THRESH,
                     feature_stride=cfg.network.RPN_FEAT_STRIDE, ratios=tuple(cfg.network.ANCHOR_RATIOS),
                     scales=tuple(cfg.network.ANCHOR_SCALES))
+
+    def _proposal_target(self, cfg, rpn_prob, box, im_info, gt_boxes, valid_ranges):
+        """-> (rois, label, bbox_target, bbox_weight, *variant extras)  (:283-284)"""
+        return tuple(mx.sym.MultiProposalTarget(cls_prob=rpn_prob, bbox_pred=box, im_info=im_info, gt_boxes=gt_boxes,
+                                                valid_ranges=valid_ranges, batch_size=cfg.TRAIN.BATCH_IMAGES,
+                                                name='multi_proposal_target'))
+
+    def _extra_train_outputs(self, cfg, feat, extras, grad_scale):
+        return []
 
     def _head(self, feat, rois, num_classes):
         """conv_new_1 features -> offset branch -> deformable PS-RoI pooling -> 2 FC -> cls / bbox (:286-303)."""
@@ -156,8 +170,8 @@ class resnet_mx_101_e2e(Symbol):
     def get_symbol_rpn(self, cfg, is_train=True):
         A = cfg.network.NUM_ANCHORS
         data = mx.sym.Variable(name='data')
-        cat = self._trunk(cfg, data)
-        cls, box = self.get_rpn(cat, A)
+        feat4, cat = self._trunk(cfg, data)
+        cls, box = self._rpn(feat4, cat, A)
         cls_r = mx.sym.Reshape(data=cls, shape=(0, 2, -1, 0), name='rpn_cls_score_reshape')
         if is_train:
             prob, loss = self._rpn_losses(cfg, cls_r, box, mx.sym.Variable(name='label'), mx.sym.Variable(name='bbox_target'),
@@ -183,8 +197,8 @@ class resnet_mx_101_e2e(Symbol):
             scale_label = mx.sym.Variable(name='scale_label') if cfg.TRAIN.AUTO_FOCUS else None
         else:
             im_info, im_ids, chip_ids = (mx.sym.Variable(name=n) for n in ('im_info', 'im_ids', 'chip_ids'))
-        cat = self._trunk(cfg, data)
-        cls, box = self.get_rpn(cat, A)
+        feat4, cat = self._trunk(cfg, data)
+        cls, box = self._rpn(feat4, cat, A)
         feat = mx.sym.Activation(data=mx.sym.Convolution(data=cat, kernel=(1, 1), num_filter=256, name='conv_new_1'),
                                  act_type='relu', name='conv_new_1_relu')
         focus = None
@@ -198,9 +212,8 @@ class resnet_mx_101_e2e(Symbol):
         if is_train:
             gs = self._scale(cfg)
             rpn_prob, rpn_loss = self._rpn_losses(cfg, cls_r, box, label, target, weight)
-            rois, rlabel, rtarget, rweight = mx.sym.MultiProposalTarget(
-                cls_prob=rpn_prob, bbox_pred=box, im_info=im_info, gt_boxes=gt_boxes, valid_ranges=valid_ranges,
-                batch_size=cfg.TRAIN.BATCH_IMAGES, name='multi_proposal_target')
+            pt = self._proposal_target(cfg, rpn_prob, box, im_info, gt_boxes, valid_ranges)
+            rois, rlabel, rtarget, rweight = pt[:4]
             rlabel = mx.sym.Reshape(data=rlabel, shape=(-1,), name='label_reshape')
             score, bpred = self._head(feat, rois, C)
             prob = mx.sym.SoftmaxOutput(name='cls_prob', data=score, label=rlabel, normalization='valid', use_ignore=True,
@@ -215,6 +228,7 @@ class resnet_mx_101_e2e(Symbol):
             outs.append(mx.sym.Reshape(data=prob, shape=(cfg.TRAIN.BATCH_IMAGES, -1, C), name='cls_prob_reshape'))
             outs.append(mx.sym.Reshape(data=bloss, shape=(cfg.TRAIN.BATCH_IMAGES, -1, 4), name='bbox_loss_reshape'))
             outs.append(mx.sym.BlockGrad(rlabel))
+            outs += self._extra_train_outputs(cfg, feat, pt[4:], gs)
             group = mx.sym.Group(outs)
         else:
             prob = mx.sym.SoftmaxActivation(data=cls_r, mode='channel', name='rpn_cls_prob')
