@@ -28,6 +28,7 @@ import sniper_amd.mx as mx
 from .. import hip
 from ..data.anchors import AnchorAssigner
 from ..data.chip_worker import chip_worker
+from ..data.mask_utils import encode_chip_masks
 
 
 def synthetic_im_source(chip_hw):
@@ -52,7 +53,7 @@ class MNIteratorE2E(mx.io.DataIter):
         if config.TRAIN.AUTO_FOCUS:
             self.label_name.append('scale_label')      # FocusPixel labels (reference :28-29)
         if config.TRAIN.WITH_MASK:
-            raise NotImplementedError('mask branch is out of scope (SURVEY.md 8(f).3)')
+            self.label_name.append('gt_masks')         # encoded polygons (B, 100, 500) (reference :31-32)
         self.chip_worker = chip_worker(config, crop_size[0])
         self.anchors = AnchorAssigner(config, crop_size[0])
         self.im_source = im_source or synthetic_im_source(crop_size)
@@ -178,6 +179,10 @@ class MNIteratorE2E(mx.io.DataIter):
             self.label.append(mx.nd.NDArray(out['gt_boxes']))
         if self.cfg.TRAIN.AUTO_FOCUS:
             self.label.append(mx.nd.NDArray(self.anchors.focus_mask(worker_data)))      # scale_label (B, F*F), :182-197,213-214
+        if self.cfg.TRAIN.WITH_MASK:                   # reference :186,199-200,216-217 (anchor_worker.worker :231-257)
+            enc = np.stack([encode_chip_masks(w[0], w[1], w[2], w[5], w[7], r['gt_masks'])
+                            for w, r in zip(worker_data, roidb)])
+            self.label.append(mx.nd.NDArray(torch.from_numpy(enc).to(dev)))
         batch = mx.io.DataBatch(data=self.data, label=self.label, pad=0, index=self.getindex(),
                                 provide_data=self.provide_data, provide_label=self.provide_label)
         batch.worker_data = worker_data   # the anchor-labelling inputs (bench.py re-runs the labelling per step)

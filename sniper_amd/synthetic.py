@@ -26,9 +26,27 @@ def _iou_max(boxes, gts):
     return (inter / (a[:, None] + b[None, :] - inter)).max(axis=1).astype(np.float32)
 
 
-def make_roidb(n_images=5000, seed=0, n_proposals=0, num_classes=81):
+def make_polygons(rs, box, long_prob=0.03):
+    """COCO-style segmentation of one object (lib/dataset/coco.py:244-255): 1-3 polygons, each a flat
+    [x0, y0, x1, y1, ...] list of a noisy ellipse inscribed in (a part of) the box; now and then a polygon with hundreds of
+    vertices, so that the 500-float budget of `poly_encoder` truncates."""
+    x1, y1, x2, y2 = [float(v) for v in box]
+    segs = []
+    for _ in range(int(rs.randint(1, 4))):
+        nv = int(rs.randint(130, 300)) if rs.uniform() < long_prob else int(rs.randint(3, 13))
+        cx, cy = rs.uniform(x1 + 0.3 * (x2 - x1), x2 - 0.3 * (x2 - x1)), rs.uniform(y1 + 0.3 * (y2 - y1), y2 - 0.3 * (y2 - y1))
+        rx, ry = min(cx - x1, x2 - cx), min(cy - y1, y2 - cy)
+        ang = np.sort(rs.uniform(0, 2 * np.pi, nv))
+        rad = rs.uniform(0.6, 1.0, nv)
+        px, py = cx + rx * rad * np.cos(ang), cy + ry * rad * np.sin(ang)
+        segs.append([float(v) for v in np.round(np.stack((px, py), 1).reshape(-1), 2)])
+    return segs
+
+
+def make_roidb(n_images=5000, seed=0, n_proposals=0, num_classes=81, with_masks=False):
     """Returns list[dict] (the reference's roidb).  GT rows first, then `n_proposals` uniform boxes
-    per image (the merged layout of lib/dataset/imdb.py:398-419)."""
+    per image (the merged layout of lib/dataset/imdb.py:398-419).  with_masks adds `gt_masks` (drawn from a separate
+    stream: the boxes of a seed do not depend on it)."""
     rs = np.random.RandomState(seed)
     sizes = [s for s, _ in _SIZES]
     probs = np.array([p for _, p in _SIZES])
@@ -57,6 +75,10 @@ def make_roidb(n_images=5000, seed=0, n_proposals=0, num_classes=81):
             boxes = np.vstack((gt, props))
             max_ov = np.concatenate((max_ov, pov))
             max_cls = np.concatenate((max_cls, np.zeros(n_proposals, np.int32)))
+        extra = {}
+        if with_masks:
+            prs = np.random.RandomState([seed, i, 7])
+            extra['gt_masks'] = [make_polygons(prs, b) for b in gt]
         roidb.append({
             'image': 'synthetic_%06d.jpg' % i,
             'width': int(W),
@@ -66,6 +88,7 @@ def make_roidb(n_images=5000, seed=0, n_proposals=0, num_classes=81):
             'max_classes': max_cls,
             'max_overlaps': max_ov,
             'flipped': False,
+            **extra,
         })
     return roidb
 
