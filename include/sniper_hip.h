@@ -235,6 +235,27 @@ int sn_multi_proposal_target(const float *cls_prob, const float *bbox_pred, cons
                              const float *bbox_stds4, void *ws, float *rois, float *label, float *bbox_target,
                              float *bbox_weight, sn_stream_t stream);
 
+/* Mask branch (symbols/faster/resnet_mx_101_e2e_mask.py:317-318,374-405; fork operators, semantics = DESIGN.md / oracle/nn.py).
+ * sn_multi_proposal_target_mask: sn_multi_proposal_target plus, per chip, the first num_mask_rois foreground RoIs
+ *   (mask_rois (B*num_mask_rois, 5), padded with [b,0,0,0,0]) and the gt_boxes row each matched (mask_ids, -1 = padding);
+ *   match_ws = B * post_nms_top_n floats of scratch.
+ * sn_mask_rcnn_target: the matched object's polygons (mask_polys (B, max_gts, max_len), rows as lib/data_utils/mask_utils.py
+ *   :22-46 encodes them) rasterised into each RoI's mask_size^2 grid -> targets (N, ms, ms) in {1, 0, -1 = ignore}, cls (N).
+ * sn_depth_to_space2 / sn_space_to_depth2: (N,H,W,4C) <-> (N,2H,2W,C) fp16, channel (a*2+b)*C + c <-> pixel (2h+a, 2w+b): the
+ *   2x2 / stride-2 Deconvolution is a 1x1 convolution to 4C channels followed by this shuffle (relu fused on the way out).
+ * sn_pick_fwd / sn_pick_bwd: pick(axis=1, keepdims) on a channels-last fp16 tensor (N, HW, C) with one index per n. */
+int sn_multi_proposal_target_mask(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *gt_boxes,
+                                  const float *valid_ranges, const float *base_anchors, int B, int A, int Fh, int Fw, int feat_stride,
+                                  int G, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float fg_thresh,
+                                  const float *bbox_stds4, void *ws, float *match_ws, int num_mask_rois, float *rois, float *label,
+                                  float *bbox_target, float *bbox_weight, float *mask_rois, float *mask_ids, sn_stream_t stream);
+int sn_mask_rcnn_target(const float *rois, const float *mask_polys, const float *mask_ids, int N, int rois_per_image, int max_gts,
+                        int max_len, int mask_size, float *targets, float *cls, sn_stream_t stream);
+int sn_depth_to_space2(const void *in, void *out, int N, int H, int W, int C, int relu, sn_stream_t stream);
+int sn_space_to_depth2(const void *in, void *out, int N, int H, int W, int C, sn_stream_t stream);
+int sn_pick_fwd(const void *x, const float *index, void *y, int N, int HW, int C, sn_stream_t stream);
+int sn_pick_bwd(const void *dy, const float *index, void *dx, int N, int HW, int C, int accumulate, sn_stream_t stream);
+
 /* DeformablePSROIPooling, group_size 1 (:286-293).  data (B,H,W,C) fp16, rois (R,5), trans (R,2,P,P) or NULL,
  * out (R,P,P,C) fp16.  Backward: d_data (B,H,W,C) fp16 (d_data_f32 = 0) or fp32 and d_trans (R,2,P,P) fp32 are
  * OVERWRITTEN (every element written exactly once, no atomics); ws = sn_dpsroi_bwd_workspace_bytes(R). */

@@ -99,7 +99,7 @@ class _RoundF16(torch.autograd.Function):
 
 # operators whose output the engine keeps as an fp16 activation tensor (sniper_amd/engine/executor.py, _PRODUCES_ACT)
 _F16_OUT = {'Convolution', 'FullyConnected', 'BatchNorm', 'Activation', 'Pooling', 'Concat', 'DeformableConvolution',
-            'DeformablePSROIPooling', 'clip', '_plus', 'elemwise_add'}
+            'DeformablePSROIPooling', 'clip', '_plus', 'elemwise_add', 'Deconvolution', 'pick'}
 
 
 class _MakeLoss(torch.autograd.Function):
@@ -247,9 +247,19 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
             y = torch.where(x.abs() < 1.0 / sg ** 2, 0.5 * (sg * x) ** 2, x.abs() - 0.5 / sg ** 2)
         elif op == 'MakeLoss':
             y = _MakeLoss.apply(ins[0], float(a.get('grad_scale', 1.0)))
-        elif op in ('MultiProposal', 'MultiProposalTarget') and not fork_ops and (node.name, 0) in overrides:
+        elif op == 'Deconvolution':
+            y = F.conv_transpose2d(s['data'], s['weight'], s.get('bias'), _tup(a.get('stride', 1)), _tup(a.get('pad', 0)))
+        elif op == 'pick':
+            assert int(a.get('axis', -1)) == 1 and _bool(a.get('keepdims', False))
+            x, idx = s['data'], s['index'].detach().long().clamp(0, s['data'].shape[1] - 1)
+            y = x.gather(1, idx.reshape(-1, 1, 1, 1).expand(-1, 1, x.shape[2], x.shape[3]))
+        elif op == 'MaskRcnnTarget':
+            r, pl, ids = [s[k].detach().numpy() for k in ('rois', 'mask_polys', 'mask_ids')]
+            tg, cl = onn.mask_rcnn_target(r, pl, ids, r.shape[0] // pl.shape[0], int(a.get('mask_size', 28)))
+            y = (torch.from_numpy(tg), torch.from_numpy(cl))
+        elif op in ('MultiProposal', 'MultiProposalTarget', 'MultiProposalTargetMask') and not fork_ops and (node.name, 0) in overrides:
             y = tuple(torch.from_numpy(np.asarray(overrides[(node.name, i)], np.float32)) for i in range(node.num_outputs))
-        elif op in ('MultiProposal', 'MultiProposalTarget'):
+        elif op in ('MultiProposal', 'MultiProposalTarget', 'MultiProposalTargetMask'):
             cls, box, info = [s[k].detach().numpy() for k in ('cls_prob', 'bbox_pred', 'im_info')]
             Fm = cls.shape[3]
             cls = cls.reshape(cls.shape[0], 2, -1, Fm)
@@ -262,8 +272,13 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
             if op == 'MultiProposal':
                 y = (torch.from_numpy(rois), torch.from_numpy(scores))
             else:
-                lab, tgt, wgt = onn.proposal_targets(rois, s['gt_boxes'].detach().numpy(), s['valid_ranges'].detach().numpy(), post)
+                gtb, vrn = s['gt_boxes'].detach().numpy(), s['valid_ranges'].detach().numpy()
+                lab, tgt, wgt = onn.proposal_targets(rois, gtb, vrn, post)
                 y = (torch.from_numpy(rois), torch.from_numpy(lab), torch.from_numpy(tgt), torch.from_numpy(wgt))
+                if op == 'MultiProposalTargetMask':
+                    mr, mi = onn.mask_rois_select(rois, lab, onn.proposal_target_matches(rois, gtb, vrn, post), post,
+                                                  int(a.get('num_mask_rois', 50)))
+                    y = y + (torch.from_numpy(mr), torch.from_numpy(mi))
         elif op == 'DeformablePSROIPooling':
             no_trans = _bool(a.get('no_trans', False)) or 'trans' not in s
             y = _DPSROIPool.apply(s['data'], s['rois'].detach(), None if no_trans else s['trans'], int(a['pooled_size']),

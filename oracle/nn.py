@@ -110,6 +110,101 @@ def proposal_targets(rois, gt_boxes, valid_ranges, post_nms, fg_thresh=0.5, stds
 
 
 # ---------------------------------------------------------------------------------------------
+# Mask branch (symbols/faster/resnet_mx_101_e2e_mask.py:317-318,392-395; fork operators -- spec ours, parity unpinned)
+# ---------------------------------------------------------------------------------------------
+def proposal_target_matches(rois, gt_boxes, valid_ranges, post, fg_thresh=0.5):
+    """gt_boxes row matched by every foreground RoI (-1 otherwise): the arg-max the labelling of proposal_targets uses."""
+    f32 = np.float32
+    R = rois.shape[0]
+    match = -np.ones((R,), np.float32)
+    for r in range(R):
+        b = r // post
+        x1, y1, x2, y2 = [f32(v) for v in rois[r, 1:5]]
+        area = (x2 - x1 + f32(1)) * (y2 - y1 + f32(1))
+        lo, hi = f32(valid_ranges[b, 0]), f32(valid_ranges[b, 1])
+        best_v, arg = f32(-1), -1
+        for g in range(gt_boxes.shape[1]):
+            gx1, gy1, gx2, gy2, c = [f32(v) for v in gt_boxes[b, g]]
+            if c < 0:
+                continue
+            size = np.sqrt((gx2 - gx1 + f32(1)) * (gy2 - gy1 + f32(1)))
+            if not (size >= lo and size <= hi):
+                continue
+            iw = min(x2, gx2) - max(x1, gx1) + f32(1)
+            ov = f32(0)
+            if iw > 0:
+                ih = min(y2, gy2) - max(y1, gy1) + f32(1)
+                if ih > 0:
+                    ov = iw * ih / (area + (gx2 - gx1 + f32(1)) * (gy2 - gy1 + f32(1)) - iw * ih)
+            if ov > best_v:
+                best_v, arg = ov, g
+        if arg >= 0 and best_v >= f32(fg_thresh):
+            match[r] = arg
+    return match
+
+
+def mask_rois_select(rois, label, match, post, nm):
+    """First nm foreground RoIs of every chip in RoI order, padded with [b,0,0,0,0] / -1."""
+    B = rois.shape[0] // post
+    mrois = np.zeros((B * nm, 5), np.float32)
+    mids = -np.ones((B * nm,), np.float32)
+    for b in range(B):
+        mrois[b * nm:(b + 1) * nm, 0] = b
+        k = 0
+        for r in range(b * post, (b + 1) * post):
+            if label[r] > 0 and k < nm:
+                mrois[b * nm + k] = rois[r]
+                mids[b * nm + k] = match[r]
+                k += 1
+    return mrois, mids
+
+
+def mask_rcnn_target(rois, polys, ids, nm, ms=28):
+    """-> targets (N, ms, ms) in {1, 0, -1}, cls (N).  Centre of RoI cell (i, j) inside the union of the matched object's
+    polygons (even-odd rule per polygon, float32 crossing test as the kernel evaluates it)."""
+    f32 = np.float32
+    N = rois.shape[0]
+    tg = -np.ones((N, ms, ms), np.float32)
+    cls = np.zeros((N,), np.float32)
+    for n in range(N):
+        gid = int(ids[n])
+        if gid < 0:
+            continue
+        row = polys[n // nm, gid].astype(np.float32)
+        if row[0] < 0:
+            continue
+        cls[n] = row[0]
+        nseg = int(row[1])
+        if nseg <= 0:
+            continue
+        x1, y1 = f32(rois[n, 1]), f32(rois[n, 2])
+        cw = (f32(rois[n, 3]) - x1 + f32(1)) / f32(ms)
+        ch = (f32(rois[n, 4]) - y1 + f32(1)) / f32(ms)
+        px = x1 + (np.arange(ms, dtype=np.float32) + f32(0.5)) * cw
+        py = y1 + (np.arange(ms, dtype=np.float32) + f32(0.5)) * ch
+        PX, PY = np.meshgrid(px, py)
+        inside = np.zeros((ms, ms), bool)
+        off = 2 + nseg
+        for sgm in range(nseg):
+            ln = int(row[2 + sgm])
+            xs, ys = row[off:off + ln:2], row[off + 1:off + ln:2]
+            nv = ln // 2
+            inn = np.zeros((ms, ms), bool)
+            c = nv - 1
+            for a in range(nv):
+                xa, ya, xc, yc = xs[a], ys[a], xs[c], ys[c]
+                cross = (ya > PY) != (yc > PY)
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    xi = (xc - xa) * (PY - ya) / (yc - ya) + xa
+                inn ^= cross & (PX < xi)
+                c = a
+            inside |= inn
+            off += ln
+        tg[n] = inside.astype(np.float32)
+    return tg, cls
+
+
+# ---------------------------------------------------------------------------------------------
 # DeformablePSROIPooling (Deformable ConvNets v1; call site :286-293 uses group_size 1; BASELINE config C4 swaps the
 # head for the position-sensitive R-FCN variant, group_size = pooled_size = 7).
 # data (B,C,H,W) with C = output_dim * G * G, rois (R,5), trans (R,2,P,P) or None -> out (R,output_dim,P,P).

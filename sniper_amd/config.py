@@ -81,6 +81,14 @@ def res101_e2e(batch_images=20):
     return c
 
 
+def res101_e2e_mask(batch_images=20):
+    """configs/faster/sniper_res101_e2e_mask.yml: the R101 detector trained with the auxiliary mask branch."""
+    c = res101_e2e(batch_images)
+    c.symbol = 'resnet_mx_101_e2e_mask'
+    c.TRAIN.WITH_MASK = True
+    return c
+
+
 def res101_e2e_autofocus(batch_images=20):
     """configs/faster/sniper_res101_e2e_autofocus.yml TEST section (BASELINE C5): coarse-to-fine scales, FocusChips."""
     c = res101_e2e(batch_images)

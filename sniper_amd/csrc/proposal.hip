@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void proposal_output_kernel(const float *__res
 __global__ __launch_bounds__(256) void proposal_target_kernel(const float *__restrict__ rois, const float *__restrict__ gt_boxes,
                                                               const float *__restrict__ valid_ranges, int G, int post,
                                                               float fg_thresh, float4 stds, float *__restrict__ label,
-                                                              float *__restrict__ bbox_target, float *__restrict__ bbox_weight) {
+                                                              float *__restrict__ bbox_target, float *__restrict__ bbox_weight,
+                                                              float *__restrict__ match) {
   const int b = blockIdx.y;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) float sgt[];  // G x 6: box, class, valid flag
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void proposal_target_kernel(const float *__res
   }
   const size_t o = (size_t)b * post + k;
   label[o] = lab;
+  if (match) match[o] = wv > 0.f ? (float)arg : -1.f;   // gt_boxes row of a foreground RoI (mask branch)
 #pragma unroll
   for (int c = 0; c < 4; ++c) { bbox_target[4 * o + c] = t[c]; bbox_weight[4 * o + c] = wv; }
 }
@@ -341,7 +343,75 @@ SN_EXPORT int sn_multi_proposal_target(const float *cls_prob, const float *bbox_
   const PropLayout L = prop_layout(B, A, Fh, Fw, pre_nms_top_n, post_nms_top_n);
   const float4 stds = make_float4(bbox_stds4[0], bbox_stds4[1], bbox_stds4[2], bbox_stds4[3]);
   hipLaunchKernelGGL(proposal_target_kernel, dim3(sn_div_up(L.post, 256), B), dim3(256), (size_t)G * 6 * sizeof(float),
-                     sn_stream(stream), rois, gt_boxes, valid_ranges, G, L.post, fg_thresh, stds, label, bbox_target, bbox_weight);
+                     sn_stream(stream), rois, gt_boxes, valid_ranges, G, L.post, fg_thresh, stds, label, bbox_target, bbox_weight,
+                     (float *)nullptr);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// MultiProposalTargetMask (symbols/faster/resnet_mx_101_e2e_mask.py:317-318; fork operator, spec ours -- DESIGN.md):
+// MultiProposalTarget plus, per chip, the first `num_mask_rois` FOREGROUND RoIs in RoI order (mask_rois (B*nm, 5)) and the
+// gt_boxes row each one matched (mask_ids (B*nm)); chips with fewer foreground RoIs are padded with [b, 0, 0, 0, 0] / -1,
+// which MaskRcnnTarget turns into all-ignore targets.  match_ws: B*post floats of scratch.
+__global__ __launch_bounds__(256) void mask_rois_select_kernel(const float *__restrict__ rois, const float *__restrict__ label,
+                                                               const float *__restrict__ match, int post, int nm,
+                                                               float *__restrict__ mask_rois, float *__restrict__ mask_ids) {
+  __shared__ int wave_cnt[4];
+  __shared__ int taken_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  if (tid == 0) taken_s = 0;
+  __syncthreads();
+  for (int base = 0; base < post; base += 256) {
+    const int k = base + tid;
+    const bool fg = k < post && label[(size_t)b * post + k] > 0.f;
+    const unsigned long long m = __ballot(fg);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = taken_s, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      off += w < wave ? wave_cnt[w] : 0;
+      total += wave_cnt[w];
+    }
+    const int slot = off + __popcll(m & lt);
+    if (fg && slot < nm) {
+      const float *r = rois + ((size_t)b * post + k) * 5;
+      float *o = mask_rois + ((size_t)b * nm + slot) * 5;
+      o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[4];
+      mask_ids[(size_t)b * nm + slot] = match[(size_t)b * post + k];
+    }
+    __syncthreads();
+    if (tid == 0) taken_s += total;
+    __syncthreads();
+    if (taken_s >= nm) break;
+  }
+  for (int slot = min(taken_s, nm) + tid; slot < nm; slot += 256) {
+    float *o = mask_rois + ((size_t)b * nm + slot) * 5;
+    o[0] = (float)b; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f;
+    mask_ids[(size_t)b * nm + slot] = -1.f;
+  }
+}
+
+SN_EXPORT int sn_multi_proposal_target_mask(const float *cls_prob, const float *bbox_pred, const float *im_info, const float *gt_boxes,
+                                            const float *valid_ranges, const float *base_anchors, int B, int A, int Fh, int Fw,
+                                            int feat_stride, int G, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
+                                            float min_size, float fg_thresh, const float *bbox_stds4, void *ws, float *match_ws,
+                                            int num_mask_rois, float *rois, float *label, float *bbox_target, float *bbox_weight,
+                                            float *mask_rois, float *mask_ids, sn_stream_t stream) {
+  SN_REQUIRE(gt_boxes && valid_ranges && label && bbox_target && bbox_weight && bbox_stds4 && G > 0 && G <= 1024 && match_ws &&
+                 mask_rois && mask_ids && num_mask_rois > 0, "sn_multi_proposal_target_mask: bad arguments");
+  if (int rc = sn_multi_proposal(cls_prob, bbox_pred, im_info, base_anchors, B, A, Fh, Fw, feat_stride, pre_nms_top_n, post_nms_top_n,
+                                 nms_thresh, min_size, ws, rois, nullptr, stream))
+    return rc;
+  const PropLayout L = prop_layout(B, A, Fh, Fw, pre_nms_top_n, post_nms_top_n);
+  const float4 stds = make_float4(bbox_stds4[0], bbox_stds4[1], bbox_stds4[2], bbox_stds4[3]);
+  hipLaunchKernelGGL(proposal_target_kernel, dim3(sn_div_up(L.post, 256), B), dim3(256), (size_t)G * 6 * sizeof(float),
+                     sn_stream(stream), rois, gt_boxes, valid_ranges, G, L.post, fg_thresh, stds, label, bbox_target, bbox_weight,
+                     match_ws);
+  SN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mask_rois_select_kernel, dim3(B), dim3(256), 0, sn_stream(stream), rois, label, match_ws, L.post, num_mask_rois,
+                     mask_rois, mask_ids);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -70,6 +70,8 @@ class Param(object):
         a = np.asarray(a, np.float32).reshape(self.ref_shape)
         if self.kind == 'conv':
             return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+        if self.kind == 'deconv':    # (Cin, Cout, 2, 2) -> rows (a, b, o) of a 1x1 convolution: [4*Cout][1][Cin]
+            return np.ascontiguousarray(a.transpose(2, 3, 1, 0)).reshape(self.int_shape)
         if self.kind == 'stem':      # (O, C<=4, KH, KW) -> [O][KH][KWP*4], zero padded
             kh, kw, kwp = self.fc_in
             out = np.zeros((a.shape[0], kh, kwp, 4), np.float32)
@@ -85,6 +87,9 @@ class Param(object):
         if self.kind == 'conv':
             o, i, kh, kw = self.ref_shape
             return np.ascontiguousarray(a.reshape(o, kh, kw, i).transpose(0, 3, 1, 2))
+        if self.kind == 'deconv':
+            ci, co, kh, kw = self.ref_shape
+            return np.ascontiguousarray(a.reshape(kh, kw, co, ci).transpose(3, 2, 0, 1))
         if self.kind == 'stem':
             o, i, kh, kw = self.ref_shape
             return np.ascontiguousarray(a.reshape(o, kh, self.fc_in[2], 4)[:, :, :kw, :i].transpose(0, 3, 1, 2))
@@ -97,7 +102,7 @@ class Param(object):
 _F32_CONSUMERS = {'Reshape', 'SoftmaxOutput', 'SoftmaxActivation', 'smooth_l1', 'MakeLoss', 'MultiProposal',
                   'MultiProposalTarget', 'BlockGrad', '_mul_scalar', '_plus_scalar', '_minus_scalar', 'Flatten', 'Custom'}
 _PRODUCES_ACT = {'Convolution', 'FullyConnected', 'BatchNorm', 'Activation', 'Pooling', 'Concat', 'DeformableConvolution',
-                 'DeformablePSROIPooling', 'clip'}
+                 'DeformablePSROIPooling', 'clip', 'Deconvolution', 'pick'}
 
 
 class Executor(object):
@@ -282,10 +287,10 @@ class Executor(object):
                 for c in cs:   # element-wise ops follow their other operand; rois/trans slots are f32
                     if c.op in binary and fmt[(id(c), 0)] == 'f32':
                         wants_f32[i] = True
-                    if c.op == 'DeformablePSROIPooling':
+                    if c.op in ('DeformablePSROIPooling', 'pick', 'MaskRcnnTarget'):
                         slots = c.extra.get('slots') or []
                         for s, (n2, i2) in zip(slots, c.inputs):
-                            if n2 is node and i2 == i and s in ('rois', 'trans'):
+                            if n2 is node and i2 == i and s in ('rois', 'trans', 'index', 'mask_polys', 'mask_ids'):
                                 wants_f32[i] = True
             step = cls(self, node, wants_f32)
             self.steps.append(step)
@@ -303,6 +308,9 @@ class Executor(object):
         if kind == 'conv':
             o, i, kh, kw = shp
             p.int_shape = (o, kh * kw, i)
+        elif kind == 'deconv':
+            ci, co, kh, kw = shp
+            p.int_shape = (kh * kw * co, 1, ci)
         elif kind == 'stem':
             kh, kw, kwp = fc_in
             p.int_shape = (shp[0], kh, kwp * 4)
@@ -357,7 +365,7 @@ class Executor(object):
             if not p.trainable:
                 p.master = self.zeros(p.int_shape, F32)
                 p.w16 = self.zeros(p.int_shape, F16)
-            if p.need_wT and p.kind in ('conv', 'fc'):
+            if p.need_wT and p.kind in ('conv', 'fc', 'deconv'):
                 o, t, i = p.int_shape
                 p.wT16 = self.zeros((i, t, _pad8(o)), F16)
         self.n_trainable = total

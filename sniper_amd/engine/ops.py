@@ -912,6 +912,121 @@ class MultiProposalTargetStep(_ProposalBase):
                  self.min_size, self.fg, self.stds.ctypes.data, self.wsbuf, rois, label, tgt, wgt, hip.stream())
 
 
+@register('MultiProposalTargetMask')
+class MultiProposalTargetMaskStep(_ProposalBase):
+    """resnet_mx_101_e2e_mask.py:317-318: MultiProposalTarget + the mask RoIs of every chip and the GT row each matched."""
+
+    def setup(self):
+        self.common()
+        self.gt, self.vr = self.data_in('gt_boxes'), self.data_in('valid_ranges')
+        self.G = self.gt.shape[1]
+        self.fg = float(self.a.get('fg_thresh', 0.5))
+        self.stds = np.array(self.a.get('bbox_stds', (0.1, 0.1, 0.2, 0.2)), np.float32)
+        self.outs = [self.new_out('f32', i) for i in range(6)]
+        self.nm = self.outs[4].shape[0] // self.B
+        self.match = self.ex.empty((self.B * self.post,), F32)
+
+    def forward(self):
+        ex = self.ex
+        rois, label, tgt, wgt, mrois, mids = [o.t for o in self.outs]
+        hip.call('sn_multi_proposal_target_mask', ex.as_f32(self.cls), ex.as_f32(self.bbox), ex.as_f32(self.info), ex.as_f32(self.gt),
+                 ex.as_f32(self.vr), self.base, self.B, self.A, self.Fh, self.Fw, self.stride, self.G, self.pre, self.post, self.thresh,
+                 self.min_size, self.fg, self.stds.ctypes.data, self.wsbuf, self.match, self.nm, rois, label, tgt, wgt, mrois, mids,
+                 hip.stream())
+
+
+@register('MaskRcnnTarget')
+class MaskRcnnTargetStep(Step):
+    """:392-395: rasterise the matched GT polygon into every mask RoI's 28 x 28 grid (labels only, no gradient)."""
+
+    def setup(self):
+        a = self.a
+        self.rois, self.polys, self.ids = self.data_in('rois'), self.data_in('mask_polys'), self.data_in('mask_ids')
+        self.ms = int(a.get('mask_size', 28))
+        self.B, self.max_gts, self.max_len = self.polys.shape
+        self.N = self.rois.shape[0]
+        if self.N % self.B:
+            raise ValueError('%s: %d mask RoIs for %d chips' % (self.node.name, self.N, self.B))
+        self.outs = [self.new_out('f32', 0), self.new_out('f32', 1)]
+
+    def forward(self):
+        ex = self.ex
+        hip.call('sn_mask_rcnn_target', ex.as_f32(self.rois), ex.as_f32(self.polys), ex.as_f32(self.ids), self.N, self.N // self.B,
+                 self.max_gts, self.max_len, self.ms, self.outs[0].t, self.outs[1].t, hip.stream())
+
+
+@register('Deconvolution')
+class DeconvolutionStep(Step):
+    """2x2 / stride-2 up-sampling of the mask head (:247-248): every input pixel writes its own 2x2 output block, so the
+    operator is a 1x1 convolution to 4*Cout channels (weight rows ordered (a, b, o), the implicit-GEMM kernels) followed by
+    a depth-to-space shuffle."""
+
+    def setup(self):
+        ex, a = self.ex, self.a
+        self.x = self.data_in()
+        k, s, p = _tup(a['kernel']), _tup(a.get('stride', (1, 1))), _tup(a.get('pad', (0, 0)))
+        if k != (2, 2) or s != (2, 2) or p != (0, 0) or int(a.get('num_group', 1)) != 1 or 'bias' in self.slots:
+            raise NotImplementedError('%s: Deconvolution other than kernel 2x2 / stride 2 / no pad / no bias' % self.node.name)
+        self.N, self.C, self.H, self.W = self.x.shape
+        self.O = int(a['num_filter'])
+        self.w = ex.register_param(self.pname('weight'), 'deconv', None, need_wT=ex.for_training and self.x.needs_grad)
+        self.y = self.new_out('act')
+        self.y.needs_grad = ex.for_training and (self.x.needs_grad or self.w.trainable)
+        self.tmp = ex.empty((self.N, self.H, self.W, 4 * self.O), F16)
+
+    def forward(self):
+        ex = self.ex
+        O4 = 4 * self.O
+        hip.call('sn_conv_fwd', ex.as_act(self.x), self.w.w16, None, None, self.tmp, self.N, self.H, self.W, self.C, self.C, O4, O4, 0,
+                 1, 1, 1, 0, 1, 0, 0, hip.stream())
+        hip.call('sn_depth_to_space2', self.tmp, self.y.t, self.N, self.H, self.W, self.O, 0, hip.stream())
+
+    def backward(self):
+        ex = self.ex
+        if self.y.grad is None or not self.y.needs_grad:
+            return
+        g = self.y.grad
+        O4 = 4 * self.O
+        dtmp = ex.empty((self.N, self.H, self.W, O4), F16)
+        hip.call('sn_space_to_depth2', g, dtmp, self.N, self.H, self.W, self.O, hip.stream())
+        x = ex.as_act(self.x)
+        if self.w.trainable:
+            ex.on_side(lambda: _wgrad(ex, dtmp, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, O4, O4, 1, 1, 1, 0, 1),
+                       keep=(dtmp, x))
+        if self.x.needs_grad:
+            dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty((self.N, self.H, self.W, self.C), F16), False)
+            hip.call('sn_conv_dgrad', dtmp, self.w.wT16, dx if acc else None, dx, self.N, self.H, self.W, self.C, self.C, O4, O4, self.C,
+                     1, 1, 1, 0, 1, 0, hip.stream())
+            if self.x.fmt != 'act':
+                ex.add_grad(self.x, dx, 'act')
+        self.y.grad = None
+
+
+@register('pick')
+class PickStep(Step):
+    """mx.sym.pick(data, index, axis=1, keepdims=True) (:398-399): the RoI class's mask map."""
+
+    def setup(self):
+        a = self.a
+        self.x, self.idx = self.data_in('data'), self.data_in('index')
+        if int(a.get('axis', -1)) != 1 or not _bool(a.get('keepdims', False)) or len(self.x.shape) != 4 or self.x.fmt != 'act':
+            raise NotImplementedError('%s: pick other than axis=1, keepdims=True on an activation tensor' % self.node.name)
+        self.y = self.new_out('act')
+        self.y.needs_grad = self.x.needs_grad
+
+    def forward(self):
+        n, h, w, c = self.x.nhwc()
+        hip.call('sn_pick_fwd', self.x.t, self.ex.as_f32(self.idx), self.y.t, n, h * w, c, hip.stream())
+
+    def backward(self):
+        if self.y.grad is None or not self.x.needs_grad:
+            return
+        n, h, w, c = self.x.nhwc()
+        dx, acc = self.ex.grad_slot(self.x)
+        hip.call('sn_pick_bwd', self.y.grad, self.ex.as_f32(self.idx), dx, n, h * w, c, 1 if acc else 0, hip.stream())
+        self.y.grad = None
+
+
 @register('DeformablePSROIPooling')
 class DPSROIPoolStep(Step):
     """group_size 1 (the SNIPER heads, :286-293): sn_dpsroi_pool_*; group_size G > 1 (position-sensitive R-FCN head,

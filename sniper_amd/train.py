@@ -37,9 +37,13 @@ class Trainer(object):
         cfg = self.cfg
         cfg.TRAIN.USE_NEG_CHIPS = n_proposals > 0
         np.random.seed(seed)
-        self.roidb = make_roidb(n_images, seed=seed, n_proposals=n_proposals)
+        self.roidb = make_roidb(n_images, seed=seed, n_proposals=n_proposals, with_masks=bool(cfg.TRAIN.WITH_MASK))
         self.iter = MNIteratorE2E(self.roidb, cfg, batch_size=batch_images, nGPUs=1)
-        self.net = resnet_mx_101_e2e.resnet_mx_101_e2e(n_proposals=400, momentum=momentum)
+        # main_train.py:83-84: the symbol class is named by the config
+        import importlib
+        name = cfg.get('symbol', 'resnet_mx_101_e2e')
+        net_cls = getattr(importlib.import_module('sniper_amd.symbols.faster.' + name), name)
+        self.net = net_cls(n_proposals=400, momentum=momentum)
         self.sym = self.net.get_symbol_rcnn(cfg)
         self.mod = mx.mod.Module(self.sym, context=[mx.gpu(0)], data_names=[k for k, _ in self.iter.provide_data_single],
                                  label_names=[k for k, _ in self.iter.provide_label_single],

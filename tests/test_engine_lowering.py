@@ -107,3 +107,34 @@ def test_rfcn_lowering_plan():
     net.init_weight_rcnn(cfg, arg, aux)
     assert float(np.abs(arg['rfcn_cls_offset_t_weight'].asnumpy()).max()) == 0.0
     assert arg['rfcn_bbox_weight'].shape == (49 * 4, 256, 1, 1)
+
+
+def test_mask_lowering_plan():
+    """sniper_res101_e2e_mask.yml graph: RPN on C4, mask RoIs, 14x14 pooling, 4 convs, 2x2 deconvolution as 1x1 conv + shuffle,
+    per-RoI channel picks, per-pixel 2-way softmax."""
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e_mask as mk
+    B = 2
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    net = mk.resnet_mx_101_e2e_mask(momentum=0.995)
+    sym = net.get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, 21 * 32 * 32),
+                  bbox_target=(B, 84, 32, 32), bbox_weight=(B, 84, 32, 32), gt_boxes=(B, 100, 5), gt_masks=(B, 100, 500))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    kinds = {}
+    for s in ex.steps:
+        kinds[type(s).__name__] = kinds.get(type(s).__name__, 0) + 1
+    assert kinds['MultiProposalTargetMaskStep'] == 1 and kinds['MaskRcnnTargetStep'] == 1 and kinds['DeconvolutionStep'] == 1
+    assert kinds['PickStep'] == 2 and kinds['DPSROIPoolStep'] == 4
+    pool = [s for s in ex.steps if type(s).__name__ == 'DPSROIPoolStep' and s.P == 14]
+    assert len(pool) == 2 and all(s.rois.shape == (B * 50, 5) for s in pool)
+    picks = [s for s in ex.steps if type(s).__name__ == 'PickStep']
+    assert all(s.y.fmt == 'act' and s.y.shape == (B * 50, 1, 28, 28) and s.idx.fmt == 'f32' for s in picks)
+    dec = [s for s in ex.steps if type(s).__name__ == 'DeconvolutionStep'][0]
+    assert dec.y.shape == (B * 50, 256, 28, 28) and dec.w.kind == 'deconv' and dec.w.int_shape == (1024, 1, 256) and dec.w.wT16 is not None
+    a = np.random.RandomState(0).standard_normal(dec.w.ref_shape).astype(np.float32)
+    assert dec.w.ref_shape == (256, 256, 2, 2) and np.array_equal(dec.w.to_reference(dec.w.to_internal(a)), a)
+    i = dec.w.to_internal(a)                                  # row (a, b, o) holds W[:, o, a, b]
+    assert np.array_equal(i[(1 * 2 + 0) * 256 + 7, 0], a[:, 7, 1, 0])
+    assert ex.params['rpn_conv_3x3_weight'].int_shape == (512, 9, 1024)
+    out = [s for s in ex.steps if type(s).__name__ == 'SoftmaxOutputStep' and s.node.name == 'mask_cls_prob'][0]
+    assert ex.shapes[(id(out.node), 0)] == (B * 50, 2, 28, 28)

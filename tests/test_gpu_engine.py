@@ -393,7 +393,7 @@ def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
     assert all(np.isfinite(g).all() for g in got)
     ov = {}
     for node in sym._topo():
-        if node.op in ('MultiProposalTarget', 'MultiProposal'):
+        if node.op in ('MultiProposalTarget', 'MultiProposal', 'MultiProposalTargetMask'):
             for i in range(node.num_outputs):
                 v = ex.vals.get((id(node), i))
                 if v is not None and v.t is not None:
