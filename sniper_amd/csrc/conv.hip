@@ -319,19 +319,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
   };
 
   half8 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
+  int t = 0;
   gload(ra0, rb0);
-  if (nk > 1) gload(ra1, rb1);
-  lstore(0, ra0, rb0);
-  if (nk > 2) gload(ra0, rb0);
-  __syncthreads();
-  for (int t = 0; t < nk; t += 2) {
-    // even step t: tile t+1 lives in set 1, tile t+2 in set 0
+  if (nk > 4) {
+    // Steady state WITHOUT a branch around any load or store.  The compiler places s_waitcnt vmcnt(N) from a dataflow
+    // model of the outstanding loads; a conditional gload / lstore inside the loop (or in the code leading to it) makes
+    // the two joined paths disagree, the merge is conservative, and every ds_write of tile t+1 ended up behind
+    // `s_waitcnt vmcnt(0)` -- i.e. behind the loads of tile t+2 issued one step earlier: ONE tile in flight, not two (seen
+    // in the ISA: vmcnt(7)..vmcnt(0) before the eight ds_write_b128).  Straight-line code from the first load on lets it
+    // count exactly: the stores of one register set wait with the other set's eight loads still in flight.
+    gload(ra1, rb1);
+    lstore(0, ra0, rb0);
+    gload(ra0, rb0);
+    __syncthreads();
+    for (; t + 4 < nk; t += 2) {
+      lstore(1, ra1, rb1);      // even step t: tile t+1 lives in set 1, tile t+2 in set 0
+      gload(ra1, rb1);          // tile t+3
+      compute(0);
+      __syncthreads();
+      lstore(0, ra0, rb0);      // odd step t+1: tile t+2 lives in set 0, tile t+3 in set 1
+      gload(ra0, rb0);          // tile t+4
+      compute(1);
+      __syncthreads();
+    }
+  } else {
+    if (nk > 1) gload(ra1, rb1);
+    lstore(0, ra0, rb0);
+    if (nk > 2) gload(ra0, rb0);
+    __syncthreads();
+  }
+  // tail (and the whole loop of a short contraction): the guarded form; tiles t+1 / t+2 are in flight as above
+  for (; t < nk; t += 2) {
     if (t + 1 < nk) lstore(1, ra1, rb1);
     if (t + 3 < nk) gload(ra1, rb1);
     compute(0);
     __syncthreads();
     if (t + 1 >= nk) break;
-    // odd step t+1: tile t+2 lives in set 0, tile t+3 in set 1
     if (t + 2 < nk) lstore(0, ra0, rb0);
     if (t + 4 < nk) gload(ra0, rb0);
     compute(1);
@@ -666,8 +689,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
 #pragma unroll
   for (int i = 0; i < 2; ++i) dy_voff[i] = a_cok ? (unsigned)(lr + 16 * i) * dy_ps_b + (unsigned)a_c * 2u : kOob;
   // one register set = one 64-pixel tile: rows {lr, lr+16} of unit 0 and of unit 1, A (dY) and B (X)
+  // (the two units of a tile are located first -- scalar loops that skip padding rows -- and the eight loads are then
+  // issued back to back, with no control flow between them)
   auto gload = [&](half8 (&ra)[4], half8 (&rb)[4]) -> bool {
-    bool any = false;
+    bool have[2];
+    int ox0[2];
+    size_t dy_base[2], x_base[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int sy = 0;
@@ -676,26 +703,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
         if ((unsigned)sy < (unsigned)p.H) break;
         it_advance();
       }
-      const bool have = it_left > 0;
-      any = any || have;
-      const int ox0 = it_xc * 32;
-      const size_t dy_base = ((size_t)it_r * p.Wo + ox0) * dy_ps_b;
-      const size_t x_base = ((size_t)it_img * p.H + (have ? sy : 0)) * p.W * (size_t)x_ps_b;
+      // (readfirstlane: these are block-uniform, but the compiler must KNOW it -- a descriptor it believes divergent is
+      // loaded inside an exec-masked waterfall, i.e. control flow around every buffer_load)
+      have[h] = __builtin_amdgcn_readfirstlane(it_left > 0 ? 1 : 0) != 0;
+      ox0[h] = __builtin_amdgcn_readfirstlane(it_xc * 32);
+      const unsigned dyrow = (unsigned)__builtin_amdgcn_readfirstlane(it_r * p.Wo + ox0[h]);
+      const unsigned xrow = (unsigned)__builtin_amdgcn_readfirstlane((it_img * p.H + sy) * p.W);
+      dy_base[h] = have[h] ? (size_t)dyrow * dy_ps_b : 0;
+      x_base[h] = have[h] ? (size_t)xrow * x_ps_b : 0;
+      if (have[h]) it_advance();
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
       const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char *>(dyb) + (have ? dy_base : 0), 0, have ? (int)((unsigned)(p.Wo - ox0) * dy_ps_b) : 0, 0x00020000);
+          const_cast<char *>(dyb) + dy_base[h], 0, have[h] ? (int)((unsigned)(p.Wo - ox0[h]) * dy_ps_b) : 0, 0x00020000);
       const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char *>(xbp) + (have ? x_base : 0), 0, have ? (int)((unsigned)p.W * x_ps_b) : 0, 0x00020000);
+          const_cast<char *>(xbp) + x_base[h], 0, have[h] ? (int)((unsigned)p.W * x_ps_b) : 0, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ox = ox0 + lr + 16 * i, sx = ox * p.stride - p.pad + kw * p.dil;
-        const bool okb = ox < p.Wo && b_cok && (unsigned)sx < (unsigned)p.W;
+        const int ox = ox0[h] + lr + 16 * i, sx = ox * p.stride - p.pad + kw * p.dil;
+        // bitwise, not short-circuit: `&&` here became an exec-masked if/else with the dY load duplicated into both arms
+        const bool okb = (ox < p.Wo) & b_cok & ((unsigned)sx < (unsigned)p.W);
         ra[h * 2 + i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rdy, dy_voff[i], 0, 0));
         rb[h * 2 + i] = __builtin_bit_cast(
             half8, __builtin_amdgcn_raw_buffer_load_b128(rxx, okb ? (unsigned)sx * x_ps_b + (unsigned)b_c * 2u : kOob, 0, 0));
       }
-      if (have) it_advance();
     }
-    return any;
+    return have[0] || have[1];
   };
   auto lstore = [&](int buf, const half8 (&ra)[4], const half8 (&rb)[4]) {
 #pragma unroll
@@ -725,29 +759,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
     }
   };
 
+  // Same pipeline discipline as conv_igemm_p2_kernel: the steady-state loop has NO branch around a load or a store (an
+  // exhausted iterator loads through empty descriptors = zeros, which is harmless), so the compiler's s_waitcnt vmcnt
+  // model is exact and the stores of one register set wait with the other set's loads still in flight.  Which of the
+  // three tiles in flight are real is tracked in block-uniform flags that only the drain looks at.
   half8 ra0[4], rb0[4], ra1[4], rb1[4];
-  bool h0 = gload(ra0, rb0);               // tile 0 (all flags are block-uniform)
-  bool h1 = h0 ? gload(ra1, rb1) : false;  // tile 1
-  if (h0) lstore(0, ra0, rb0);
-  const bool any_tile = h0;
-  h0 = h0 ? gload(ra0, rb0) : false;       // tile 2
+  bool fa = gload(ra0, rb0);               // tile 0 -> LDS[0]
+  bool fb = gload(ra1, rb1);               // tile 1 in set 1
+  lstore(0, ra0, rb0);
+  bool fc = gload(ra0, rb0);               // tile 2 in set 0
   __syncthreads();
-  while (any_tile) {
-    // LDS[0] = tile t; set 1 = tile t+1 (h1), set 0 = tile t+2 (h0)
-    if (h1) lstore(1, ra1, rb1);
-    const bool h1n = h1 ? gload(ra1, rb1) : false;   // tile t+3
+  while (it_left > 0) {                    // tiles t (LDS[0]), t+1 (set 1), t+2 (set 0) are real, and so is tile t+3
+    lstore(1, ra1, rb1);
+    const bool fb_next = gload(ra1, rb1);  // tile t+3
     compute(0);
     __syncthreads();
-    if (!h1) break;
-    // LDS[1] = tile t+1; set 0 = tile t+2 (h0), set 1 = tile t+3 (h1n)
-    if (h0) lstore(0, ra0, rb0);
-    const bool h0n = h0 ? gload(ra0, rb0) : false;   // tile t+4
+    lstore(0, ra0, rb0);
+    const bool fc_next = gload(ra0, rb0);  // tile t+4 (may be empty)
     compute(1);
     __syncthreads();
-    if (!h0) break;
-    h1 = h1n;
-    h0 = h0n;
+    fa = fc;
+    fb = fb_next;
+    fc = fc_next;
   }
+  // drain: LDS[0] = tile A (fa), set 1 = tile B (fb), set 0 = tile C (fc)
+  if (fb) lstore(1, ra1, rb1);
+  if (fa) compute(0);
+  __syncthreads();
+  if (fc) lstore(0, ra0, rb0);
+  if (fb) compute(1);
+  __syncthreads();
+  if (fc) compute(0);
   // The product was formed transposed (X as the MFMA A operand): lane (fr, fq) holds, for each (i, j), output channel
   // co = ..+fr and 4 consecutive input channels ci = ..+fq*4 .. +3 -> one 16-byte store per (i, j).
   // With K-splits the partial tile goes to this split's slab with plain stores (a split without any valid unit
