@@ -258,7 +258,7 @@ def main():
         ex.use_graphs, ex._graph_fb, ex._graph_up = saved
         ex.use_side_stream = side
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel / conv_wgrad_kernel (sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad)',
+        roof = {'bound': 'mfma', 'kernel': 'conv_igemm_p2_kernel<DGRAD,BM> / conv_wgrad_tr_kernel (+ conv_igemm_kernel for narrow layers): sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad',
                 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
                 'traffic': pmc_traffic(),
                 'launches_per_step': sum(v[0] for v in per.values()) // 2,
