@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0
 
 def conv_flops(name, a):
     """Algorithmic FLOPs of one conv-family launch from its C-ABI arguments."""
-    if name == 'sn_conv_fwd':
+    if name in ('sn_conv_fwd', 'sn_conv_fwd_stats'):
         N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[5:18]
     elif name == 'sn_conv_dgrad':
         N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[4:17]
@@ -56,7 +56,7 @@ def conv_flops(name, a):
 class ConvProfiler(object):
     """Wraps sniper_amd.hip.call: brackets every conv-family launch with HIP events recorded on the
     stream the kernel is launched on (torch's current stream)."""
-    NAMES = ('sn_conv_fwd', 'sn_conv_dgrad', 'sn_conv_wgrad', 'sn_conv_stem_fwd')
+    NAMES = ('sn_conv_fwd', 'sn_conv_fwd_stats', 'sn_conv_dgrad', 'sn_conv_wgrad', 'sn_conv_stem_fwd')
 
     def __init__(self):
         from sniper_amd import hip

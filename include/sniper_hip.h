@@ -145,6 +145,15 @@ int sn_bbox_decode(const float *d_rois, const float *d_deltas, const float *d_im
 int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
                 int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
                 int relu, int out_f32, sn_stream_t stream);
+/* sn_conv_fwd that also emits the BatchNorm statistics of its fp16 output (sum and sum of squares of the STORED values per
+ * row tile): stats (blocks, 2, Cout) fp32, blocks = sn_conv_fwd_stats_blocks(...) (0: the layer does not qualify -- narrow or
+ * unaligned layers -- use sn_conv_fwd + sn_bn_stats).  Consumed by sn_bn_finalize_blocks: the batch-statistics pass of
+ * BatchNorm(train) after a convolution (resnet_mx_101_e2e.py:38-66) costs no extra read of the tensor. */
+int sn_conv_fwd_stats_blocks(int N, int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride,
+                             int KH, int KW, int stride, int pad, int dil);
+int sn_conv_fwd_stats(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
+                      int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad,
+                      int dil, int relu, float *stats, sn_stream_t stream);
 /* conv0 on the packed stem input (xp (N,Hp,Wp,4) fp16 from sn_pack_stem_input; w [Cout][KH][KWP*4]). */
 int sn_conv_stem_fwd(const void *xp, const void *w, const float *bias, void *y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
                      int out_pix_stride, int KH, int KWP, int stride, int relu, int out_f32, sn_stream_t stream);
@@ -178,6 +187,9 @@ int sn_bn_stats(const void *x, int M, int C, int ps, void *ws, sn_stream_t strea
 int sn_bn_finalize(const void *ws, int M, int C, float eps, float momentum, const float *gamma, const float *beta,
                    float *run_mean, float *run_var, float *scale, float *shift, float *save_mean, float *save_invstd,
                    sn_stream_t stream);
+int sn_bn_finalize_blocks(const float *partials, int nblk, int M, int C, float eps, float momentum, const float *gamma,
+                          const float *beta, float *run_mean, float *run_var, float *scale, float *shift, float *save_mean,
+                          float *save_invstd, sn_stream_t stream);
 int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int C, float eps,
                              float *scale, float *shift, sn_stream_t stream);
 int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, const float *scale, const float *shift, int relu,

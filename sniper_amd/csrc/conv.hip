@@ -46,6 +46,8 @@ struct ConvParams {
   int M;               // N*Ho*Wo
   int relu, out_f32;
   unsigned x_bytes, w_bytes;  // addressable extent of x / w (buffer-descriptor bounds of the pipelined kernel)
+  float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
+                       // STORED fp16 values (what bn_stats_kernel would read back), or null
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
@@ -363,6 +365,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
 
   // ---- epilogue: lane (fr, fq) holds, for each (i, jn), pixel m = ..+fr and channels n = ..+fq*4 .. +3
   const bool vec = (p.out_ps % 4 == 0) && (p.Nout % 4 == 0) && (!p.res || p.res_ps % 4 == 0);
+  float st_s[NI][4], st_q[NI][4];        // BatchNorm statistics of this lane's 16 output channels (host: only with `vec`)
+#pragma unroll
+  for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_s[jn][r] = st_q[jn][r] = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * WM + i * 16 + fr;
@@ -395,6 +402,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
           *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + n) = o;
+          if (p.stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float f = (float)o[r];
+              st_s[jn][r] += f;
+              st_q[jn][r] += f * f;
+            }
+          }
         }
       } else {
 #pragma unroll
@@ -408,6 +423,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
           else reinterpret_cast<half_t *>(p.y)[(size_t)m * p.out_ps + n + r] = (half_t)x;
         }
       }
+    }
+  }
+  if (p.stats) {
+    // rows: the 16 lanes that share fq hold different pixels of the same 4 channels -> xor-shuffle over fr, then the two
+    // waves of a column pair (wm = 0, 1) through LDS (the K loop is over: sA is free); fixed order -> deterministic
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          st_s[jn][r] += __shfl_xor(st_s[jn][r], off, 64);
+          st_q[jn][r] += __shfl_xor(st_q[jn][r], off, 64);
+        }
+      }
+    float *red = reinterpret_cast<float *>(&sA[0][0]);   // [wm][wn][2][64]
+    __syncthreads();
+    if (fr == 0) {
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = jn * 16 + fq * 4 + r;
+          red[((wm * 2 + wn) * 2 + 0) * 64 + c] = st_s[jn][r];
+          red[((wm * 2 + wn) * 2 + 1) * 64 + c] = st_q[jn][r];
+        }
+    }
+    __syncthreads();
+    // 256 threads: (which, column of the 128-wide tile)
+    const int which = tid >> 7, col = tid & 127, cw = col >> 6, cc = col & 63;
+    const int n = n0 + col;
+    if (n < p.Nout) {
+      const float a = red[((0 * 2 + cw) * 2 + which) * 64 + cc] + red[((1 * 2 + cw) * 2 + which) * 64 + cc];
+      p.stats[((size_t)mt * 2 + which) * p.Nout + n] = a;
     }
   }
 }
@@ -426,42 +475,57 @@ static int conv_check(const ConvParams &p, const char *who) {
   return SN_OK;
 }
 
-template <bool DGRAD>
-static int conv_launch(const ConvParams &p, hipStream_t s) {
-  // BN = 64 when the output is narrow (stage1 / RPN heads), 128 otherwise; BM = 128 always.  Layers whose taps are
-  // whole 64-channel K-steps and 16-byte addressable take the pipelined kernel.
+// which kernel a layer takes: BM = 64 / 128 -> conv_igemm_p2_kernel, 0 -> conv_igemm_kernel
+struct ConvPlan {
+  int bm, mtiles, ntiles;
+  unsigned x_bytes, w_bytes;
+};
+static ConvPlan conv_plan(const ConvParams &p) {
+  // BN = 64 when the output is narrow (stage1 / RPN heads), 128 otherwise.  Layers whose taps are whole 64-channel K-steps
+  // and 16-byte addressable take the pipelined kernel.
+  ConvPlan q = {0, 0, 0, 0u, 0u};
   const unsigned long x_bytes = ((unsigned long)p.N * p.H * p.W - 1) * p.in_ps * 2 + (unsigned long)p.Cin * 2;
   const unsigned long w_bytes = (unsigned long)p.Nout * p.KH * p.KW * p.Cin * 2;
   if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul &&
       !getenv("SNIPER_CONV_V1")) {
-    ConvParams q = p;
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
-    const int ntiles = sn_div_up(p.Nout, 128);
+    q.ntiles = sn_div_up(p.Nout, 128);
     const char *force = getenv("SNIPER_CONV_BM");
-    const bool small = force ? atoi(force) == 64 : sn_div_up(p.M, 128) * ntiles < 448;   // < ~1.75 workgroups per CU
-    if (small) {
-      const int mtiles = sn_div_up(p.M, 64);
-      hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD, 64>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, q, mtiles, ntiles);
-    } else {
-      const int mtiles = sn_div_up(p.M, 128);
-      hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD, 128>), dim3(sn_div_up(mtiles, 8) * 8 * ntiles), dim3(256), 0, s, q, mtiles, ntiles);
-    }
-  } else if (p.Nout <= 64) {
-    dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 64));
-    hipLaunchKernelGGL((conv_igemm_kernel<128, 64, DGRAD>), grid, dim3(256), 0, s, p);
+    const bool small = force ? atoi(force) == 64 : sn_div_up(p.M, 128) * q.ntiles < 448;   // < ~1.75 workgroups per CU
+    q.bm = small ? 64 : 128;
+    q.mtiles = sn_div_up(p.M, q.bm);
+  }
+  return q;
+}
+
+template <bool DGRAD>
+static int conv_launch(const ConvParams &p, hipStream_t s) {
+  const ConvPlan pl = conv_plan(p);
+  if (pl.bm) {
+    ConvParams q = p;
+    q.x_bytes = pl.x_bytes;
+    q.w_bytes = pl.w_bytes;
+    const dim3 grid(sn_div_up(pl.mtiles, 8) * 8 * pl.ntiles);
+    if (pl.bm == 64) hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD, 64>), grid, dim3(256), 0, s, q, pl.mtiles, pl.ntiles);
+    else hipLaunchKernelGGL((conv_igemm_p2_kernel<DGRAD, 128>), grid, dim3(256), 0, s, q, pl.mtiles, pl.ntiles);
   } else {
-    dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 128));
-    hipLaunchKernelGGL((conv_igemm_kernel<128, 128, DGRAD>), grid, dim3(256), 0, s, p);
+    SN_REQUIRE(!p.stats, "convolution statistics are emitted by the pipelined kernel only (query sn_conv_fwd_stats_blocks first)");
+    if (p.Nout <= 64) {
+      dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 64));
+      hipLaunchKernelGGL((conv_igemm_kernel<128, 64, DGRAD>), grid, dim3(256), 0, s, p);
+    } else {
+      dim3 grid(sn_div_up(p.M, 128), sn_div_up(p.Nout, 128));
+      hipLaunchKernelGGL((conv_igemm_kernel<128, 128, DGRAD>), grid, dim3(256), 0, s, p);
+    }
   }
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
 
-SN_EXPORT int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H,
-                          int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH,
-                          int KW, int stride, int pad, int dil, int relu, int out_f32, sn_stream_t stream) {
-  ConvParams p;
+static void conv_fwd_params(ConvParams &p, const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H,
+                            int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW,
+                            int stride, int pad, int dil, int relu, int out_f32) {
   p.x = (const half_t *)x; p.w = (const half_t *)w; p.y = y; p.bias = bias; p.res = (const half_t *)residual;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.in_ps = in_pix_stride;
   p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
@@ -469,7 +533,42 @@ SN_EXPORT int sn_conv_fwd(const void *x, const void *w, const float *bias, const
   p.Nout = Cout; p.out_ps = out_pix_stride; p.res_ps = res_pix_stride;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.M = N * p.Ho * p.Wo; p.relu = relu; p.out_f32 = out_f32;
+}
+
+SN_EXPORT int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H,
+                          int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH,
+                          int KW, int stride, int pad, int dil, int relu, int out_f32, sn_stream_t stream) {
+  ConvParams p;
+  conv_fwd_params(p, x, w, bias, residual, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH, KW, stride, pad,
+                  dil, relu, out_f32);
   if (int rc = conv_check(p, "sn_conv_fwd")) return rc;
+  return conv_launch<false>(p, sn_stream(stream));
+}
+
+// Forward convolution that also emits the BatchNorm statistics of its (fp16) output: partials (blocks, 2, Cout) fp32 with
+// blocks = sn_conv_fwd_stats_blocks(...) row tiles, consumed by sn_bn_finalize_blocks -- the separate read pass of
+// sn_bn_stats over the tensor disappears.  sn_conv_fwd_stats_blocks returns 0 when the layer does not qualify (narrow or
+// unaligned layers, fp32 output): use sn_conv_fwd + sn_bn_stats then.
+SN_EXPORT int sn_conv_fwd_stats_blocks(int N, int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride,
+                                       int res_pix_stride, int KH, int KW, int stride, int pad, int dil) {
+  ConvParams p;
+  conv_fwd_params(p, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH,
+                  KW, stride, pad, dil, 0, 0);
+  if (p.Ho <= 0 || p.Wo <= 0 || Cout % 4 != 0 || out_pix_stride % 4 != 0 || (res_pix_stride % 4) != 0) return 0;
+  const ConvPlan pl = conv_plan(p);
+  return pl.bm ? pl.mtiles : 0;
+}
+
+SN_EXPORT int sn_conv_fwd_stats(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W,
+                                int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW,
+                                int stride, int pad, int dil, int relu, float *stats, sn_stream_t stream) {
+  ConvParams p;
+  conv_fwd_params(p, x, w, bias, residual, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH, KW, stride, pad,
+                  dil, relu, 0);
+  if (int rc = conv_check(p, "sn_conv_fwd_stats")) return rc;
+  SN_REQUIRE(stats && Cout % 4 == 0 && out_pix_stride % 4 == 0 && (!residual || res_pix_stride % 4 == 0),
+             "sn_conv_fwd_stats: statistics need 8-byte aligned output rows (query sn_conv_fwd_stats_blocks)");
+  p.stats = stats;
   return conv_launch<false>(p, sn_stream(stream));
 }
 

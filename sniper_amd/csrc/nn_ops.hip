@@ -393,6 +393,18 @@ SN_EXPORT int sn_bn_finalize(const void *ws, int M, int C, float eps, float mome
   return SN_OK;
 }
 
+// bn_finalize over partials produced elsewhere (sn_conv_fwd_stats: one row block per convolution row tile)
+SN_EXPORT int sn_bn_finalize_blocks(const float *partials, int nblk, int M, int C, float eps, float momentum, const float *gamma,
+                                    const float *beta, float *run_mean, float *run_var, float *scale, float *shift,
+                                    float *save_mean, float *save_invstd, sn_stream_t stream) {
+  SN_REQUIRE(partials && nblk > 0 && beta && scale && shift && save_mean && save_invstd && M > 0 && C > 0,
+             "sn_bn_finalize_blocks: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(kBnFinThreads), 0, sn_stream(stream), partials, nblk, M, C, eps,
+                     momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean, save_invstd);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
 SN_EXPORT int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int C,
                                        float eps, float *scale, float *shift, sn_stream_t stream) {
   SN_REQUIRE(beta && mean && var && scale && shift, "sn_bn_global_scale_shift: null pointer");

@@ -118,6 +118,16 @@ class BatchNormStep(Step):
         self.y.needs_grad = ex.for_training and (self.x.needs_grad or self.gamma.trainable or self.beta.trainable) \
             and not self.is_stem
         self._global_ready = False
+        # batch statistics from the producing convolution's epilogue (plain conv -> BN, or the conv that absorbed the
+        # residual add this BN reads): sn_conv_fwd_stats + sn_bn_finalize_blocks instead of sn_bn_stats + sn_bn_finalize
+        self.stats_from = None
+        if ex.for_training and not self.global_stats and not self.is_stem and self.x.fmt == 'act':
+            prod = self.x.producer
+            conv = getattr(prod, 'fused_conv', None) if type(prod).__name__ == 'BinaryStep' else prod
+            if type(conv).__name__ == 'ConvolutionStep':
+                got = conv.request_stats()
+                if got is not None:
+                    self.stats_from = got
 
     def params_changed(self, only_trainable=False):
         # after an optimizer step only trainable parameters moved; a moving-statistics layer with frozen
@@ -146,9 +156,14 @@ class BatchNormStep(Step):
         if self._use_batch_stats():
             if self.bws is None:
                 self.bws = ex.empty((hip.query('sn_bn_workspace_bytes', M, c),), torch.uint8)
-            hip.call('sn_bn_stats', x, M, c, c, self.bws, hip.stream())
-            hip.call('sn_bn_finalize', self.bws, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
-                     self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
+            if self.stats_from is not None:
+                part, nblk = self.stats_from
+                hip.call('sn_bn_finalize_blocks', part, nblk, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
+                         self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
+            else:
+                hip.call('sn_bn_stats', x, M, c, c, self.bws, hip.stream())
+                hip.call('sn_bn_finalize', self.bws, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
+                         self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
         hip.call('sn_bn_apply', x, self.y.t, M, c, c, c, self.scale, self.shift, self.act, hip.stream())
 
     def backward(self):
@@ -378,6 +393,23 @@ class ConvolutionStep(_GemmLike):
     def x_shape_nhwc(self):
         return (self.N, self.H, self.W, self.C)
 
+    def _stats_blocks(self):
+        if self.is_stem or self.depthwise or self.out_f32 or os.environ.get('SNIPER_FUSE_BN_STATS', '1') == '0':
+            return 0
+        res = getattr(self, 'fused_residual', None)
+        return hip.query('sn_conv_fwd_stats_blocks', self.N, self.H, self.W, self.C, self.C, self.O, self.O,
+                         0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0])
+
+    def request_stats(self):
+        """A batch-statistics BatchNorm reading this convolution's output (or the residual sum its epilogue writes) asks
+        for the per-row-tile sums: -> (partials (blocks, 2, O) fp32, blocks) or None when the layer does not qualify."""
+        if getattr(self, 'stats_buf', None) is None:
+            nblk = self._stats_blocks()
+            if nblk <= 0:
+                return None
+            self.stats_buf, self.stats_blocks = self.ex.empty((nblk, 2, self.O), F32), nblk
+        return self.stats_buf, self.stats_blocks
+
     def launch_fwd(self, x, dst, bias):
         ex = self.ex
         if self.is_stem:
@@ -396,6 +428,14 @@ class ConvolutionStep(_GemmLike):
         res = getattr(self, 'fused_residual', None)
         if res is not None:      # y = conv(x) + residual written straight into the consuming add's tensor (BinaryStep)
             dst = self.fused_dst.t
+        if getattr(self, 'stats_buf', None) is not None and self.ex.is_train:
+            # the consuming BatchNorm's sum / sum of squares come out of the epilogue (no separate read pass)
+            if self._stats_blocks() != self.stats_blocks:
+                raise RuntimeError('%s: kernel selection changed after the statistics buffer was sized' % self.node.name)
+            hip.call('sn_conv_fwd_stats', x, self.w.w16, bias, None if res is None else res.t, dst, self.N, self.H, self.W, self.C,
+                     self.C, self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0,
+                     self.stats_buf, hip.stream())
+            return
         hip.call('sn_conv_fwd', x, self.w.w16, bias, None if res is None else res.t, dst, self.N, self.H, self.W, self.C, self.C,
                  self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0,
                  1 if self.out_f32 else 0, hip.stream())

@@ -339,6 +339,54 @@ def test_sgd_and_weight_transpose():
     assert torch.equal(wp[..., :O], wt) and float(wp[..., O:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize('N,H,C,O,K,bm,res', [(3, 17, 64, 192, 1, '64', False), (2, 24, 128, 256, 3, '128', True), (5, 9, 64, 128, 3, '64', True),
+                                              (4, 32, 256, 320, 1, '128', False)])
+def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch):
+    """sn_conv_fwd_stats: same output as sn_conv_fwd, and the per-row-tile partials sum to the statistics of the STORED
+    fp16 tensor (what sn_bn_stats would read back); both tile heights, ragged M / Cout tiles, residual epilogue."""
+    hip = _hip()
+    monkeypatch.setenv('SNIPER_CONV_BM', bm)
+    rs = np.random.RandomState(N * H + O)
+    x = rs.standard_normal((N, H, H, C)).astype(np.float32)
+    w = (rs.standard_normal((O, K * K, C)) / np.sqrt(K * K * C)).astype(np.float32)
+    r = rs.standard_normal((N, H, H, O)).astype(np.float32) if res else None
+    xd, wd = torch.from_numpy(x).to(dev()).half(), torch.from_numpy(w).to(dev()).half()
+    rd = torch.from_numpy(r).to(dev()).half() if res else None
+    y0 = torch.empty((N, H, H, O), dtype=torch.float16, device=dev())
+    hip.call('sn_conv_fwd', xd, wd, None, rd, y0, N, H, H, C, C, O, O, O if res else 0, K, K, 1, K // 2, 1, 0, 0, hip.stream())
+    nblk = hip.query('sn_conv_fwd_stats_blocks', N, H, H, C, C, O, O, O if res else 0, K, K, 1, K // 2, 1)
+    M = N * H * H
+    assert nblk == -(-M // int(bm))
+    part = torch.full((nblk, 2, O), 7.0, dtype=torch.float32, device=dev())
+    y1 = torch.empty_like(y0)
+    hip.call('sn_conv_fwd_stats', xd, wd, None, rd, y1, N, H, H, C, C, O, O, O if res else 0, K, K, 1, K // 2, 1, 0, part, hip.stream())
+    assert torch.equal(y0, y1)
+    yf = y1.double().reshape(M, O)
+    s, q = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    assert_close(s.cpu().numpy(), yf.sum(0).cpu().numpy(), 1e-5, 1e-3, 'sum')
+    assert_close(q.cpu().numpy(), (yf * yf).sum(0).cpu().numpy(), 1e-5, 1e-3, 'sum of squares')
+    # per tile too (rows of tile t)
+    t = nblk // 2
+    rows = yf[t * int(bm):(t + 1) * int(bm)]
+    assert_close(part[t, 0].cpu().numpy(), rows.sum(0).cpu().numpy(), 1e-5, 1e-3, 'tile sum')
+    # finalize over these partials == finalize over sn_bn_stats partials
+    ws = torch.empty(hip.query('sn_bn_workspace_bytes', M, O), dtype=torch.uint8, device=dev())
+    f = lambda v: torch.full((O,), v, device=dev())
+    outs = []
+    for use_blocks in (False, True):
+        g, b, rm, rv, sc, sh, sm, si = f(1.3), f(0.2), f(0.0), f(1.0), f(0.0), f(0.0), f(0.0), f(0.0)
+        if use_blocks:
+            hip.call('sn_bn_finalize_blocks', part, nblk, M, O, 2e-5, 0.9, g, b, rm, rv, sc, sh, sm, si, hip.stream())
+        else:
+            hip.call('sn_bn_stats', y1, M, O, O, ws, hip.stream())
+            hip.call('sn_bn_finalize', ws, M, O, 2e-5, 0.9, g, b, rm, rv, sc, sh, sm, si, hip.stream())
+        outs.append([t_.clone() for t_ in (sc, sh, sm, si, rm, rv)])
+    for a, b in zip(*outs):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-5, 1e-6, 'finalize')
+    # a narrow layer does not qualify
+    assert hip.query('sn_conv_fwd_stats_blocks', N, H, H, C, C, 48, 48, 0, 1, 1, 1, 0, 1) == 0
+
+
 def test_weight_transpose_batched_equals_single():
     """sn_weight_transpose_batched (one launch, LDS-tiled) against sn_weight_transpose per weight: ragged O / I, taps, O_pad."""
     hip = _hip()
