@@ -164,6 +164,16 @@ int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp,
 int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
                   int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil,
                   int out_f32, sn_stream_t stream);
+/* sn_conv_dgrad that also emits the reduction of the BatchNorm(+activation) backward below it: dx is dL/dy of
+ * y = act(BN(bn_x)) (bn_act: 0 none, 1 ReLU, 2 ReLU6), partials (blocks, 2, Cin) fp32 = per row tile sum g and sum g*(bn_x - mean)
+ * with g = the stored dx masked by the activation; blocks = sn_conv_dgrad_bn_blocks(...) (0: the layer does not qualify).
+ * Only valid when this convolution is y's only consumer (dx complete).  Consumed by sn_bn_backward_blocks. */
+int sn_conv_dgrad_bn_blocks(int N, int H, int W, int Cin, int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH,
+                            int KW, int stride, int pad, int dil);
+int sn_conv_dgrad_bn(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin, int dx_pix_stride,
+                     int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil, const void *bn_x,
+                     int bn_x_pix_stride, const float *bn_scale, const float *bn_shift, const float *bn_mean, int bn_act,
+                     float *partials, sn_stream_t stream);
 /* Weight gradient, accumulated (+=) into dw fp32 [Cout][KH*KW][Cin].  Layers whose weight tensor is small relative to
  * the pixel count are split over K; with ws = sn_conv_wgrad_workspace_bytes(...) bytes of scratch the partials are
  * reduced without atomics (deterministic); ws may be NULL (atomic accumulation). */
@@ -197,6 +207,9 @@ int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, con
 int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy, int ps_x, int ps_acc,
                    int ps_dx, const float *scale, const float *shift, const float *mean, const float *invstd, int relu, void *ws,
                    float *dgamma, float *dbeta, sn_stream_t stream);
+int sn_bn_backward_blocks(const float *partials, int nblk, const void *dy, const void *x, const void *accumulate, void *dx, int M,
+                          int C, int ps_dy, int ps_x, int ps_acc, int ps_dx, const float *scale, const float *shift, const float *mean,
+                          const float *invstd, int relu, void *ws, float *dgamma, float *dbeta, sn_stream_t stream);
 
 /* Depthwise 3x3 convolution (Convolution with num_group == channels; mobilenetv2_e2e.py:27-43,57-66), channels-last
  * fp16, weights [C][KH*KW] fp16.  dgrad adds `accumulate` (may be NULL / alias dx); wgrad accumulates (+=) into fp32

@@ -46,6 +46,11 @@ struct ConvParams {
   int M;               // N*Ho*Wo
   int relu, out_f32;
   unsigned x_bytes, w_bytes;  // addressable extent of x / w (buffer-descriptor bounds of the pipelined kernel)
+  // optional BatchNorm BACKWARD statistics of a data gradient (dgrad output = dL/d(act(BN(bn_x)))): with bn_x set, `stats`
+  // receives per row tile [mt][2][Nout] = sum g, sum g * (bn_x - mean), g = stored dx masked by the fused activation
+  const half_t *bn_x = nullptr;
+  const float *bn_scale = nullptr, *bn_shift = nullptr, *bn_mean = nullptr;
+  int bn_x_ps = 0, bn_act = 0;
   float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
                        // STORED fp16 values (what bn_stats_kernel would read back), or null
 };
@@ -403,11 +408,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_p2_kernel(const ConvParams 
           for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
           *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + n) = o;
           if (p.stats) {
+            if (p.bn_x) {
+              const half4 xv = *reinterpret_cast<const half4 *>(p.bn_x + (size_t)m * p.bn_x_ps + n);
+              const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + n), sh = *reinterpret_cast<const float4 *>(p.bn_shift + n);
+              const float4 mu = *reinterpret_cast<const float4 *>(p.bn_mean + n);
+              const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float f = (float)o[r];
-              st_s[jn][r] += f;
-              st_q[jn][r] += f * f;
+              for (int r = 0; r < 4; ++r) {
+                const float xf = (float)xv[r], yv = xf * scv[r] + shv[r];
+                // same mask as bn_act_pass (nn_ops.hip): 0 none, 1 relu (y > 0), 2 relu6 (0 <= y <= 6)
+                const bool pass = p.bn_act == 0 || (p.bn_act == 1 ? yv > 0.f : (yv >= 0.f && yv <= 6.f));
+                const float gf = pass ? (float)o[r] : 0.f;
+                st_s[jn][r] += gf;
+                st_q[jn][r] += gf * (xf - muv[r]);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float f = (float)o[r];
+                st_s[jn][r] += f;
+                st_q[jn][r] += f * f;
+              }
             }
           }
         }
@@ -595,17 +616,54 @@ SN_EXPORT int sn_conv_stem_fwd(const void *xp, const void *w, const float *bias,
 // Data gradient: dX (N,H,W,Cin) from dY (N,Ho,Wo,Cout) and Wt = weights as [Cin][KH*KW][Cout].
 // `accumulate` (fp16 tensor with dX's geometry, may alias dx) is added in the epilogue: that is how a
 // tensor with several consumers sums its gradients without a separate pass.
-SN_EXPORT int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W,
-                            int Cin, int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW,
-                            int stride, int pad, int dil, int out_f32, sn_stream_t stream) {
-  ConvParams p;
+static void conv_dgrad_params(ConvParams &p, const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W,
+                              int Cin, int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride,
+                              int pad, int dil, int out_f32) {
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   p.x = (const half_t *)dy; p.w = (const half_t *)wt; p.y = dx; p.bias = nullptr; p.res = (const half_t *)accumulate;
   p.N = N; p.H = Ho; p.W = Wo; p.Cin = Cout; p.in_ps = dy_pix_stride;
   p.Ho = H; p.Wo = W; p.Nout = Cin; p.out_ps = dx_pix_stride; p.res_ps = acc_pix_stride;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.M = N * H * W; p.relu = 0; p.out_f32 = out_f32;
+}
+
+SN_EXPORT int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W,
+                            int Cin, int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW,
+                            int stride, int pad, int dil, int out_f32, sn_stream_t stream) {
+  ConvParams p;
+  conv_dgrad_params(p, dy, wt, accumulate, dx, N, H, W, Cin, dx_pix_stride, Cout, dy_pix_stride, acc_pix_stride, KH, KW, stride, pad,
+                    dil, out_f32);
   if (int rc = conv_check(p, "sn_conv_dgrad")) return rc;
+  return conv_launch<true>(p, sn_stream(stream));
+}
+
+// Data gradient that also emits the reduction of the BatchNorm(+activation) backward below it (dx is dL/dy of
+// y = act(BN(bn_x))): partials (blocks, 2, Cin) = sum g, sum g * (bn_x - mean) per row tile, consumed by
+// sn_bn_backward_blocks -- the bn_bwd_reduce pass over (dy, x) disappears.  Valid only when dx is the COMPLETE gradient
+// of y (this convolution is y's only consumer).  sn_conv_dgrad_bn_blocks = 0: the layer does not qualify.
+SN_EXPORT int sn_conv_dgrad_bn_blocks(int N, int H, int W, int Cin, int dx_pix_stride, int Cout, int dy_pix_stride,
+                                      int acc_pix_stride, int KH, int KW, int stride, int pad, int dil) {
+  ConvParams p;
+  conv_dgrad_params(p, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, dx_pix_stride, Cout, dy_pix_stride, acc_pix_stride, KH, KW,
+                    stride, pad, dil, 0);
+  if (p.H <= 0 || p.W <= 0 || Cin % 4 != 0 || dx_pix_stride % 4 != 0 || acc_pix_stride % 4 != 0) return 0;
+  const ConvPlan pl = conv_plan(p);
+  return pl.bm ? pl.mtiles : 0;
+}
+
+SN_EXPORT int sn_conv_dgrad_bn(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
+                               int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad,
+                               int dil, const void *bn_x, int bn_x_pix_stride, const float *bn_scale, const float *bn_shift,
+                               const float *bn_mean, int bn_act, float *partials, sn_stream_t stream) {
+  ConvParams p;
+  conv_dgrad_params(p, dy, wt, accumulate, dx, N, H, W, Cin, dx_pix_stride, Cout, dy_pix_stride, acc_pix_stride, KH, KW, stride, pad,
+                    dil, 0);
+  if (int rc = conv_check(p, "sn_conv_dgrad_bn")) return rc;
+  SN_REQUIRE(bn_x && bn_scale && bn_shift && bn_mean && partials && Cin % 4 == 0 && dx_pix_stride % 4 == 0 &&
+                 bn_x_pix_stride % 4 == 0 && (!accumulate || acc_pix_stride % 4 == 0),
+             "sn_conv_dgrad_bn: bad arguments (query sn_conv_dgrad_bn_blocks)");
+  p.bn_x = (const half_t *)bn_x; p.bn_x_ps = bn_x_pix_stride; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean;
+  p.bn_act = bn_act; p.stats = partials;
   return conv_launch<true>(p, sn_stream(stream));
 }
 

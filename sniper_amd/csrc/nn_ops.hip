@@ -451,6 +451,30 @@ SN_EXPORT int sn_bn_backward(const void *dy, const void *x, const void *accumula
   return SN_OK;
 }
 
+// sn_bn_backward with the reduction already done elsewhere (sn_conv_dgrad_bn: partials (nblk, 2, C) = sum g, sum g*(x-mean)
+// per row tile of the data-gradient convolution): finalize + dx only.
+SN_EXPORT int sn_bn_backward_blocks(const float *partials, int nblk, const void *dy, const void *x, const void *accumulate, void *dx,
+                                    int M, int C, int ps_dy, int ps_x, int ps_acc, int ps_dx, const float *scale, const float *shift,
+                                    const float *mean, const float *invstd, int relu, void *ws, float *dgamma, float *dbeta,
+                                    sn_stream_t stream) {
+  SN_REQUIRE(partials && nblk > 0 && dy && x && scale && shift && mean && invstd && ws && bn_shape_ok(C) && M > 0,
+             "sn_bn_backward_blocks: bad arguments (C=%d)", C);
+  hipStream_t s = sn_stream(stream);
+  float *fin = (float *)ws;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(kBnFinThreads), 0, s, partials, nblk, C, invstd, fin, dgamma,
+                     dbeta);
+  SN_CHECK_LAUNCH();
+  if (dx) {
+    int rows_per_block;
+    const dim3 grid = bn_grid(M, C, 8192, &rows_per_block);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, grid, dim3(kBnThreads), 0, s, (const half_t *)dy, (const half_t *)x,
+                       (const half_t *)accumulate, (half_t *)dx, M, C, ps_dy, ps_x, ps_acc, ps_dx, rows_per_block, scale, shift,
+                       mean, invstd, (const float *)fin + C, (const float *)fin, relu);
+    SN_CHECK_LAUNCH();
+  }
+  return SN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ReLU / add / relu-gradient on channels-last fp16 (used where BN fusion does not apply)
 // ---------------------------------------------------------------------------------------------

@@ -118,6 +118,13 @@ class BatchNormStep(Step):
         self.y.needs_grad = ex.for_training and (self.x.needs_grad or self.gamma.trainable or self.beta.trainable) \
             and not self.is_stem
         self._global_ready = False
+        # the one operator that consumes this layer's (activated) output, if there is exactly one: its data gradient is then
+        # the complete dL/dy and may carry the backward reduction in its epilogue (ConvolutionStep.launch_dgrad)
+        chain = cons
+        if self.act and len(cons) == 1:
+            chain = ex.consumers.get((id(cons[0]), 0), [])
+        self.sole_consumer = chain[0] if len(chain) == 1 else None
+        self.bwd_partials = None
         # batch statistics from the producing convolution's epilogue (plain conv -> BN, or the conv that absorbed the
         # residual add this BN reads): sn_conv_fwd_stats + sn_bn_finalize_blocks instead of sn_bn_stats + sn_bn_finalize
         self.stats_from = None
@@ -180,10 +187,16 @@ class BatchNormStep(Step):
         dx, acc = (None, False)
         if self.x.needs_grad:
             dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty(x.shape, F16), False)
-        hip.call('sn_bn_backward', self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale, self.shift,
-                 self.save_mean, self.save_invstd, self.act, self.bws,
-                 self.gamma.grad if self.gamma.trainable else None, self.beta.grad if self.beta.trainable else None,
-                 hip.stream())
+        dg = self.gamma.grad if self.gamma.trainable else None
+        db = self.beta.grad if self.beta.trainable else None
+        if self.bwd_partials is not None:       # sum g, sum g*(x-mean) came out of the consumer's data-gradient epilogue
+            part, nblk = self.bwd_partials
+            self.bwd_partials = None
+            hip.call('sn_bn_backward_blocks', part, nblk, self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale,
+                     self.shift, self.save_mean, self.save_invstd, self.act, self.bws, dg, db, hip.stream())
+        else:
+            hip.call('sn_bn_backward', self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale, self.shift,
+                     self.save_mean, self.save_invstd, self.act, self.bws, dg, db, hip.stream())
         if self.x.needs_grad and self.x.fmt != 'act':
             ex.add_grad(self.x, dx, 'act')
         self.y.grad = None
@@ -445,8 +458,34 @@ class ConvolutionStep(_GemmLike):
             hip.call('sn_dwconv_dgrad', dy, self.w.w16, acc, dx, self.N, self.H, self.W, self.C, Op, self.C, self.C, self.k[0],
                      self.k[1], self.s[0], self.p[0], self.d[0], hip.stream())
             return
+        bn = self._bn_below(acc)
+        if bn is not None:
+            nblk = hip.query('sn_conv_dgrad_bn_blocks', self.N, self.H, self.W, self.C, self.C, Op, Op, 0, self.k[0], self.k[1],
+                             self.s[0], self.p[0], self.d[0])
+            if nblk > 0:
+                if getattr(self, 'bnb_buf', None) is None or self.bnb_buf.shape[0] != nblk:
+                    self.bnb_buf = self.ex.empty((nblk, 2, self.C), F32)
+                hip.call('sn_conv_dgrad_bn', dy, self.w.wT16, None, dx, self.N, self.H, self.W, self.C, self.C, Op, Op, 0, self.k[0],
+                         self.k[1], self.s[0], self.p[0], self.d[0], self.ex.as_act(bn.x), self.C, bn.scale, bn.shift, bn.save_mean,
+                         bn.act, self.bnb_buf, hip.stream())
+                bn.bwd_partials = (self.bnb_buf, nblk)
+                return
         hip.call('sn_conv_dgrad', dy, self.w.wT16, acc, dx, self.N, self.H, self.W, self.C, self.C, Op, Op, self.C,
                  self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0, hip.stream())
+
+    def _bn_below(self, acc):
+        """The batch-statistics BatchNorm whose (activated) output is this convolution's input and nobody else's: the data
+        gradient written here is then its complete dL/dy, and the epilogue can carry the backward reduction.
+        Opt-in (SNIPER_FUSE_BN_BWD=1): measured 1.5 % SLOWER end to end -- the epilogue's 8-byte reads of the BatchNorm input
+        cost the data-gradient kernels more (+1.9 ms per step) than the removed reduction pass saves (1.6 ms), DESIGN.md."""
+        if acc is not None or os.environ.get('SNIPER_FUSE_BN_BWD', '0') != '1' or self.x.fmt != 'act':
+            return None
+        bn = self.x.producer
+        if type(bn).__name__ != 'BatchNormStep' or bn.sole_consumer is not self.node or bn.global_stats or bn.is_stem:
+            return None
+        if not (self.ex.is_train and bn.y.needs_grad and bn.x.fmt == 'act'):
+            return None
+        return bn
 
     def launch_wgrad(self, dy, Op, x):
         if self.is_stem:

@@ -387,6 +387,48 @@ def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch):
     assert hip.query('sn_conv_fwd_stats_blocks', N, H, H, C, C, 48, 48, 0, 1, 1, 1, 0, 1) == 0
 
 
+@pytest.mark.parametrize('N,H,C,O,K,bm,act', [(3, 17, 128, 192, 1, '64', 1), (2, 24, 128, 256, 3, '128', 1), (4, 12, 192, 64, 3, '64', 0),
+                                              (2, 16, 320, 128, 1, '128', 2)])
+def test_conv_dgrad_bn_epilogue(N, H, C, O, K, bm, act, monkeypatch):
+    """sn_conv_dgrad_bn: same dx as sn_conv_dgrad, and partials that make sn_bn_backward_blocks reproduce sn_bn_backward
+    (dx of the BatchNorm below, dgamma, dbeta) -- ReLU / none / ReLU6 masks, both tile heights, ragged tiles."""
+    hip = _hip()
+    monkeypatch.setenv('SNIPER_CONV_BM', bm)
+    rs = np.random.RandomState(N + H + C)
+    M = N * H * H
+    dy = torch.from_numpy(rs.standard_normal((N, H, H, O)).astype(np.float32)).to(dev()).half()
+    wt = torch.from_numpy((rs.standard_normal((C, K * K, O)) / np.sqrt(K * K * O)).astype(np.float32)).to(dev()).half()
+    bnx = torch.from_numpy(rs.standard_normal((N, H, H, C)).astype(np.float32)).to(dev()).half()
+    f = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev())
+    scale, shift = f(rs.uniform(0.5, 1.5, C)), f(rs.uniform(-0.5, 2.5, C))
+    mean, invstd = f(rs.standard_normal(C) * 0.1), f(rs.uniform(0.5, 2, C))
+    dx0 = torch.empty((N, H, H, C), dtype=torch.float16, device=dev())
+    hip.call('sn_conv_dgrad', dy, wt, None, dx0, N, H, H, C, C, O, O, 0, K, K, 1, K // 2, 1, 0, hip.stream())
+    nblk = hip.query('sn_conv_dgrad_bn_blocks', N, H, H, C, C, O, O, 0, K, K, 1, K // 2, 1)
+    assert nblk == -(-M // int(bm))
+    part = torch.full((nblk, 2, C), 7.0, dtype=torch.float32, device=dev())
+    dx1 = torch.empty_like(dx0)
+    hip.call('sn_conv_dgrad_bn', dy, wt, None, dx1, N, H, H, C, C, O, O, 0, K, K, 1, K // 2, 1, bnx, C, scale, shift, mean, act, part,
+             hip.stream())
+    assert torch.equal(dx0, dx1)
+    ws = torch.empty(hip.query('sn_bn_workspace_bytes', M, C), dtype=torch.uint8, device=dev())
+    res = []
+    for blocks in (False, True):
+        dg, db = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+        out = torch.empty_like(dx0)
+        if blocks:
+            hip.call('sn_bn_backward_blocks', part, nblk, dx1, bnx, None, out, M, C, C, C, C, C, scale, shift, mean, invstd, act, ws, dg, db,
+                     hip.stream())
+        else:
+            hip.call('sn_bn_backward', dx1, bnx, None, out, M, C, C, C, C, C, scale, shift, mean, invstd, act, ws, dg, db, hip.stream())
+        res.append((out.float().cpu().numpy(), dg.cpu().numpy(), db.cpu().numpy()))
+    (o0, g0, b0), (o1, g1, b1) = res
+    assert_close(g1, g0, 1e-4, 1e-4 * np.abs(g0).max(), 'dgamma')
+    assert_close(b1, b0, 1e-4, 1e-4 * np.abs(b0).max(), 'dbeta')
+    assert_close(o1, o0, 2e-3, 2e-3 * np.abs(o0).max(), 'bn dx')
+    assert np.abs(g0).max() > 0
+
+
 def test_weight_transpose_batched_equals_single():
     """sn_weight_transpose_batched (one launch, LDS-tiled) against sn_weight_transpose per weight: ragged O / I, taps, O_pad."""
     hip = _hip()
