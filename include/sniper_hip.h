@@ -302,12 +302,13 @@ int sn_psroi_pool_bwd(const void *dout, const void *data, const float *rois, con
                       float spatial_scale, float trans_std, void *ws, sn_stream_t stream);
 
 /* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward:
- * d_data (N,H,W,C) fp16/fp32 and d_offset (same layout/dtype as offset) are OVERWRITTEN; either may be NULL. */
+ * d_data (N,H,W,C) fp16/fp32 and d_offset (same layout/dtype as offset) are OVERWRITTEN; either may be NULL.  ws: 16 bytes of
+ * device scratch (the launch's max |offset| prunes the data gradient's candidate scan) or NULL (full scan). */
 int sn_deform_im2col(const void *data, const void *offset, void *col, int N, int H, int W, int C, int KH, int KW, int stride,
                      int pad, int dil, int deformable_groups, int offset_pix_stride, int offset_dtype, sn_stream_t stream);
 int sn_deform_col2im(const void *dcol, const void *data, const void *offset, void *d_data, int d_data_f32, void *d_offset, int N,
                      int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
-                     int offset_pix_stride, int offset_dtype, sn_stream_t stream);
+                     int offset_pix_stride, int offset_dtype, void *ws, sn_stream_t stream);
 
 /* Multi-precision SGD with momentum (lib/train_utils/utils.py:26-33). */
 int sn_sgd_mom_update(float *w32, const float *grad, float *mom, void *w16, long n, float lr, float wd, float momentum,

@@ -799,7 +799,7 @@ template <typename TO>
 __global__ __launch_bounds__(256) void deform_col2im_data_kernel(const half_t *__restrict__ dcol, const TO *__restrict__ offset,
                                                                  void *__restrict__ d_data, int out_f32, int H, int W, int C, int Ho,
                                                                  int Wo, int KH, int KW, int stride, int pad, int dil, int DG,
-                                                                 int off_ps, int slabs) {
+                                                                 int off_ps, int slabs, const unsigned *__restrict__ dmax_bits) {
   __shared__ __attribute__((aligned(16))) float ent[4 * 64 * kEntStride];  // [wave][64][kEntStride]
   __shared__ int seg_n[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
@@ -811,17 +811,37 @@ __global__ __launch_bounds__(256) void deform_col2im_data_kernel(const half_t *_
   const int cl = slab * blockDim.x + tid;  // channel inside the group
   const bool active_c = cl < cg;
   const int c = g * cg + cl;
-  const int cand = Ho * Wo * T;
+  // Candidate output pixels: with D = max |offset| of the launch (deform_absmax_kernel) a sample can only reach this tile
+  // from base positions within D + 1 cells of it, i.e. from the output pixels of a small window (12 x 12 of 32 x 32 for the
+  // R101 layers while the learned offsets stay below one cell) instead of the whole map.  The window is visited in the same
+  // (oy, ox, tap) order as the full scan, so the sums are bit-identical.
+  int oy_lo = 0, oy_hi = Ho - 1, ox_lo = 0, ox_hi = Wo - 1;
+  if (dmax_bits) {
+    const float D = __uint_as_float(*dmax_bits);
+    if (D < 1.0e6f) {
+      const int Di = (int)ceilf(D) + 1, span = (KH > KW ? KH : KW) - 1;
+      auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };   // floor(a / b), b > 0
+      oy_lo = max(0, -fdiv(-(y0 - Di + pad - span * dil), stride));
+      oy_hi = min(Ho - 1, fdiv(y0 + 3 + Di + pad, stride));
+      ox_lo = max(0, -fdiv(-(x0 - Di + pad - span * dil), stride));
+      ox_hi = min(Wo - 1, fdiv(x0 + 3 + Di + pad, stride));
+    }
+  }
+  const int wh = max(oy_hi - oy_lo + 1, 0), ww = max(ox_hi - ox_lo + 1, 0);
+  const int cand = wh * ww * T, cand_full = Ho * Wo * T;
   float acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
   for (int base = 0; base < cand; base += blockDim.x) {
-    const int idx = base + tid;
+    const int widx = base + tid;
+    int idx = 0;
     bool hit = false;
     float Wx[4] = {0.f, 0.f, 0.f, 0.f}, Wy[4] = {0.f, 0.f, 0.f, 0.f};
-    if (idx < cand) {
-      const int ml = idx / T, tap = idx - ml * T;
-      const int oy = ml / Wo, ox = ml - oy * Wo;
+    if (widx < cand) {
+      const int wl = widx / T, tap = widx - wl * T;
+      const int oy = oy_lo + wl / ww, ox = ox_lo + wl % ww;
+      const int ml = oy * Wo + ox;
+      idx = ml * T + tap;
       const int kh = tap / KW, kw = tap - kh * KW;
       const TO *op = offset + ((size_t)n * Ho * Wo + ml) * off_ps + g * 2 * T + 2 * tap;
       const float py = (float)(oy * stride - pad + kh * dil) + (float)op[0];
@@ -847,7 +867,7 @@ __global__ __launch_bounds__(256) void deform_col2im_data_kernel(const half_t *_
     const unsigned long long m = __ballot(hit);
     if (hit) {
       float *e = ent + ((size_t)wave * 64 + __popcll(m & lt)) * kEntStride;
-      e[0] = __int_as_float(n * cand + idx);  // row (m, tap) of dcol
+      e[0] = __int_as_float(n * cand_full + idx);  // row (m, tap) of dcol
       *reinterpret_cast<float4 *>(e + 4) = make_float4(Wx[0], Wx[1], Wx[2], Wx[3]);
       *reinterpret_cast<float4 *>(e + 8) = make_float4(Wy[0], Wy[1], Wy[2], Wy[3]);
     }
@@ -879,9 +899,24 @@ SN_EXPORT int sn_deform_im2col(const void *data, const void *offset, void *col, 
   return SN_OK;
 }
 
+// max |offset| of a launch as float bits (non-negative floats order like unsigned integers): *out must be zero on entry
+template <typename TO>
+__global__ __launch_bounds__(256) void deform_absmax_kernel(const TO *__restrict__ offset, long rows, int cols, int ld,
+                                                            unsigned *__restrict__ out) {
+  float m = 0.f;
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const float v = fabsf((float)offset[r * ld + (i - r * cols)]);
+    m = (v > m || v != v) ? (v != v ? INFINITY : v) : m;      // NaN -> +inf: the window opens completely
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *offset, void *d_data, int d_data_f32,
                                void *d_offset, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil,
-                               int deformable_groups, int offset_pix_stride, int offset_dtype, sn_stream_t stream) {
+                               int deformable_groups, int offset_pix_stride, int offset_dtype, void *ws, sn_stream_t stream) {
   SN_REQUIRE(dcol && data && offset && C % 8 == 0 && deformable_groups > 0 && N > 0, "sn_deform_col2im: bad arguments");
   SN_REQUIRE(C % deformable_groups == 0, "sn_deform_col2im: C must be a multiple of the deformable groups");
   const int cg = C / deformable_groups, lpg = cg / 8;
@@ -905,12 +940,29 @@ SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *o
   if (d_data) {
     const int bt = cg >= 256 ? 256 : sn_div_up(cg, 64) * 64, slabs = sn_div_up(cg, bt);
     const dim3 grid(sn_div_up(W, 4) * sn_div_up(H, 4), N, deformable_groups * slabs);
+    unsigned *dmax = (unsigned *)ws;       // 4 bytes of scratch: max |offset| prunes the candidate scan (NULL: full scan)
+    if (dmax) {
+      SN_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned), s));
+      const long rows = (long)N * Ho * Wo;
+      const int cols = 2 * KH * KW * deformable_groups;
+      const long want = (rows * cols + 255) / 256;
+      const unsigned blocks = (unsigned)(want > 1024 ? 1024 : (want < 1 ? 1 : want));
+      if (offset_dtype == 0)
+        hipLaunchKernelGGL((deform_absmax_kernel<half_t>), dim3(blocks), dim3(256), 0, s, (const half_t *)offset, rows, cols,
+                           offset_pix_stride, dmax);
+      else
+        hipLaunchKernelGGL((deform_absmax_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)offset, rows, cols,
+                           offset_pix_stride, dmax);
+      SN_CHECK_LAUNCH();
+    }
     if (offset_dtype == 0)
       hipLaunchKernelGGL((deform_col2im_data_kernel<half_t>), grid, dim3(bt), 0, s, (const half_t *)dcol, (const half_t *)offset,
-                         d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, slabs);
+                         d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, slabs,
+                         (const unsigned *)dmax);
     else
       hipLaunchKernelGGL((deform_col2im_data_kernel<float>), grid, dim3(bt), 0, s, (const half_t *)dcol, (const float *)offset,
-                         d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, slabs);
+                         d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, slabs,
+                         (const unsigned *)dmax);
     SN_CHECK_LAUNCH();
   }
   return SN_OK;

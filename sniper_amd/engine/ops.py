@@ -593,8 +593,10 @@ class DeformableConvolutionStep(Step):
             oc = self.off.shape[1]
             d16 = ex.empty((self.N, self.H, self.W, self.C), F16) if self.x.needs_grad else None
             d_off = ex.empty((self.N, self.Ho, self.Wo, oc), F16) if self.off.needs_grad else None
+            if getattr(self, 'dws', None) is None:
+                self.dws = ex.zeros((16,), torch.uint8)      # max |offset| of the launch: prunes the data gradient's scan
             hip.call('sn_deform_col2im', dcol, ex.as_act(self.x), ex.as_act(self.off), d16, 0, d_off, self.N, self.H, self.W,
-                     self.C, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], self.dg, oc, 0, hip.stream())
+                     self.C, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], self.dg, oc, 0, self.dws, hip.stream())
             if self.x.needs_grad:
                 ex.add_grad(self.x, d16, 'act')
             if self.off.needs_grad:

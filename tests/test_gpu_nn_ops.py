@@ -673,7 +673,19 @@ def test_deformable_sampling_vs_oracle(N, C, H, W, DG):
     for f32 in (1, 0):
         d_data = torch.full((N, H, W, C), 7.0, dtype=torch.float32 if f32 else torch.float16, device=dev())
         d_off = torch.full((N, H, W, 2 * T * DG), 7.0, dtype=torch.float32, device=dev())
-        hip.call('sn_deform_col2im', dcd, dd, offd, d_data, f32, d_off, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, hip.stream())
+        hip.call('sn_deform_col2im', dcd, dd, offd, d_data, f32, d_off, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, None, hip.stream())
+        # the pruned candidate scan (max |offset| window) visits the same samples in the same order: bit-identical
+        d_data2 = torch.full_like(d_data, 7.0)
+        wsd = torch.zeros(16, dtype=torch.uint8, device=dev())
+        hip.call('sn_deform_col2im', dcd, dd, offd, d_data2, f32, None, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, wsd, hip.stream())
+        assert torch.equal(d_data2, d_data)
+        assert wsd.view(torch.float32)[0].item() == float(np.abs(off).max())
+        # sub-cell offsets: the window really prunes (the 40-cell outlier above opens it completely)
+        small = torch.from_numpy(np.ascontiguousarray((off * 0.2).clip(-0.9, 0.9).transpose(0, 2, 3, 1))).to(dev())
+        a, b = torch.full_like(d_data, 7.0), torch.full_like(d_data, 7.0)
+        hip.call('sn_deform_col2im', dcd, dd, small, a, f32, None, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, None, hip.stream())
+        hip.call('sn_deform_col2im', dcd, dd, small, b, f32, None, N, H, W, C, KH, KW, 1, 2, 2, DG, 2 * T * DG, 1, wsd, hip.stream())
+        assert torch.equal(a, b) and float(a.float().abs().sum()) > 0
         tol = 1e-3 if f32 else 1e-2
         assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wdata, tol, tol * np.abs(wdata).max(), 'deform d_data')
         assert_close(d_off.cpu().numpy().transpose(0, 3, 1, 2), woff, 1e-3, 1e-3 * np.abs(woff).max(), 'deform d_offset')

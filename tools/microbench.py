@@ -152,7 +152,8 @@ def main():
     print('deform im2col B=%d            %8.3f ms %8.1f GB/s (col bytes)' % (B, ms, col.numel() * 2 / ms / 1e6), flush=True)
     dx5 = torch.empty_like(x5)
     doff = torch.empty_like(off)
-    ms = timeit(lambda: hip.call('sn_deform_col2im', col, x5, off, dx5, 0, doff, B, 32, 32, C5, 3, 3, 1, 2, 2, DG, 72, 0, hip.stream()), it)
+    dws5 = torch.zeros(16, dtype=torch.uint8, device=d)
+    ms = timeit(lambda: hip.call('sn_deform_col2im', col, x5, off, dx5, 0, doff, B, 32, 32, C5, 3, 3, 1, 2, 2, DG, 72, 0, dws5, hip.stream()), it)
     print('deform col2im B=%d            %8.3f ms %8.1f GB/s (col bytes)' % (B, ms, col.numel() * 2 / ms / 1e6), flush=True)
 
 if __name__ == '__main__':
