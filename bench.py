@@ -198,11 +198,13 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...' %
                          (args.gpus, args.gpus))
-    torch.cuda.set_device(local)
+    # one process per GPU; SNIPER_DIST_BACKEND=gloo + fewer devices than ranks is the single-GPU rehearsal of the N > 1
+    # control flow (tests/test_gpu_engine.py), never a measurement
+    torch.cuda.set_device(local % torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl')   # RCCL over xGMI
+        dist.init_process_group(backend=os.environ.get('SNIPER_DIST_BACKEND', 'nccl'))   # nccl = RCCL over xGMI
 
     from sniper_amd import hip
     from sniper_amd.train import Trainer
@@ -244,28 +246,28 @@ def main():
 
     # ---- roofline of the dominant kernel family, live HIP-event timing (untimed extra steps)
     roof = None
-    if rank == 0:
-        # the timed region replays hipGraphs; for per-launch HIP events the same step is run eagerly (same kernels,
-        # same stream), bracketing every conv-family launch
-        ex = tr.mod.exe
-        saved = (ex.use_graphs, ex._graph_fb, ex._graph_up)
-        ex.use_graphs, ex._graph_fb, ex._graph_up = False, None, None
-        side, ex.use_side_stream = ex.use_side_stream, False      # one stream: a launch's duration is its own
-        with ConvProfiler() as prof:
-            for i in range(2):
-                step(i)
-            tot_ms, tot_fl, per = prof.summary()
-        ex.use_graphs, ex._graph_fb, ex._graph_up = saved
-        ex.use_side_stream = side
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'conv_igemm_p2_kernel<DGRAD,BM> / conv_wgrad_tr_kernel (+ conv_igemm_kernel for narrow layers): sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad',
-                'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
-                'traffic': pmc_traffic(),
-                'launches_per_step': sum(v[0] for v in per.values()) // 2,
-                'avg_launch_ms': round(tot_ms / max(1, sum(v[0] for v in per.values())), 4),
-                'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
-                'by_entry': {k: {'launches': v[0] // 2, 'ms_per_step': round(v[1] / 2, 3),
-                                 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in per.items()}}
+    # the timed region replays hipGraphs; for per-launch HIP events the same step is run eagerly (same kernels,
+    # same stream), bracketing every conv-family launch.  EVERY rank runs these two extra steps: a step contains the
+    # gradient all-reduce, and a collective entered by rank 0 alone would never return.
+    ex = tr.mod.exe
+    saved = (ex.use_graphs, ex._graph_fb, ex._graph_up)
+    ex.use_graphs, ex._graph_fb, ex._graph_up = False, None, None
+    side, ex.use_side_stream = ex.use_side_stream, False      # one stream: a launch's duration is its own
+    with ConvProfiler() as prof:
+        for i in range(2):
+            step(i)
+        tot_ms, tot_fl, per = prof.summary()
+    ex.use_graphs, ex._graph_fb, ex._graph_up = saved
+    ex.use_side_stream = side
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    roof = {'bound': 'mfma', 'kernel': 'conv_igemm_p2_kernel<DGRAD,BM> / conv_wgrad_tr_kernel (+ conv_igemm_kernel for narrow layers): sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad',
+            'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
+            'traffic': pmc_traffic(),
+            'launches_per_step': sum(v[0] for v in per.values()) // 2,
+            'avg_launch_ms': round(tot_ms / max(1, sum(v[0] for v in per.values())), 4),
+            'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
+            'by_entry': {k: {'launches': v[0] // 2, 'ms_per_step': round(v[1] / 2, 3),
+                             'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in per.items()}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

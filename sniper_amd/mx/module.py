@@ -33,8 +33,8 @@ def init_distributed():
     import torch.distributed as dist
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     if ws > 1 and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group(backend='nccl')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+        dist.init_process_group(backend=os.environ.get('SNIPER_DIST_BACKEND', 'nccl'))
     return dist if ws > 1 else None
 
 
@@ -100,8 +100,10 @@ class Module(object):
             shapes[name] = self._local(shp)
         args = set(self.symbol.list_arguments())
         shapes = {k: v for k, v in shapes.items() if k in args}
-        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', self.contexts[0].device_id)) if self.world > 1
-                           else self.contexts[0].device_id)
+        # one process per GPU: rank-local device.  (Modulo the device count only matters for the single-GPU rehearsal of
+        # the multi-rank control flow, SNIPER_DIST_BACKEND=gloo; a real launch has one device per local rank.)
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', self.contexts[0].device_id)) % torch.cuda.device_count()
+                           if self.world > 1 else self.contexts[0].device_id)
         torch.cuda.set_device(dev)
         self._device = dev
         self._exes = {}          # test-time batches change shape (scale, chip size): one bound executor per input shape

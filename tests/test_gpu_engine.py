@@ -515,3 +515,24 @@ def test_r101_c4_rfcn_head_parity_vs_cpu_reference_ops():
     assert checked >= 250
     names = [n for n, p in ex.params.items() if p.trainable]
     assert all(k in names for k in ('rfcn_cls_weight', 'rfcn_bbox_weight', 'rfcn_cls_offset_t_weight', 'rfcn_bbox_offset_t_bias'))
+
+
+def test_bench_two_rank_control_flow():
+    """`bench.py --gpus 2` launched the way the driver does (torch.distributed.run, one process per rank), rehearsed on ONE
+    GPU: both ranks share the device and the gradient all-reduce goes through gloo (SNIPER_DIST_BACKEND) -- not a
+    measurement, a guard for the collective call pattern: every rank must enter every all-reduce (a rank-0-only profiling
+    step once deadlocked here), and rank 0 alone prints the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNIPER_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29531', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '2', '--batch', '4']
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 8 and d['config']['parallelism'] == 'dp2'
+    assert d['value'] > 0 and d['roofline']['achieved'] > 0 and d['cpu_baseline'] is None
