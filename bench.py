@@ -215,9 +215,11 @@ def main():
     import sniper_amd.mx as mx
     anchors = tr.iter.anchors
 
+    packed = [anchors.pack_device(b.worker_data) for b in batches]     # GT boxes per chip: resident like the chips
+
     def step(i):
         b = batches[i % len(batches)]
-        lab = anchors.assign(b.worker_data, seed=i)
+        lab = anchors.assign(packed=packed[i % len(batches)], seed=i)
         label = [mx.nd.NDArray(lab['label']), mx.nd.NDArray(lab['bbox_target']), mx.nd.NDArray(lab['bbox_weight']),
                  mx.nd.NDArray(lab['gt_boxes'])]
         tr.step(mx.io.DataBatch(data=b.data, label=label, pad=0, index=None, provide_data=b.provide_data,

@@ -69,12 +69,19 @@ class AnchorAssigner(object):
             scale[b] = np.float32(im_scale)
         return gt, cls, inchip, ngt, crop, scale
 
-    def assign(self, chips, keys=None, seed=0, want_label_pre=False):
+    def pack_device(self, chips):
+        """The labelling inputs of a chip batch, packed and uploaded once: pass the result as `assign(packed=...)` when
+        the same batch is labelled repeatedly (bench.py: inputs resident in HBM; the per-step upload from pageable host
+        memory would make the host wait for the previous step)."""
+        return (len(chips),) + tuple(hip.dev(a) for a in self._pack(chips))
+
+    def assign(self, chips=None, keys=None, seed=0, want_label_pre=False, packed=None):
         """chips: list of anchor_worker.worker argument lists.  keys: optional (B, A*F*F) uint32
         sub-sampling keys in reference anchor order (see sn_anchor_assign); None = on-device hash."""
         device = hip.require_gpu()
-        B = len(chips)
-        gt, cls, inchip, ngt, crop, scale = self._pack(chips)
+        if packed is None:
+            packed = self.pack_device(chips)
+        B, gt, cls, inchip, ngt, crop, scale = packed
         if self._d_base is None:
             self._d_base = hip.dev(self.base, torch.float64)
         A, F = self.A, self.F
@@ -88,7 +95,7 @@ class AnchorAssigner(object):
         lp = torch.empty((B, self.total), dtype=torch.int8, device=device) if want_label_pre else None
         ws = self._ws.get(hip.query("sn_anchor_workspace_bytes", B, A, F, self.MAX_GT))
         d_keys = hip.dev(np.ascontiguousarray(keys, np.uint32).view(np.int32), torch.int32) if keys is not None else None
-        hip.call("sn_anchor_assign", hip.dev(gt), hip.dev(cls), hip.dev(inchip), hip.dev(ngt), hip.dev(crop), hip.dev(scale),
+        hip.call("sn_anchor_assign", gt, cls, inchip, ngt, crop, scale,
                  B, self.MAX_GT, self._d_base, A, F, self.feat_stride, self.chip_size, self.chip_size,
                  self.pos_thresh, self.neg_thresh, self.rpn_batch, self.num_fg, d_keys, int(seed), ws,
                  out['label'], out['bbox_target'], out['bbox_weight'], out['gt_boxes'], out['counts'], lp, hip.stream())

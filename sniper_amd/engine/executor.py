@@ -570,7 +570,15 @@ class Executor(object):
 
     def update(self, lr, wd, momentum, rescale_grad=1.0):
         """SGD with momentum on the fp32 masters (mx 'sgd', multi_precision; utils.py:26-33)."""
-        self.hyper.copy_(torch.tensor([lr, wd, momentum, rescale_grad], dtype=F32), non_blocking=True)
+        # Hyper-parameters live on the device (the captured optimizer graph reads them).  They are written by fill kernels
+        # with the value as a launch argument, and only when they change: a host-to-device copy from pageable memory makes
+        # the host wait for everything already queued on the stream, i.e. for the whole previous step.
+        vals = (float(lr), float(wd), float(momentum), float(rescale_grad))
+        last = getattr(self, '_hyper_host', None)
+        for i, v in enumerate(vals):
+            if last is None or last[i] != v:
+                hip.call('sn_ew_f32', None, None, self.hyper[i:], 1, 4, v, hip.stream())
+        self._hyper_host = vals
         self.num_update += 1
         if self._graph_up is not None:
             self._graph_up.replay()

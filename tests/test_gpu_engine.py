@@ -523,6 +523,7 @@ def test_bench_two_rank_control_flow():
     measurement, a guard for the collective call pattern: every rank must enter every all-reduce (a rank-0-only profiling
     step once deadlocked here), and rank 0 alone prints the JSON line."""
     import json
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
