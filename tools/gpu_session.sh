@@ -22,7 +22,7 @@ if [[ $WHAT == all || $WHAT == micro ]]; then
   cat gpurun_out/microbench.log
 fi
 if [[ $WHAT == all || $WHAT == bench ]]; then
-  timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
+  timeout 1200 python bench.py --steps 20 --warmup 5 --inference > gpurun_out/bench.log 2>&1
   echo "bench exit $?" >> gpurun_out/bench.log
   tail -5 gpurun_out/bench.log
   cd /tmp && export TMPDIR=/tmp
