@@ -54,7 +54,7 @@ class Val(object):
 
 class Param(object):
     __slots__ = ('name', 'ref_shape', 'kind', 'int_shape', 'trainable', 'lr_mult', 'wd_mult', 'master', 'grad', 'mom',
-                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in')
+                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in', 'half_region')
 
     def __init__(self, name, ref_shape):
         self.name, self.ref_shape = name, tuple(ref_shape)
@@ -63,6 +63,7 @@ class Param(object):
         self.master = self.grad = self.mom = self.w16 = self.wT16 = None
         self.need_wT = False
         self.fc_in = None
+        self.half_region = False   # weight of an operator the reference graph runs in fp16 (between its Cast nodes)
         self.numel = int(np.prod(ref_shape))
 
     # reference layout <-> kernel layout
@@ -128,6 +129,7 @@ class Executor(object):
         self._wt_tables = {}
         self.num_update = 0
         self._lower()
+        self._mark_half_region()
         self._alloc_params()
         # HIP graphs: a training step is ~2500 launches of static shape on preallocated buffers -- launch-bound on
         # the host (43 ms of enqueue per 47 ms step measured eagerly).  After `graph_warmup` eager steps the
@@ -340,7 +342,10 @@ class Executor(object):
             p.lr_mult = float(node.extra.get('lr_mult', 1.0)) if node is not None else 1.0
             wd_default = 1.0 if (p.name.endswith('_weight') or p.name.endswith('_gamma')) else 0.0  # mx optimizer rule
             p.wd_mult = float(node.extra.get('wd_mult', wd_default)) if node is not None else wd_default
-        train = sorted([p for p in ps if p.trainable], key=lambda q: (q.lr_mult, q.wd_mult))
+        # fp16-region weights first (one contiguous range = the fp16 bucket of the gradient all-reduce), then by
+        # (lr_mult, wd_mult) class so that every class is at most two contiguous ranges
+        train = sorted([p for p in ps if p.trainable], key=lambda q: (not q.half_region, q.lr_mult, q.wd_mult))
+        self.half_elems = sum(_pad8(p.numel) for p in train if p.half_region)
         total = sum(_pad8(p.numel) for p in train)
         self.arena_master = self.zeros((max(total, 8),), F32)
         self.arena_grad = self.zeros((max(total, 8),), F32)
@@ -355,7 +360,7 @@ class Executor(object):
             p.grad = self.arena_grad[off:off + n].view(p.int_shape)
             p.mom = self.arena_mom[off:off + n].view(p.int_shape)
             p.w16 = self.arena_w16[off:off + n].view(p.int_shape)
-            key = (p.lr_mult, p.wd_mult)
+            key = (p.lr_mult, p.wd_mult, p.half_region)
             if self.groups and self.groups[-1][0] == key:
                 self.groups[-1][2] = off + _pad8(n)
             else:
@@ -369,6 +374,36 @@ class Executor(object):
                 o, t, i = p.int_shape
                 p.wT16 = self.zeros((i, t, _pad8(o)), F16)
         self.n_trainable = total
+
+    def _mark_half_region(self):
+        """Which weights the reference holds in fp16: those of the Convolution / DeformableConvolution / FullyConnected
+        operators between its Cast(float16) and Cast(float32) nodes (resnet_mx_101_e2e.py:405-406, :250-252).  MXNet's
+        multi-precision SGD keeps fp32 masters of them but their GRADIENTS -- what kvstore exchanges -- are fp16; the
+        data-parallel all-reduce transports exactly these in fp16 (43.3 M fp16 + 30.2 M fp32 for R101)."""
+        half = {}
+        for node in self.nodes:
+            if node.op is None:
+                half[(id(node), 0)] = False
+                continue
+            if node.op == 'Cast':
+                dt = node.attrs.get('dtype')
+                try:
+                    h = np.dtype(dt) == np.float16
+                except TypeError:
+                    h = 'float16' in str(dt)
+            else:
+                h = False
+                for n, i in node.inputs:
+                    if n.op is not None or n.name not in self.params and n.name not in self.aux:
+                        h = half.get((id(n), i), False)
+                        break
+            for i in range(node.num_outputs):
+                half[(id(node), i)] = h
+            if h and node.op in ('Convolution', 'DeformableConvolution', 'FullyConnected', 'Deconvolution'):
+                slots = node.extra.get('slots') or []
+                for sl, (n, i) in zip(slots, node.inputs):
+                    if sl in ('weight', 'bias') and n.op is None and n.name in self.params:
+                        self.params[n.name].half_region = True
 
     def _var_node(self, name):
         for n in self.nodes:
@@ -563,7 +598,7 @@ class Executor(object):
         return self.outputs
 
     def _update_body(self, lr=None, wd=None, momentum=None, rescale_grad=None):
-        for (lr_mult, wd_mult), a, b in self.groups:
+        for (lr_mult, wd_mult, _half), a, b in self.groups:
             hip.call('sn_sgd_mom_update_dev', self.arena_master[a:], self.arena_grad[a:], self.arena_mom[a:], self.arena_w16[a:],
                      b - a, self.hyper, float(lr_mult), float(wd_mult), hip.stream())
         self.refresh_compute_copies(only_trainable=True)

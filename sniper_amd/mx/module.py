@@ -230,7 +230,12 @@ class Module(object):
 
     def update(self):
         from ..parallel import allreduce_gradients
-        allreduce_gradients(self.exe.grad_arena(), _dist())   # sum over ranks == kvstore 'device' push/pull
+        d = _dist()
+        if d is not None and d.get_world_size() > 1:          # sum over ranks == kvstore 'device' push/pull
+            exe = self.exe
+            if getattr(exe, '_half_buf', None) is None and exe.half_elems > 0:
+                exe._half_buf = torch.empty(exe.half_elems, dtype=torch.float16, device=exe.arena_grad.device)
+            allreduce_gradients(exe.grad_arena(), d, half_elems=exe.half_elems, half_buf=getattr(exe, '_half_buf', None))
         sched = self.opt['lr_scheduler']
         lr = sched(self.exe.num_update + 1) if sched is not None else self.opt['lr']
         self.exe.update(lr, self.opt['wd'], self.opt['momentum'], self.opt['rescale_grad'])

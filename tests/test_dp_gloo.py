@@ -28,6 +28,14 @@ def _worker(rank, world_size, port, out):
     n_coll = parallel.allreduce_gradients(g, dist, bucket_bytes=1024)          # 256 floats per bucket -> 4 collectives
     want = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world_size))
     ok_sum = bool(torch.equal(g, want)) and n_coll == 4
+    # fp16 bucket: the first 300 gradients travel in fp16 (the weights the reference holds in fp16), the rest in fp32
+    g2 = torch.cat((torch.arange(300, dtype=torch.float32) * (rank + 1) / 8, torch.full((700,), 0.1 * (rank + 1))))
+    buf = torch.empty(512, dtype=torch.float16)
+    n2 = parallel.allreduce_gradients(g2, dist, bucket_bytes=1 << 20, half_elems=300, half_buf=buf)
+    tot = sum(r + 1 for r in range(world_size))
+    ok_sum = ok_sum and n2 == 2 and bool(torch.equal(g2[:300], torch.arange(300, dtype=torch.float32) * tot / 8)) and \
+        bool(torch.allclose(g2[300:], torch.full((700,), 0.1 * tot), rtol=1e-6)) and \
+        not bool(torch.equal(g2[300:].half().float(), g2[300:]))          # the fp32 part did NOT go through fp16
     # a global batch is split rank-major
     batch = np.arange(8 * 3).reshape(8, 3)
     mine = parallel.rank_slice(batch, rank, world_size)
