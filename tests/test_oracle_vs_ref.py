@@ -167,3 +167,42 @@ def test_soft_and_hard_nms_match_cpu_nms_pyx():
             d = problem(rs, n, 40)
             assert list(oracle.cpu_nms(d, thr)) == list(refnms.cpu_nms(d.copy(), thr)), (n, thr)
     assert checked == 30
+
+
+def test_hard_nms_matches_reference_numpy_nms():
+    """oracle.nms_sorted (the nms_kernel.cu rule: suppress IoU > thresh on score-sorted boxes) against the reference's own
+    lib/nms/nms.py:90-127 `nms` (keeps ovr <= thresh) and its `nms_wrapper` / `soft_nms` front ends, imported unchanged
+    with the compiled cpu_nms module of oracle/_ref under their import names."""
+    import importlib.util
+    import sys
+    import types
+    sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'golden'))
+    from make_nms_golden import load_ref_cpu_nms, problem
+    saved = {k: sys.modules.get(k) for k in ('cpu_nms', 'gpu_nms')}
+    try:
+        sys.modules['cpu_nms'] = load_ref_cpu_nms()
+        g = types.ModuleType('gpu_nms')
+        g.gpu_nms = None                       # nvcc-only; nms.py merely imports the name (lib/nms/nms.py:3-4)
+        sys.modules['gpu_nms'] = g
+        spec = importlib.util.spec_from_file_location('ref_nms_py', '/root/reference/lib/nms/nms.py')
+        refnms = importlib.util.module_from_spec(spec)
+        sys.dont_write_bytecode = True
+        spec.loader.exec_module(refnms)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    rs = np.random.RandomState(13)
+    for n in (1, 6, 80, 400, 1500):
+        for thr in (0.3, 0.5, 0.7):
+            d = problem(rs, n, 30 if n % 2 == 0 else None)
+            want = [int(i) for i in refnms.nms(d, thr)]
+            order = d[:, 4].argsort()[::-1]
+            got = order[oracle.nms_sorted(d[order], thr)]
+            assert [int(i) for i in got] == want, (n, thr)
+            assert [int(i) for i in refnms.nms_wrapper(thr, -1).process(d)] == want
+    d = problem(rs, 200, 20)
+    soft = refnms.nms_wrapper(-1, 0.55).process(d.copy())
+    assert np.array_equal(np.asarray(soft, np.float32), oracle.soft_nms(d.copy(), 0.55, 0.3, 0.001, 2))
