@@ -206,3 +206,27 @@ def test_hard_nms_matches_reference_numpy_nms():
     d = problem(rs, 200, 20)
     soft = refnms.nms_wrapper(-1, 0.55).process(d.copy())
     assert np.array_equal(np.asarray(soft, np.float32), oracle.soft_nms(d.copy(), 0.55, 0.3, 0.001, 2))
+
+
+def test_box_coders_match_bbox_transform(ref):
+    """oracle data_path.{bbox_transform, bbox_pred, clip_boxes, filter_boxes} against the reference's
+    lib/bbox/bbox_transform.py (nonlinear_transform :64-90, nonlinear_pred :93-130, clip_boxes :35-50, filter_boxes :52-61):
+    bit-equal on float32 and float64 inputs, class-agnostic (4 columns) and per-class (4*K columns) deltas, empty inputs."""
+    bt = ref.bbox_transform
+    rs = np.random.RandomState(21)
+    for dt in (np.float32, np.float64):
+        for n, k in ((0, 1), (1, 1), (300, 1), (57, 3)):
+            c = rs.uniform(0, 500, (n, 2))
+            wh = rs.uniform(1, 200, (n, 2))
+            boxes = np.hstack((c - wh / 2, c + wh / 2)).astype(dt)
+            c2 = c + rs.normal(0, 10, (n, 2))
+            wh2 = wh * np.exp(rs.normal(0, 0.3, (n, 2)))
+            gt = np.hstack((c2 - wh2 / 2, c2 + wh2 / 2)).astype(dt)
+            deltas = (rs.standard_normal((n, 4 * k)) * 0.4).astype(dt)
+            if n:
+                assert np.array_equal(data_path.bbox_transform(boxes.copy(), gt.copy()), bt.bbox_transform(boxes.copy(), gt.copy()))
+            got, want = data_path.bbox_pred(boxes.copy(), deltas.copy()), bt.bbox_pred(boxes.copy(), deltas.copy())
+            assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), (dt, n, k)
+            if n:
+                assert np.array_equal(data_path.clip_boxes(got.copy(), (384, 511)), bt.clip_boxes(want.copy(), (384, 511)))
+                assert np.array_equal(data_path.filter_boxes(boxes, 12), bt.filter_boxes(boxes, 12))
