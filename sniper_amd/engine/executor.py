@@ -54,7 +54,7 @@ class Val(object):
 
 class Param(object):
     __slots__ = ('name', 'ref_shape', 'kind', 'int_shape', 'trainable', 'lr_mult', 'wd_mult', 'master', 'grad', 'mom',
-                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in', 'half_region')
+                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in', 'half_region', 'step_index', 'phase')
 
     def __init__(self, name, ref_shape):
         self.name, self.ref_shape = name, tuple(ref_shape)
@@ -64,6 +64,8 @@ class Param(object):
         self.need_wT = False
         self.fc_in = None
         self.half_region = False   # weight of an operator the reference graph runs in fp16 (between its Cast nodes)
+        self.step_index = 0        # forward index of the (first) step that owns it
+        self.phase = 0             # 0: its gradient is complete after the first backward segment, 1: after the second
         self.numel = int(np.prod(ref_shape))
 
     # reference layout <-> kernel layout
@@ -108,7 +110,7 @@ _PRODUCES_ACT = {'Convolution', 'FullyConnected', 'BatchNorm', 'Activation', 'Po
 
 class Executor(object):
     def __init__(self, symbol, input_shapes, for_training=True, fixed_param_names=(), device=None, data_names=None,
-                 label_names=None, loss_scale_hint=None):
+                 label_names=None, loss_scale_hint=None, split_backward=False):
         self.sym = symbol
         self.device = device or hip.require_gpu()
         self.for_training = for_training
@@ -130,6 +132,7 @@ class Executor(object):
         self.num_update = 0
         self._lower()
         self._mark_half_region()
+        self.split_k = self._choose_split() if (split_backward and for_training) else 0
         self._alloc_params()
         # HIP graphs: a training step is ~2500 launches of static shape on preallocated buffers -- launch-bound on
         # the host (43 ms of enqueue per 47 ms step measured eagerly).  After `graph_warmup` eager steps the
@@ -303,6 +306,7 @@ class Executor(object):
         p = self.params.get(name)
         if p is None:
             p = Param(name, shp)
+            p.step_index = len(self.steps)      # the step being constructed gets this index
             self.params[name] = p
         p.kind = kind
         p.fc_in = fc_in
@@ -344,8 +348,21 @@ class Executor(object):
             p.wd_mult = float(node.extra.get('wd_mult', wd_default)) if node is not None else wd_default
         # fp16-region weights first (one contiguous range = the fp16 bucket of the gradient all-reduce), then by
         # (lr_mult, wd_mult) class so that every class is at most two contiguous ranges
-        train = sorted([p for p in ps if p.trainable], key=lambda q: (not q.half_region, q.lr_mult, q.wd_mult))
-        self.half_elems = sum(_pad8(p.numel) for p in train if p.half_region)
+        for p in ps:
+            p.phase = 1 if (self.split_k and p.step_index < self.split_k) else 0
+        train = sorted([p for p in ps if p.trainable], key=lambda q: (q.phase, not q.half_region, q.lr_mult, q.wd_mult))
+        self.half_elems = sum(_pad8(p.numel) for p in train if p.half_region) if not self.split_k else 0
+        # all-reduce ranges in arena order: (phase, is_half, begin, end)
+        self.ar_ranges = []
+        o = 0
+        for p in train:
+            n8 = _pad8(p.numel)
+            key = (p.phase, p.half_region)
+            if self.ar_ranges and tuple(self.ar_ranges[-1][:2]) == key:
+                self.ar_ranges[-1][3] = o + n8
+            else:
+                self.ar_ranges.append([p.phase, p.half_region, o, o + n8])
+            o += n8
         total = sum(_pad8(p.numel) for p in train)
         self.arena_master = self.zeros((max(total, 8),), F32)
         self.arena_grad = self.zeros((max(total, 8),), F32)
@@ -360,7 +377,7 @@ class Executor(object):
             p.grad = self.arena_grad[off:off + n].view(p.int_shape)
             p.mom = self.arena_mom[off:off + n].view(p.int_shape)
             p.w16 = self.arena_w16[off:off + n].view(p.int_shape)
-            key = (p.lr_mult, p.wd_mult, p.half_region)
+            key = (p.lr_mult, p.wd_mult, (p.phase, p.half_region))
             if self.groups and self.groups[-1][0] == key:
                 self.groups[-1][2] = off + _pad8(n)
             else:
@@ -374,6 +391,31 @@ class Executor(object):
                 o, t, i = p.int_shape
                 p.wT16 = self.zeros((i, t, _pad8(o)), F16)
         self.n_trainable = total
+
+    def _choose_split(self):
+        """Backward in two segments so that the gradient all-reduce of the first (heads, RPN, the late trunk) overlaps the
+        second (the early trunk): the boundary is the forward step index k where the steps k.. hold about half of the
+        GEMM work of the backward pass (for R101 that is the stage-3 / stage-4 boundary: 2/3 of the parameter bytes are
+        complete with more than half of the backward still to run).  0 = no split."""
+        work = []
+        for st in self.steps:
+            w = getattr(st, 'w', None)
+            f = 0.0
+            if w is not None and getattr(w, 'trainable', False):
+                out = getattr(st, 'y', None)
+                if out is not None:
+                    n, h, wd, c = out.nhwc()
+                    f = float(n * h * wd) * float(w.numel)
+            work.append(f)
+        total = sum(work)
+        if total <= 0:
+            return 0
+        acc = 0.0
+        for k in range(len(work) - 1, -1, -1):
+            acc += work[k]
+            if acc >= 0.5 * total:
+                return k if 0 < k < len(work) - 1 else 0
+        return 0
 
     def _mark_half_region(self):
         """Which weights the reference holds in fp16: those of the Convolution / DeformableConvolution / FullyConnected
@@ -547,28 +589,37 @@ class Executor(object):
             fn()
         self._side_used = True
 
-    def backward(self):
-        self.zero_grad()
-        self._side_used = False
-        for v in self.vals.values():
-            v.grad = None
-        for s in reversed(self.steps):
+    def backward(self, segment=None):
+        """segment None: the whole pass.  With a split (self.split_k): 'a' = the steps split_k.. (their parameter gradients
+        are complete afterwards), 'b' = the rest; gradients of tensors that cross the boundary stay in Val.grad in between."""
+        k = self.split_k if segment is not None else 0
+        if segment in (None, 'a'):
+            self.zero_grad()
+            self._side_used = False
+            for v in self.vals.values():
+                v.grad = None
+        steps = self.steps if segment is None else (self.steps[k:] if segment == 'a' else self.steps[:k])
+        for s in reversed(steps):
             s.backward()
-        for v in self.vals.values():
-            v.grad = None
+        if segment in (None, 'b'):
+            for v in self.vals.values():
+                v.grad = None
         if self._side_used:                       # join: the optimizer / all-reduce read the gradient arena
             ev = torch.cuda.Event()
             ev.record(self.side_stream)
             torch.cuda.current_stream().wait_event(ev)
+            self._side_used = False
         self._keepalive = []
 
-    def _capture(self, fn, what):
-        """Capture fn() into a hipGraph; on failure fall back to eager execution for good."""
+    def _capture(self, fn, what, pool=None):
+        """Capture fn() into a hipGraph; on failure fall back to eager execution for good.  pool: share the memory pool
+        of an earlier capture that is always replayed right before this one (tensors live across the two)."""
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of a multi-GPU job may query events while this thread captures
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            kw = {'pool': pool} if pool is not None else {}
+            with torch.cuda.graph(g, capture_error_mode='thread_local', **kw):
                 fn()
             return g
         except Exception as e:   # noqa: BLE001 -- any capture failure means "run eagerly", never "stop training"
@@ -577,23 +628,50 @@ class Executor(object):
             torch.cuda.synchronize()
             return None
 
-    def forward_backward(self, inputs):
-        """One training forward + backward pass (graph replay once captured)."""
+    def forward_backward(self, inputs, between=None):
+        """One training forward + backward pass (graph replay once captured).  With a backward split, `between()` runs
+        after the first segment (forward + backward of the steps split_k..) has been enqueued: the data-parallel module
+        starts the all-reduce of the finished gradients there, on its own stream, while the second segment runs."""
         self.is_train = True
         self.load_inputs(inputs)
-        if self._graph_fb is not None:
-            self._graph_fb.replay()
-            return self.outputs
-
-        def body():
-            self._forward_body()
-            self.backward()
-        if self.use_graphs and self._eager_fb >= self.graph_warmup:
-            self._graph_fb = self._capture(body, 'forward+backward')
+        if not self.split_k:
             if self._graph_fb is not None:
                 self._graph_fb.replay()
                 return self.outputs
-        body()
+
+            def body():
+                self._forward_body()
+                self.backward()
+            if self.use_graphs and self._eager_fb >= self.graph_warmup:
+                self._graph_fb = self._capture(body, 'forward+backward')
+                if self._graph_fb is not None:
+                    self._graph_fb.replay()
+                    return self.outputs
+            body()
+            self._eager_fb += 1
+            return self.outputs
+
+        def seg_a():
+            self._forward_body()
+            self.backward('a')
+
+        def seg_b():
+            self.backward('b')
+        if self._graph_fb is None and self.use_graphs and self._eager_fb >= self.graph_warmup:
+            ga = self._capture(seg_a, 'forward + first backward segment')
+            gb = self._capture(seg_b, 'second backward segment', pool=ga.pool()) if ga is not None else None
+            if ga is not None and gb is not None:
+                self._graph_fb = (ga, gb)
+        if self._graph_fb is not None:
+            self._graph_fb[0].replay()
+            if between is not None:
+                between()
+            self._graph_fb[1].replay()
+            return self.outputs
+        seg_a()
+        if between is not None:
+            between()
+        seg_b()
         self._eager_fb += 1
         return self.outputs
 

@@ -115,8 +115,11 @@ class Module(object):
         key = tuple(sorted((k, tuple(v)) for k, v in shapes.items()))
         ex = self._exes.get(key)
         if ex is None:
+            # data parallel: backward in two segments, the first segment's gradients are all-reduced under the second
+            ov = os.environ.get('SNIPER_OVERLAP_ALLREDUCE', '1')
+            split = self.for_training and ((self.world > 1 and ov != '0') or ov == 'force')
             ex = Executor(self.symbol, dict(shapes), for_training=self.for_training, fixed_param_names=self.fixed_param_names,
-                          device=self._device)
+                          device=self._device, split_backward=split)
             if self._arg_params is not None:
                 ex.set_params(self._arg_params, self._aux_params)
             if len(self._exes) >= 8 and not self.for_training:      # bound the activation memory of stale shapes
@@ -225,17 +228,47 @@ class Module(object):
         self.exe.backward()
 
     def forward_backward(self, data_batch):
-        """The training step's compute: one hipGraph replay once the executor has captured it."""
-        self.exe.forward_backward(self._feed(data_batch))
+        """The training step's compute: one hipGraph replay once the executor has captured it (two with a split
+        backward: the first segment's gradient all-reduce is started between them)."""
+        self._comm_event = None
+        self.exe.forward_backward(self._feed(data_batch), between=self._allreduce_first_segment if self.exe.split_k else None)
+
+    def _half_buf(self):
+        exe = self.exe
+        if getattr(exe, '_half_buf', None) is None:
+            n = max([b for _, half, _, b in exe.ar_ranges if half] or [0])
+            exe._half_buf = torch.empty(max(n, 8), dtype=torch.float16, device=exe.arena_grad.device)
+        return exe._half_buf
+
+    def _allreduce_first_segment(self):
+        """Gradients of the steps behind the split (heads, RPN, late trunk) are final: sum them over the ranks on a
+        communication stream while the main stream runs the second backward segment (disjoint arena ranges)."""
+        from ..parallel import allreduce_ranges
+        d = _dist()
+        if d is None or d.get_world_size() == 1:
+            return
+        exe = self.exe
+        if getattr(self, '_comm_stream', None) is None:
+            self._comm_stream = torch.cuda.Stream(device=exe.arena_grad.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self._comm_stream.wait_event(ready)
+        with torch.cuda.stream(self._comm_stream):
+            allreduce_ranges(exe.grad_arena(), [(h, a, b) for ph, h, a, b in exe.ar_ranges if ph == 0], d, self._half_buf())
+            self._comm_event = torch.cuda.Event()
+            self._comm_event.record(self._comm_stream)
 
     def update(self):
-        from ..parallel import allreduce_gradients
+        from ..parallel import allreduce_ranges
         d = _dist()
         if d is not None and d.get_world_size() > 1:          # sum over ranks == kvstore 'device' push/pull
             exe = self.exe
-            if getattr(exe, '_half_buf', None) is None and exe.half_elems > 0:
-                exe._half_buf = torch.empty(exe.half_elems, dtype=torch.float16, device=exe.arena_grad.device)
-            allreduce_gradients(exe.grad_arena(), d, half_elems=exe.half_elems, half_buf=getattr(exe, '_half_buf', None))
+            first_done = getattr(self, '_comm_event', None) is not None
+            rest = [(h, a, b) for ph, h, a, b in exe.ar_ranges if not (first_done and ph == 0)]
+            allreduce_ranges(exe.grad_arena(), rest, d, self._half_buf())
+            if first_done:
+                torch.cuda.current_stream().wait_event(self._comm_event)
+                self._comm_event = None
         sched = self.opt['lr_scheduler']
         lr = sched(self.exe.num_update + 1) if sched is not None else self.opt['lr']
         self.exe.update(lr, self.opt['wd'], self.opt['momentum'], self.opt['rescale_grad'])

@@ -59,6 +59,32 @@ def allreduce_gradients(arena, dist=None, bucket_bytes=256 << 20, half_elems=0, 
     return k
 
 
+def allreduce_ranges(arena, ranges, dist, half_buf=None, bucket_bytes=256 << 20):
+    """Sum the arena ranges [(is_half, begin, end), ...] over all ranks, each in its transport dtype (see
+    allreduce_gradients).  Used by the module for the two segments of a split backward pass."""
+    if dist is None or dist.get_world_size() == 1:
+        return 0
+    use_half = os.environ.get('SNIPER_GRAD_FP16', '1') != '0'
+    k = 0
+    for is_half, a, b in ranges:
+        if b <= a:
+            continue
+        if is_half and use_half:
+            h = half_buf[a:b] if half_buf is not None else torch.empty(b - a, dtype=torch.float16, device=arena.device)
+            _convert(arena[a:b], h)
+            step = max(1, bucket_bytes // 2)
+            for o in range(0, b - a, step):
+                dist.all_reduce(h[o:o + step])
+                k += 1
+            _convert(h, arena[a:b])
+        else:
+            step = max(1, bucket_bytes // arena.element_size())
+            for o in range(a, b, step):
+                dist.all_reduce(arena[o:min(b, o + step)])
+                k += 1
+    return k
+
+
 def _convert(src, dst):
     """fp32 <-> fp16 copy of a flat range: sn_copy2d on the device (the C ABI), torch on the host (gloo CPU tests)."""
     if src.is_cuda:

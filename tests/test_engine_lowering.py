@@ -146,3 +146,34 @@ def test_mask_lowering_plan():
     assert ex.params['rpn_conv_3x3_weight'].int_shape == (512, 9, 1024)
     out = [s for s in ex.steps if type(s).__name__ == 'SoftmaxOutputStep' and s.node.name == 'mask_cls_prob'][0]
     assert ex.shapes[(id(out.node), 0)] == (B * 50, 2, 28, 28)
+
+
+def test_backward_split_for_allreduce_overlap():
+    """Data parallel: the backward pass is cut where about half of its GEMM work is done; the parameters behind the cut
+    (heads, RPN, stage 4) lead the gradient arena and are all-reduced while the rest (stages 2-3) still runs."""
+    B = 2
+    cfg = cfgmod.res101_e2e(batch_images=B)
+    sym = ours.resnet_mx_101_e2e(momentum=0.995).get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, 21 * 32 * 32),
+                  bbox_target=(B, 84, 32, 32), bbox_weight=(B, 84, 32, 32), gt_boxes=(B, 100, 5))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'), split_backward=True)
+    assert ex.split_k > 0
+    names = [s.node.name for s in ex.steps]
+    first_late = names[ex.split_k]
+    assert first_late.startswith('stage4') or first_late.startswith('stage3_unit2'), first_late   # the stage-3 / stage-4 boundary region
+    ph = {n: p.phase for n, p in ex.params.items() if p.trainable}
+    assert ph['fc_new_1_weight'] == 0 and ph['rpn_conv_3x3_weight'] == 0 and ph['stage4_unit3_conv2_weight'] == 0
+    assert ph['stage2_unit1_conv1_weight'] == 1 and ph['stage3_unit2_conv1_weight'] == 1 and ph['stage3_unit2_bn1_gamma'] == 1
+    # arena: phase 0 first, inside a phase the fp16-transported weights first; ranges tile the arena
+    assert [r[0] for r in ex.ar_ranges] == sorted(r[0] for r in ex.ar_ranges)
+    assert ex.ar_ranges[0][2] == 0 and all(a[3] == b[2] for a, b in zip(ex.ar_ranges, ex.ar_ranges[1:])) and ex.ar_ranges[-1][3] == ex.n_trainable
+    early = sum(b - a for p_, h, a, b in ex.ar_ranges if p_ == 0)
+    assert 0.5 < early / ex.n_trainable < 0.9            # most parameter bytes are final with half of the backward to go
+    for n, p in ex.params.items():
+        if p.trainable:
+            r = [q for q in ex.ar_ranges if q[2] <= p.offset < q[3]][0]
+            assert (r[0], r[1]) == (p.phase, p.half_region), n
+    assert len(ex.groups) <= 16
+    # without the split nothing changes
+    ex0 = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    assert ex0.split_k == 0 and all(p.phase == 0 for p in ex0.params.values()) and [r[:2] for r in ex0.ar_ranges] == [[0, True], [0, False]]

@@ -537,3 +537,31 @@ def test_bench_two_rank_control_flow():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 8 and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and d['roofline']['achieved'] > 0 and d['cpu_baseline'] is None
+
+
+def test_split_backward_equals_single_pass(monkeypatch):
+    """The two-segment backward used for all-reduce overlap (forced here on one rank) must train exactly like the single
+    pass: same outputs every step and the same parameters after eager AND graph-replayed steps."""
+    from sniper_amd.train import Trainer
+    runs = []
+    for mode in ('0', 'force'):
+        monkeypatch.setenv('SNIPER_OVERLAP_ALLREDUCE', mode)
+        tr = Trainer(batch_images=2, n_images=4, seed=3)
+        assert (tr.mod.exe.split_k > 0) == (mode == 'force')
+        outs = []
+        for _ in range(5):                       # 2 eager steps, capture, 2 replays
+            o = tr.step()
+            outs.append([t.asnumpy().copy() for t in o])
+        torch.cuda.synchronize()
+        if mode == 'force':
+            assert isinstance(tr.mod.exe._graph_fb, tuple) and len(tr.mod.exe._graph_fb) == 2
+        arg, aux = tr.mod.exe.get_params()
+        runs.append((outs, arg, aux))
+    (o0, a0, x0), (o1, a1, x1) = runs
+    for s, (p, q) in enumerate(zip(o0, o1)):
+        for u, v in zip(p, q):
+            assert np.array_equal(u, v), ('step', s, float(np.abs(u - v).max()))
+    for k in a0:
+        assert np.array_equal(a0[k], a1[k]), (k, float(np.abs(a0[k] - a1[k]).max()))
+    for k in x0:
+        assert np.array_equal(x0[k], x1[k]), k
