@@ -280,12 +280,12 @@ def test_hip_graph_replay_matches_eager(monkeypatch):
     shapes = dict(data=(B, 3, S, S), label=(B, A * F * F), bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F))
     rs = np.random.RandomState(5)
     results = []
-    for graphs in ('0', '1'):
+    for graphs, split in (('0', False), ('1', False), ('1', True)):     # eager, one graph, two graphs (split backward)
         monkeypatch.setenv('SNIPER_HIP_GRAPHS', graphs)
         sym = _mini_graph(mx, A)
         fixed = [n for n in sym.list_arguments() if any(p in n for p in ('conv0', 'bn0', 'bn_data'))]
-        ex = Executor(sym, shapes, True, fixed)
-        assert ex.use_graphs == (graphs == '1')
+        ex = Executor(sym, shapes, True, fixed, split_backward=split)
+        assert ex.use_graphs == (graphs == '1') and (ex.split_k > 0) == split
         if not results:
             args, _, auxs = sym.infer_shape(**shapes)
             P, AUX = {}, {}
@@ -308,13 +308,15 @@ def test_hip_graph_replay_matches_eager(monkeypatch):
         torch.cuda.synchronize()
         if graphs == '1':
             assert ex._graph_fb is not None and ex._graph_up is not None, 'hipGraph capture did not happen'
+            assert isinstance(ex._graph_fb, tuple) == split
         results.append((outs, {k: p.master.clone() for k, p in ex.params.items()}))
-    (oe, pe), (og, pg) = results
-    for a, b in zip(oe, og):
-        for x, y in zip(a, b):
-            assert_close(y.cpu().numpy(), x.cpu().numpy(), 2e-2, 2e-2 * float(x.abs().max()) + 1e-6, 'graph vs eager outputs')
-    for k in pe:
-        assert_close(pg[k].cpu().numpy(), pe[k].cpu().numpy(), 2e-2, 2e-2 * float(pe[k].abs().max()) + 1e-6, 'graph vs eager ' + k)
+    (oe, pe) = results[0]
+    for og, pg in results[1:]:
+        for a, b in zip(oe, og):
+            for x, y in zip(a, b):
+                assert_close(y.cpu().numpy(), x.cpu().numpy(), 2e-2, 2e-2 * float(x.abs().max()) + 1e-6, 'graph vs eager outputs')
+        for k in pe:
+            assert_close(pg[k].cpu().numpy(), pe[k].cpu().numpy(), 2e-2, 2e-2 * float(pe[k].abs().max()) + 1e-6, 'graph vs eager ' + k)
 
 
 def _init_params(sym, shapes, rs, bn_gamma=(0.5, 0.9), bn_beta=(0.3, 1.2)):
@@ -540,28 +542,30 @@ def test_bench_two_rank_control_flow():
 
 
 def test_split_backward_equals_single_pass(monkeypatch):
-    """The two-segment backward used for all-reduce overlap (forced here on one rank) must train exactly like the single
-    pass: same outputs every step and the same parameters after eager AND graph-replayed steps."""
+    """The two-segment backward used for all-reduce overlap (forced here on one rank) computes what the single pass
+    computes on the full R101 network: outputs and every parameter gradient of two eager steps.  (Tolerances, not bits:
+    sn_bias_grad sums its row blocks with atomics, 1e-7 of run-to-run noise; beyond a few steps that noise flips
+    proposal ties in a random-init network, so longer comparisons say nothing -- graph replay of the split is covered on
+    the deterministic mini graph in test_hip_graph_replay_matches_eager.)"""
     from sniper_amd.train import Trainer
     runs = []
     for mode in ('0', 'force'):
         monkeypatch.setenv('SNIPER_OVERLAP_ALLREDUCE', mode)
+        monkeypatch.setenv('SNIPER_HIP_GRAPHS', '0')
         tr = Trainer(batch_images=2, n_images=4, seed=3)
-        assert (tr.mod.exe.split_k > 0) == (mode == 'force')
-        outs = []
-        for _ in range(5):                       # 2 eager steps, capture, 2 replays
-            o = tr.step()
-            outs.append([t.asnumpy().copy() for t in o])
-        torch.cuda.synchronize()
-        if mode == 'force':
-            assert isinstance(tr.mod.exe._graph_fb, tuple) and len(tr.mod.exe._graph_fb) == 2
-        arg, aux = tr.mod.exe.get_params()
-        runs.append((outs, arg, aux))
-    (o0, a0, x0), (o1, a1, x1) = runs
-    for s, (p, q) in enumerate(zip(o0, o1)):
-        for u, v in zip(p, q):
-            assert np.array_equal(u, v), ('step', s, float(np.abs(u - v).max()))
-    for k in a0:
-        assert np.array_equal(a0[k], a1[k]), (k, float(np.abs(a0[k] - a1[k]).max()))
-    for k in x0:
-        assert np.array_equal(x0[k], x1[k]), k
+        ex = tr.mod.exe
+        assert (ex.split_k > 0) == (mode == 'force')
+        rec = []
+        for _ in range(2):
+            tr.mod.forward_backward(tr.batch)
+            torch.cuda.synchronize()
+            rec.append(([t.double().cpu().numpy().copy() for t in ex.outputs],
+                        {n: p.grad.double().cpu().numpy().copy() for n, p in ex.params.items() if p.trainable}))
+            tr.mod.update()
+        runs.append(rec)
+    rel = lambda u, v: float(np.abs(u - v).max() / (np.abs(u).max() + 1e-30))
+    for s, ((o0, g0), (o1, g1)) in enumerate(zip(*runs)):
+        assert max(rel(u, v) for u, v in zip(o0, o1)) <= 1e-5, ('outputs', s)
+        worst = max((rel(g0[n], g1[n]), n) for n in g0)
+        assert worst[0] <= (1e-5 if s == 0 else 1e-3), ('gradients', s, worst)
+    assert len(runs[0][0][1]) > 250
