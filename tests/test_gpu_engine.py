@@ -569,3 +569,36 @@ def test_split_backward_equals_single_pass(monkeypatch):
         worst = max((rel(g0[n], g1[n]), n) for n in g0)
         assert worst[0] <= (1e-5 if s == 0 else 2e-2), ('gradients', s, worst)     # step 1: RoI ties may flip (see above)
     assert len(runs[0][0][1]) > 250
+
+
+def test_no_kernel_reads_uninitialised_memory(monkeypatch):
+    """Every scratch / output buffer of the engine comes from torch.empty.  Poison the caching allocator's free blocks with
+    NaN bit patterns (fp16 and fp32 views of 0xFFFF...) before the executor allocates: a kernel that reads memory nobody
+    wrote -- a partial-sum row, a padded pitch, a tile skipped by an early return -- then shows up as a non-finite output or
+    gradient, or as a difference to the run over zero-filled free blocks."""
+    from sniper_amd.train import Trainer
+    monkeypatch.setenv('SNIPER_HIP_GRAPHS', '0')
+    runs = []
+    for poison in (0x00, 0xFF):
+        torch.cuda.empty_cache()
+        junk = torch.full((6 << 30,), poison, dtype=torch.uint8, device=dev())     # 6 GB of 0x00 / 0xFF bytes ...
+        del junk                                                                    # ... back into the allocator's free list
+        tr = Trainer(batch_images=2, n_images=4, seed=3)
+        ex = tr.mod.exe
+        tr.mod.forward_backward(tr.batch)
+        torch.cuda.synchronize()
+        outs = [t.double().cpu().numpy().copy() for t in ex.outputs]
+        grads = {n: p.grad.double().cpu().numpy().copy() for n, p in ex.params.items() if p.trainable}
+        tr.mod.update()
+        torch.cuda.synchronize()
+        w = {n: p.master.double().cpu().numpy().copy() for n, p in ex.params.items() if p.trainable}
+        assert all(np.isfinite(o).all() for o in outs), 'non-finite output with poison 0x%02x' % poison
+        bad = [n for n, g in grads.items() if not np.isfinite(g).all()] + [n for n, v in w.items() if not np.isfinite(v).all()]
+        assert not bad, ('non-finite gradients / weights with poison 0x%02x' % poison, bad[:8])
+        runs.append((outs, grads))
+        del tr, ex
+    rel = lambda u, v: float(np.abs(u - v).max() / (np.abs(u).max() + 1e-30))
+    (o0, g0), (o1, g1) = runs
+    assert max(rel(u, v) for u, v in zip(o0, o1)) <= 1e-6
+    worst = max((rel(g0[n], g1[n]), n) for n in g0)
+    assert worst[0] <= 1e-5, worst
