@@ -581,7 +581,7 @@ def test_no_kernel_reads_uninitialised_memory(monkeypatch):
     runs = []
     for poison in (0x00, 0xFF):
         torch.cuda.empty_cache()
-        junk = torch.full((6 << 30,), poison, dtype=torch.uint8, device=dev())     # 6 GB of 0x00 / 0xFF bytes ...
+        junk = torch.full((6 << 30,), poison, dtype=torch.uint8, device='cuda')     # 6 GB of 0x00 / 0xFF bytes ...
         del junk                                                                    # ... back into the allocator's free list
         tr = Trainer(batch_images=2, n_images=4, seed=3)
         ex = tr.mod.exe
