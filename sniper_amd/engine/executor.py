@@ -149,6 +149,7 @@ class Executor(object):
         self.side_stream = None
         self.use_side_stream = for_training and os.environ.get('SNIPER_WGRAD_STREAM', '1') != '0' and self.device.type == 'cuda'
         self._keepalive = []
+        self._side_reads = set()     # storages the side stream may still be reading (see grad_slot)
         self._graph_fb = self._graph_up = None
         self._eager_fb = self._eager_up = 0
 
@@ -206,10 +207,18 @@ class Executor(object):
 
     # ---- gradient plumbing -------------------------------------------------------------------
     def grad_slot(self, v):
-        """-> (tensor in v's own format, accumulate?).  First writer overwrites, later ones add."""
+        """-> (tensor in v's own format, accumulate?).  First writer overwrites, later ones add (in place).
+        A gradient tensor can be shared: a residual add hands the SAME tensor to both operands (add_grad), so the tensor
+        about to be accumulated into may be the dY a convolution's weight-gradient kernels are still reading on the side
+        stream.  If it was handed to the side stream, the main stream waits for the side stream first."""
         if v.grad is None:
             v.grad = self.empty(v.t.shape, v.t.dtype)
             return v.grad, False
+        if self._side_reads and v.grad.untyped_storage().data_ptr() in self._side_reads:
+            ev = torch.cuda.Event()
+            ev.record(self.side_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._side_reads.clear()
         return v.grad, True
 
     def add_grad(self, v, g, g_fmt):
@@ -585,6 +594,9 @@ class Executor(object):
         ev.record(main)
         self.side_stream.wait_event(ev)
         self._keepalive.extend(keep)
+        for t in keep:
+            if isinstance(t, torch.Tensor):
+                self._side_reads.add(t.untyped_storage().data_ptr())
         with torch.cuda.stream(self.side_stream):
             fn()
         self._side_used = True
@@ -596,6 +608,7 @@ class Executor(object):
         if segment in (None, 'a'):
             self.zero_grad()
             self._side_used = False
+            self._side_reads.clear()
             for v in self.vals.values():
                 v.grad = None
         steps = self.steps if segment is None else (self.steps[k:] if segment == 'a' else self.steps[:k])
@@ -609,6 +622,7 @@ class Executor(object):
             ev.record(self.side_stream)
             torch.cuda.current_stream().wait_event(ev)
             self._side_used = False
+            self._side_reads.clear()
         self._keepalive = []
 
     def _capture(self, fn, what, pool=None):
