@@ -145,6 +145,12 @@ int sn_bbox_decode(const float *d_rois, const float *d_deltas, const float *d_im
 int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
                 int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
                 int relu, int out_f32, sn_stream_t stream);
+/* Kernel-selection override for sn_conv_fwd / sn_conv_dgrad (tuning hook, tools/conv_tune.py; no reference counterpart):
+ * -1 = built-in per-layer table (default), 0 = register-staged kernels only, 1..9 = that LDS-DMA tile configuration for every
+ * layer that qualifies (see conv_dma.hip).  Results are identical up to fp32 summation order inside a tile's K loop
+ * (the K order itself does not change).  Process-wide; set it while no launch is in flight. */
+int sn_conv_tune(int cfg);
+
 /* sn_conv_fwd that also emits the BatchNorm statistics of its fp16 output (sum and sum of squares of the STORED values per
  * row tile): stats (blocks, 2, Cout) fp32, blocks = sn_conv_fwd_stats_blocks(...) (0: the layer does not qualify -- narrow or
  * unaligned layers -- use sn_conv_fwd + sn_bn_stats).  Consumed by sn_bn_finalize_blocks: the batch-statistics pass of
@@ -157,9 +163,12 @@ int sn_conv_fwd_stats(const void *x, const void *w, const float *bias, const voi
 /* conv0 on the packed stem input (xp (N,Hp,Wp,4) fp16 from sn_pack_stem_input; w [Cout][KH][KWP*4]). */
 int sn_conv_stem_fwd(const void *xp, const void *w, const float *bias, void *y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
                      int out_pix_stride, int KH, int KWP, int stride, int relu, int out_f32, sn_stream_t stream);
-/* Weight gradient of the stem convolution, accumulated into the packed fp32 weight [Cout][KH][KWP*4]. */
+/* Weight gradient of the stem convolution, accumulated into the packed fp32 weight [Cout][KH][KWP*4].  The pixel range is
+ * split over workgroups whose partials go to `ws` (sn_conv_stem_wgrad_workspace_bytes) and are summed in split order --
+ * deterministic, no atomics; without scratch the layer runs unsplit. */
+size_t sn_conv_stem_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int KH, int KWP);
 int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp, int Wp, int Ho, int Wo, int Cout, int dy_pix_stride,
-                       int KH, int KWP, int stride, sn_stream_t stream);
+                       int KH, int KWP, int stride, void *ws, size_t ws_bytes, sn_stream_t stream);
 /* Data gradient; wt = weights as [Cin][KH*KW][Cout] fp16; `accumulate` (fp16, may alias dx) is added. */
 int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
                   int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil,
@@ -177,6 +186,11 @@ int sn_conv_dgrad_bn(const void *dy, const void *wt, const void *accumulate, voi
 /* Weight gradient, accumulated (+=) into dw fp32 [Cout][KH*KW][Cin].  Layers whose weight tensor is small relative to
  * the pixel count are split over K; with ws = sn_conv_wgrad_workspace_bytes(...) bytes of scratch the partials are
  * reduced without atomics (deterministic); ws may be NULL (atomic accumulation). */
+/* Kernel-selection override for sn_conv_wgrad (tuning hook, tools/wgrad_tune.py): LDS-DMA stages of the flat (1x1 / FC)
+ * kernel {-1 built-in, 0 off, 2, 3} and of the all-taps 3x3 kernel {-1, 0, 3, 4}; target_workgroups = the workgroup count
+ * the K-split aims at (0 = built-in; fewer workgroups = fewer, larger split-K partial slabs).  Must be set before the workspace query
+ * of the launches it affects (the K-split count depends on it). */
+int sn_conv_wgrad_tune(int flat_stages, int taps_stages, int target_workgroups);
 size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH, int KW,
                                      int stride, int pad, int dil);
 int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride, int Cout,

@@ -23,37 +23,9 @@
 //
 // The weight gradient needs both operands transposed (the contraction index is the pixel, which is
 // the slow dimension of both dY and X); see conv_wgrad_kernel below.
-#include "common.h"
+#include "conv_common.h"
 
 #include <stdlib.h>
-
-typedef _Float16 half_t;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-struct ConvParams {
-  const half_t *x;  // source activations
-  const half_t *w;  // [Nout][taps][Cin] fp16
-  void *y;          // destination (fp16 or fp32)
-  const float *bias;   // [Nout] or null
-  const half_t *res;   // residual added in the epilogue (fp16, pixel stride res_ps) or null
-  int N, H, W;         // source dims
-  int Cin, in_ps;      // K per tap, source pixel stride (elements)
-  int Ho, Wo;          // destination spatial dims
-  int Nout, out_ps, res_ps;
-  int KH, KW, stride, pad, dil;
-  int M;               // N*Ho*Wo
-  int relu, out_f32;
-  unsigned x_bytes, w_bytes;  // addressable extent of x / w (buffer-descriptor bounds of the pipelined kernel)
-  // optional BatchNorm BACKWARD statistics of a data gradient (dgrad output = dL/d(act(BN(bn_x)))): with bn_x set, `stats`
-  // receives per row tile [mt][2][Nout] = sum g, sum g * (bn_x - mean), g = stored dx masked by the fused activation
-  const half_t *bn_x = nullptr;
-  const float *bn_scale = nullptr, *bn_shift = nullptr, *bn_mean = nullptr;
-  int bn_x_ps = 0, bn_act = 0;
-  float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
-                       // STORED fp16 values (what bn_stats_kernel would read back), or null
-};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
 
@@ -496,21 +468,55 @@ static int conv_check(const ConvParams &p, const char *who) {
   return SN_OK;
 }
 
-// which kernel a layer takes: BM = 64 / 128 -> conv_igemm_p2_kernel, 0 -> conv_igemm_kernel
+// which kernel a layer takes: dma = 1..kConvDmaConfigs -> conv_dma_kernel (conv_dma.hip) with that tile configuration;
+// else BM = 64 / 128 -> conv_igemm_p2_kernel, 0 -> conv_igemm_kernel
 struct ConvPlan {
-  int bm, mtiles, ntiles;
+  int bm, mtiles, ntiles, dma;
   unsigned x_bytes, w_bytes;
 };
+// Tuning override (tools/conv_tune.py, tests): -1 = the built-in table, 0 = register-staged kernels only, 1..kConvDmaConfigs = that
+// LDS-DMA configuration for every layer that qualifies.  Process-wide; not meant to change while launches are in flight.
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+static int g_conv_cfg = env_int("SNIPER_CONV_CFG", -1);   // A/B runs of whole programs (bench.py) without code changes
+SN_EXPORT int sn_conv_tune(int cfg) {
+  SN_REQUIRE(cfg >= -1 && cfg <= kConvDmaConfigs, "sn_conv_tune: configuration %d out of range", cfg);
+  g_conv_cfg = cfg;
+  return SN_OK;
+}
+
+// Built-in choice for a layer that qualifies for the pipelined kernels: M output pixels, Nout channels, nk 64-deep K-steps.
+// Table measured on MI355X with tools/conv_tune.py (profiles/r02_conv_tune.txt).
+static int conv_dma_choice(int M, int Nout, int nk) {
+  const long t128 = (long)sn_div_up(M, 128) * sn_div_up(Nout, 128), t64 = (long)sn_div_up(M, 64) * sn_div_up(Nout, 128);
+  if (Nout <= 128) return nk >= 64 ? 5 : 6;          // one column tile: 64-row tiles, deeper ring for long contractions
+  if (t128 >= 3840 && nk >= 8) return 7;              // >= 3.75 tiles of 256 x 256 per CU: the tile with the least LDS / L2 bytes per FLOP
+  if (nk >= 128) return (Nout >= 1024 && M < 8192) ? 4 : 1;
+  if (t64 <= 2560) return 6;                          // <= 10 resident 64 x 128 workgroups per CU over the launch: 3 per CU co-resident
+  return 1;
+}
+
 static ConvPlan conv_plan(const ConvParams &p) {
-  // BN = 64 when the output is narrow (stage1 / RPN heads), 128 otherwise.  Layers whose taps are whole 64-channel K-steps
-  // and 16-byte addressable take the pipelined kernel.
-  ConvPlan q = {0, 0, 0, 0u, 0u};
+  // Layers whose taps are whole 64-channel K-steps and 16-byte addressable take a pipelined kernel; narrow outputs
+  // (stage1 / RPN heads) and the packed stem stay on conv_igemm_kernel.
+  ConvPlan q = {0, 0, 0, 0, 0u, 0u};
   const unsigned long x_bytes = ((unsigned long)p.N * p.H * p.W - 1) * p.in_ps * 2 + (unsigned long)p.Cin * 2;
   const unsigned long w_bytes = (unsigned long)p.Nout * p.KH * p.KW * p.Cin * 2;
   if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul &&
       !getenv("SNIPER_CONV_V1")) {
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
+    const int cfg = g_conv_cfg >= 0 ? g_conv_cfg : conv_dma_choice(p.M, p.Nout, p.KH * p.KW * (p.Cin / 64));
+    if (cfg > 0) {
+      const ConvDmaConfig c = conv_dma_config(cfg);
+      q.dma = cfg;
+      q.bm = c.bm;
+      q.ntiles = sn_div_up(p.Nout, c.bn);
+      q.mtiles = sn_div_up(p.M, c.bm);
+      return q;
+    }
     q.ntiles = sn_div_up(p.Nout, 128);
     const char *force = getenv("SNIPER_CONV_BM");
     const bool small = force ? atoi(force) == 64 : sn_div_up(p.M, 128) * q.ntiles < 448;   // < ~1.75 workgroups per CU
@@ -523,6 +529,12 @@ static ConvPlan conv_plan(const ConvParams &p) {
 template <bool DGRAD>
 static int conv_launch(const ConvParams &p, hipStream_t s) {
   const ConvPlan pl = conv_plan(p);
+  if (pl.dma) {
+    ConvParams q = p;
+    q.x_bytes = pl.x_bytes;
+    q.w_bytes = pl.w_bytes;
+    return conv_dma_launch(q, DGRAD, pl.dma, s);
+  }
   if (pl.bm) {
     ConvParams q = p;
     q.x_bytes = pl.x_bytes;
@@ -680,16 +692,6 @@ SN_EXPORT int sn_conv_dgrad_bn(const void *dy, const void *wt, const void *accum
 // Pixels are walked row by row (img, oy) in chunks of 32 consecutive ox so that the source row and
 // validity are scalar per step; 1x1/stride-1 layers and FCs pass the whole tensor as one long row.
 // ============================================================================================
-struct WgradParams {
-  const half_t *dy;  // (N, Ho, Wo, Cout) pixel stride dy_ps
-  const half_t *x;   // (N, H, W, Cin)    pixel stride x_ps
-  float *dw;         // [Cout][taps][Cin] fp32, accumulated into
-  int N, H, W, Ho, Wo, Cin, Cout, dy_ps, x_ps;
-  int KH, KW, stride, pad, dil;
-  int units_per_split;  // 32-pixel K chunks handled per blockIdx.z split
-  float *slab;          // split-K partials [split][Cout][taps][Cin] (plain stores, reduced by wgrad_reduce_kernel) or null
-  size_t slab_stride;   // elements per split
-};
 
 __device__ __forceinline__ half8 gather8(const half_t *base, int stride_elems, unsigned valid_mask) {
   half8 v;
@@ -763,7 +765,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int ci = ci0 + j * 16 + fr;
-        if (ci < p.Cin) atomicAdd(p.dw + ((size_t)co * taps + tap) * p.Cin + ci, acc[i][j][rr]);
+        if (ci < p.Cin) {
+          // one owner per element: plain store into this split's slab, or read-modify-write of dw when unsplit
+          const size_t e = ((size_t)co * taps + tap) * p.Cin + ci;
+          if (p.slab) p.slab[(size_t)split * p.slab_stride + e] = acc[i][j][rr];
+          else p.dw[e] += acc[i][j][rr];
+        }
       }
     }
 }
@@ -968,10 +975,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (ci + r < p.Cin) q[r] = acc[i][j][r];
-      } else {
+      } else {   // unsplit: this workgroup is the only writer of its tile
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (ci + r < p.Cin) atomicAdd(q + r, acc[i][j][r]);
+          if (ci + r < p.Cin) q[r] += acc[i][j][r];
       }
     }
   }
@@ -996,11 +1003,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
-// K-split plan shared by the workspace query and the launch
+// K-split plan shared by the workspace query and the launch.  kind: 0 = conv_wgrad_tr_kernel (taps in the grid) or, for
+// operands that are not 16-byte addressable, conv_wgrad_kernel; 1 / 2 = the LDS-DMA kernels of conv_wgrad_dma.hip.
 struct WgradPlan {
-  int gx, gy, taps, nunits, splits, units_per_split, Ho, Wo, flat;
+  int gx, gy, taps, nunits, splits, units_per_split, Ho, Wo, flat, kind, stages;
   bool vec_ok;
 };
+// Tuning override (tools/wgrad_tune.py, tests): stages of the flat / all-taps LDS-DMA kernels; -1 = built-in choice,
+// 0 = that kernel off (register-staged kernel instead).  Process-wide.
+static int g_wgrad_flat = env_int("SNIPER_WGRAD_FLAT", -1), g_wgrad_taps = env_int("SNIPER_WGRAD_TAPS", -1);
+static int g_wgrad_wgs = env_int("SNIPER_WGRAD_WGS", 0);   // K-split target (workgroups per launch); 0 = built-in
+SN_EXPORT int sn_conv_wgrad_tune(int flat_stages, int taps_stages, int target_workgroups) {
+  SN_REQUIRE(target_workgroups >= 0 && target_workgroups <= 4096, "sn_conv_wgrad_tune: bad workgroup target");
+  g_wgrad_wgs = target_workgroups;
+  SN_REQUIRE((flat_stages == -1 || flat_stages == 0 || flat_stages == 2 || flat_stages == 3) &&
+                 (taps_stages == -1 || taps_stages == 0 || taps_stages == 3 || taps_stages == 4),
+             "sn_conv_wgrad_tune: flat stages in {-1, 0, 2, 3}, taps stages in {-1, 0, 3, 4}");
+  g_wgrad_flat = flat_stages;
+  g_wgrad_taps = taps_stages;
+  return SN_OK;
+}
+
 static WgradPlan wgrad_plan(const void *dy, const void *x, int N, int H, int W, int Cin, int x_ps, int Cout, int dy_ps, int KH,
                             int KW, int stride, int pad, int dil) {
   WgradPlan q;
@@ -1014,22 +1037,43 @@ static WgradPlan wgrad_plan(const void *dy, const void *x, int N, int H, int W, 
   // 16-byte channel runs: pixel strides multiples of 8 that cover the last (possibly partial) chunk, aligned bases
   q.vec_ok = dy_ps % 8 == 0 && x_ps % 8 == 0 && dy_ps >= sn_div_up(Cout, 8) * 8 && x_ps >= sn_div_up(Cin, 8) * 8 &&
              ((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0;
-  // K-splits: 2 workgroups per CU (LDS 64 KB)
-  int splits = sn_div_up(q.vec_ok ? 512 : 1024, q.gx * q.gy * q.taps);
-  if (splits > q.nunits / 2) splits = q.nunits / 2;   // at least one 64-pixel K-step per split
+  q.kind = 0;
+  q.stages = 0;
+  int tiles = q.gx * q.gy * q.taps, min_units = 2;   // workgroups per split; least K per split (one 64-pixel step)
+  const int flat_tiles = q.gx * q.gy, taps_tiles = sn_div_up(Cout, 64) * sn_div_up(Cin, 64);
+  const int fs = g_wgrad_flat >= 0 ? g_wgrad_flat : (flat_tiles >= 64 ? 2 : 0);      // built-in choice: profiles/r02_wgrad_tune.txt
+  const int ts = g_wgrad_taps >= 0 ? g_wgrad_taps : (taps_tiles >= 256 ? 4 : 0);
+  if (q.vec_ok && q.flat && fs) {
+    q.kind = 1;
+    q.stages = fs;
+    tiles = flat_tiles;
+  } else if (q.vec_ok && KH == 3 && KW == 3 && stride == 1 && dil <= 4 && ts) {
+    q.kind = 2;
+    q.stages = ts;
+    q.gx = sn_div_up(Cout, 64);
+    q.gy = sn_div_up(Cin, 64);
+    tiles = taps_tiles;
+    min_units = 1;
+  }
+  // K-splits: at most `target` workgroups (2 per CU resident: one more than fits starts a second, nearly empty round --
+  // measured +30 % for 540 instead of 504 workgroups); few tiles -> fewer, longer splits (the slabs are the cost there)
+  const int target = g_wgrad_wgs > 0 ? g_wgrad_wgs : (tiles <= 16 ? 256 : 512);
+  int splits = target / tiles;
+  if (splits > q.nunits / min_units) splits = q.nunits / min_units;
   if (splits < 1) splits = 1;
   q.units_per_split = sn_div_up(q.nunits, splits);
+  if (q.kind == 1 && (q.units_per_split & 1)) ++q.units_per_split;   // whole 64-pixel K-steps
   q.splits = sn_div_up(q.nunits, q.units_per_split);
   return q;
 }
 
-// Scratch for the split-K partials of sn_conv_wgrad (0 when the layer needs no split).  Pointer alignment is assumed
-// (the query has no pointers); an unaligned call falls back to the atomic kernel and ignores the workspace.
+// Scratch for the split-K partials of sn_conv_wgrad (0 when the layer needs no split).  Without it (or with too little)
+// the layer runs unsplit -- slower, same result modulo summation order; there is no atomic accumulation anywhere.
 SN_EXPORT size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH,
                                                int KW, int stride, int pad, int dil) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const WgradPlan q = wgrad_plan(nullptr, nullptr, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil);
-  if (!q.vec_ok || q.splits <= 1) return 0;
+  if (q.splits <= 1) return 0;
   return sn_align(sizeof(float) * (size_t)q.splits * Cout * q.taps * Cin);
 }
 
@@ -1042,32 +1086,34 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dy_ps = dy_pix_stride; p.x_ps = x_pix_stride;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   SN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sn_conv_wgrad: bad dims");
-  const WgradPlan q = wgrad_plan(dy, x, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil);
+  WgradPlan q = wgrad_plan(dy, x, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil);
   p.Ho = q.Ho; p.Wo = q.Wo;
   SN_REQUIRE(p.Ho > 0 && p.Wo > 0, "sn_conv_wgrad: bad dims");
   SN_REQUIRE((long)N * H * W * x_pix_stride < (1l << 31) && (long)N * p.Ho * p.Wo * dy_pix_stride < (1l << 31),
              "sn_conv_wgrad: tensor too large for 32-bit offsets");
   if (q.flat) { p.W = p.Wo = N * H * W; p.H = p.Ho = 1; p.N = 1; }
-  p.units_per_split = q.units_per_split;
   const size_t n = (size_t)Cout * q.taps * Cin;
-  const size_t need = sizeof(float) * (size_t)q.splits * n;
   p.slab = nullptr;
   p.slab_stride = n;
+  if (q.splits > 1) {
+    if (ws && ws_bytes >= sizeof(float) * (size_t)q.splits * n && ((uintptr_t)ws % 16) == 0) p.slab = (float *)ws;
+    else { q.splits = 1; q.units_per_split = q.nunits + (q.nunits & 1); }   // no scratch: one owner per element, no split
+  }
+  p.units_per_split = q.units_per_split;
   hipStream_t s = sn_stream(stream);
-  const dim3 grid(q.gx, q.gy, q.taps * q.splits);
-  if (q.vec_ok) {
-    if (q.splits > 1 && ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) p.slab = (float *)ws;
-    hipLaunchKernelGGL(conv_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
-    SN_CHECK_LAUNCH();
-    if (p.slab) {
-      long blocks = (long)((n / 4 + 255) / 256);
-      if (blocks > 4096) blocks = 4096;
-      if (blocks < 1) blocks = 1;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)p.slab, q.splits, n, dw);
-      SN_CHECK_LAUNCH();
-    }
+  if (q.kind) {
+    if (int rc = wgrad_dma_launch(p, q.kind, q.stages, q.splits, s)) return rc;
   } else {
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    const dim3 grid(q.gx, q.gy, q.taps * q.splits);
+    if (q.vec_ok) hipLaunchKernelGGL(conv_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    SN_CHECK_LAUNCH();
+  }
+  if (p.slab) {
+    long blocks = (long)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)p.slab, q.splits, n, dw);
     SN_CHECK_LAUNCH();
   }
   return SN_OK;
@@ -1077,23 +1123,47 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
 // is trainable: `conv1` in its FIXED_PARAMS matches no parameter name of that network).  dw is the packed weight
 // [Cout][KH][KWP*4] fp32 (accumulated into); geometry as sn_conv_stem_fwd.  The packed rows are only 8-byte aligned,
 // so this runs on the gather kernel (version 1).
+static int stem_wgrad_splits(int Ho, int Wo, int N, int Cout, int KH, int KWP, int *units_per_split) {
+  const int gx = sn_div_up(Cout, 128), gy = sn_div_up(4 * KWP, 128);
+  const int nunits = N * Ho * sn_div_up(Wo, 32);
+  int splits = sn_div_up(1024, gx * gy * KH);
+  if (splits > nunits) splits = nunits;
+  if (splits < 1) splits = 1;
+  *units_per_split = sn_div_up(nunits, splits);
+  return sn_div_up(nunits, *units_per_split);
+}
+
+SN_EXPORT size_t sn_conv_stem_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int KH, int KWP) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || KH <= 0 || KWP <= 0) return 0;
+  int ups;
+  const int splits = stem_wgrad_splits(Ho, Wo, N, Cout, KH, KWP, &ups);
+  return splits > 1 ? sn_align(sizeof(float) * (size_t)splits * Cout * KH * KWP * 4) : 0;
+}
+
 SN_EXPORT int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
-                                 int dy_pix_stride, int KH, int KWP, int stride, sn_stream_t stream) {
+                                 int dy_pix_stride, int KH, int KWP, int stride, void *ws, size_t ws_bytes, sn_stream_t stream) {
   SN_REQUIRE(dy && xp && dw && N > 0 && Ho > 0 && Wo > 0 && Cout > 0, "sn_conv_stem_wgrad: bad arguments");
   SN_REQUIRE((Ho - 1) * stride + KH <= Hp && (Wo - 1) * stride + KWP <= Wp, "sn_conv_stem_wgrad: padded input too small");
   WgradParams p;
   p.dy = (const half_t *)dy; p.x = (const half_t *)xp; p.dw = dw;
   p.N = N; p.H = Hp; p.W = Wp; p.Ho = Ho; p.Wo = Wo; p.Cin = 4 * KWP; p.Cout = Cout; p.dy_ps = dy_pix_stride; p.x_ps = 4;
   p.KH = KH; p.KW = 1; p.stride = stride; p.pad = 0; p.dil = 1;
-  p.slab = nullptr; p.slab_stride = 0;
+  const size_t n = (size_t)Cout * KH * p.Cin;
+  p.slab = nullptr; p.slab_stride = n;
   const int gx = sn_div_up(Cout, 128), gy = sn_div_up(p.Cin, 128);
-  const int nunits = N * Ho * sn_div_up(Wo, 32);
-  int splits = sn_div_up(1024, gx * gy * KH);
-  if (splits > nunits) splits = nunits;
-  if (splits < 1) splits = 1;
-  p.units_per_split = sn_div_up(nunits, splits);
-  splits = sn_div_up(nunits, p.units_per_split);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, KH * splits), dim3(256), 0, sn_stream(stream), p);
+  int splits = stem_wgrad_splits(Ho, Wo, N, Cout, KH, KWP, &p.units_per_split);
+  if (splits > 1) {
+    if (ws && ws_bytes >= sizeof(float) * (size_t)splits * n && ((uintptr_t)ws % 16) == 0) p.slab = (float *)ws;
+    else { splits = 1; p.units_per_split = N * Ho * sn_div_up(Wo, 32); }   // no scratch: unsplit, one owner per element
+  }
+  hipStream_t s = sn_stream(stream);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, KH * splits), dim3(256), 0, s, p);
   SN_CHECK_LAUNCH();
+  if (p.slab) {
+    long blocks = (long)((n / 4 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)p.slab, splits, n, dw);
+    SN_CHECK_LAUNCH();
+  }
   return SN_OK;
 }

@@ -1,0 +1,58 @@
+// conv_common.h -- types shared by the convolution translation units (conv.hip: register-staged kernels, weight gradient,
+// C-ABI entry points; conv_dma.hip: LDS-DMA pipelined implicit GEMM).  Internal, not part of the C ABI.
+#pragma once
+#include "common.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+  const half_t *x;  // source activations
+  const half_t *w;  // [Nout][taps][Cin] fp16
+  void *y;          // destination (fp16 or fp32)
+  const float *bias;   // [Nout] or null
+  const half_t *res;   // residual added in the epilogue (fp16, pixel stride res_ps) or null
+  int N, H, W;         // source dims
+  int Cin, in_ps;      // K per tap, source pixel stride (elements)
+  int Ho, Wo;          // destination spatial dims
+  int Nout, out_ps, res_ps;
+  int KH, KW, stride, pad, dil;
+  int M;               // N*Ho*Wo
+  int relu, out_f32;
+  unsigned x_bytes, w_bytes;  // addressable extent of x / w (buffer-descriptor bounds of the pipelined kernel)
+  // optional BatchNorm BACKWARD statistics of a data gradient (dgrad output = dL/d(act(BN(bn_x)))): with bn_x set, `stats`
+  // receives per row tile [mt][2][Nout] = sum g, sum g * (bn_x - mean), g = stored dx masked by the fused activation
+  const half_t *bn_x = nullptr;
+  const float *bn_scale = nullptr, *bn_shift = nullptr, *bn_mean = nullptr;
+  int bn_x_ps = 0, bn_act = 0;
+  float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
+                       // STORED fp16 values (what bn_stats_kernel would read back), or null
+};
+
+
+// LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: 1..kConvDmaConfigs, see conv_dma_config().
+struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };
+constexpr int kConvDmaConfigs = 9;
+ConvDmaConfig conv_dma_config(int cfg);
+int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
+
+// ---- weight gradient (conv.hip: gather / register-staged kernels; conv_wgrad_dma.hip: LDS-DMA kernels)
+struct WgradParams {
+  const half_t *dy;  // (N, Ho, Wo, Cout) pixel stride dy_ps
+  const half_t *x;   // (N, H, W, Cin)    pixel stride x_ps
+  float *dw;         // [Cout][taps][Cin] fp32, accumulated into
+  int N, H, W, Ho, Wo, Cin, Cout, dy_ps, x_ps;
+  int KH, KW, stride, pad, dil;
+  int units_per_split;  // 32-pixel K chunks handled per blockIdx.z split
+  float *slab;          // split-K partials [split][Cout][taps][Cin] (plain stores, reduced by wgrad_reduce_kernel) or null
+  size_t slab_stride;   // elements per split
+};
+
+// LDS-DMA weight-gradient kernels.  kind 1: "flat" contraction over one long row of pixels (1x1 / stride 1 / pad 0
+// convolutions, FullyConnected, the deformable convolution's column GEMM), 128 (co) x 128 (ci) tile per workgroup,
+// grid (Cout/128, Cin/128, splits).  kind 2: KxK stride-1 convolution with ALL taps in one workgroup, 64 (co) x 64 (ci) x
+// taps tile, grid (Cout/64, Cin/64, splits).  p.units_per_split / p.slab as for conv_wgrad_tr_kernel; with p.slab == nullptr
+// (one split) the tile is added to p.dw with plain read-modify-write stores.
+int wgrad_dma_launch(const WgradParams &p, int kind, int stages, int splits, hipStream_t s);

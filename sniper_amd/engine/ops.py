@@ -490,8 +490,10 @@ class ConvolutionStep(_GemmLike):
     def launch_wgrad(self, dy, Op, x):
         if self.is_stem:
             # the packed input self.xp still holds this step's image batch (written by launch_fwd)
+            need = hip.query('sn_conv_stem_wgrad_workspace_bytes', self.N, self.Ho, self.Wo, self.O, self.k[0], self.KWP)
+            ws = self.ex.ws.get(need) if need else None
             hip.call('sn_conv_stem_wgrad', dy, self.xp, self.w.grad, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O, Op,
-                     self.k[0], self.KWP, self.s[0], hip.stream())
+                     self.k[0], self.KWP, self.s[0], ws, need, hip.stream())
             return
         if self.depthwise:
             hip.call('sn_dwconv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, Op, self.C, self.k[0], self.k[1],

@@ -114,8 +114,54 @@ def test_conv_stem_packed_7x7():
     assert_close(got, want, 1e-2, 1e-2 * np.abs(want).max(), 'stem conv')
 
 
+@pytest.fixture
+def conv_tuning():
+    """Restores the built-in kernel selection after a test that forced one (sn_conv_tune / sn_conv_wgrad_tune are process-wide)."""
+    hip = _hip()
+    yield hip
+    hip.call('sn_conv_tune', -1)
+    hip.call('sn_conv_wgrad_tune', -1, -1, 0)
+
+
 @pytest.mark.parametrize('case', CONV_CASES[:7] + CONV_CASES[8:])
 def test_conv_dgrad_wgrad(case):
+    _check_dgrad_wgrad(case)
+
+
+# layers the pipelined kernels accept (Cin % 64 == 0, Cout > 64): every LDS-DMA tile configuration, forward + data gradient
+DMA_CASES = [CONV_CASES[i] for i in (0, 2, 3, 8, 9, 11, 12)]
+
+
+@pytest.mark.parametrize('cfg', list(range(1, 10)))
+def test_conv_dma_configurations(cfg, conv_tuning):
+    """conv_dma_kernel (csrc/conv_dma.hip): each (tile, waves, ring depth) configuration forced on layers with padding taps,
+    stride 2, dilation, ragged M / Cout tiles, bias + residual + ReLU and the scalar epilogue, against torch-CPU fp32."""
+    conv_tuning.call('sn_conv_tune', cfg)
+    for case in DMA_CASES:
+        N, C, H, W, O, K, s, p, d, hb, hr, relu = case
+        rs = np.random.RandomState(cfg * 131 + hash(case) % 2**20)
+        x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+        w = (rs.standard_normal((O, C, K, K)) / np.sqrt(C * K * K)).astype(np.float32)
+        b = rs.standard_normal(O).astype(np.float32) if hb else None
+        want0 = _ref_conv(x, w, b, None, s, p, d, 0)
+        res = rs.standard_normal(want0.shape).astype(np.float32) if hr else None
+        want = _ref_conv(x, w, b, res, s, p, d, relu)
+        got = _conv_fwd(x, w, b, res, s, p, d, relu, 0)
+        assert_close(got, want, 1e-2, 1e-2 * np.abs(want).max(), 'conv fwd cfg %d %s' % (cfg, case))
+        _check_dgrad_wgrad(case, wgrad=False)
+
+
+@pytest.mark.parametrize('mode', [(2, 3, 0), (3, 4, 0), (2, 3, 64), (3, 4, 24), (0, 0, 100)])
+def test_conv_wgrad_dma_kernels(mode, conv_tuning):
+    """wgrad_flat_dma_kernel / wgrad_taps_dma_kernel (csrc/conv_wgrad_dma.hip) forced on 1x1 and 3x3 layers (dilation 2,
+    Wo < 32 and Wo = 32, ragged channel tiles, Cout % 8 != 0), ring depths 2-4, with and without K-splits, against
+    torch-CPU fp32; (0, 0, n) = the register-staged kernel at another split count."""
+    conv_tuning.call('sn_conv_wgrad_tune', *mode)
+    for i in (0, 1, 3, 4, 8, 9, 11, 12):
+        _check_dgrad_wgrad(CONV_CASES[i], dgrad=False)
+
+
+def _check_dgrad_wgrad(case, dgrad=True, wgrad=True):
     hip = _hip()
     N, C, H, W, O, K, s, p, d, _, _, _ = case
     rs = np.random.RandomState(7 + hash(case) % 1000)
@@ -136,15 +182,18 @@ def test_conv_dgrad_wgrad(case):
     w_otI = torch.from_numpy(w_to_otI(w)).to(dev())
     wT = torch.empty((C, K * K, Op), dtype=torch.float16, device=dev())
     hip.call('sn_weight_transpose', w_otI, wT, O, K * K, C, Op, hip.stream())
-    dx = torch.empty((N, H, W, C), dtype=torch.float16, device=dev())
-    hip.call('sn_conv_dgrad', d_dy, wT, None, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, d, 0, hip.stream())
-    torch.cuda.synchronize()
-    assert_close(from_nhwc(dx), want_dx, 1e-2, 1e-2 * np.abs(want_dx).max(), 'dgrad %s' % (case,))
-    # accumulate form: dx2 = dgrad + dx
-    dx2 = dx.clone()
-    hip.call('sn_conv_dgrad', d_dy, wT, dx2, dx2, N, H, W, C, C, Op, Op, C, K, K, s, p, d, 0, hip.stream())
-    torch.cuda.synchronize()
-    assert_close(from_nhwc(dx2), 2 * want_dx, 2e-2, 2e-2 * np.abs(want_dx).max(), 'dgrad accumulate')
+    if dgrad:
+        dx = torch.empty((N, H, W, C), dtype=torch.float16, device=dev())
+        hip.call('sn_conv_dgrad', d_dy, wT, None, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, d, 0, hip.stream())
+        torch.cuda.synchronize()
+        assert_close(from_nhwc(dx), want_dx, 1e-2, 1e-2 * np.abs(want_dx).max(), 'dgrad %s' % (case,))
+        # accumulate form: dx2 = dgrad + dx
+        dx2 = dx.clone()
+        hip.call('sn_conv_dgrad', d_dy, wT, dx2, dx2, N, H, W, C, C, Op, Op, C, K, K, s, p, d, 0, hip.stream())
+        torch.cuda.synchronize()
+        assert_close(from_nhwc(dx2), 2 * want_dx, 2e-2, 2e-2 * np.abs(want_dx).max(), 'dgrad accumulate')
+    if not wgrad:
+        return
     # wgrad (+= into zeroed fp32)
     dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=dev())
     need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, d)
@@ -153,12 +202,12 @@ def test_conv_dgrad_wgrad(case):
     torch.cuda.synchronize()
     got_dw = dw.cpu().numpy().reshape(O, K, K, C).transpose(0, 3, 1, 2)
     assert_close(got_dw, want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'wgrad %s' % (case,))
-    # without scratch the K-splits accumulate with atomics: same result, and += semantics on a non-zero dw
+    # without scratch the layer runs unsplit (one owner per element, no atomics): same result, and += semantics on a non-zero dw
     dw2 = dw.clone()
     hip.call('sn_conv_wgrad', d_dy, to_nhwc_f16(x), dw2, N, H, W, C, C, O, Op, K, K, s, p, d, None, 0, hip.stream())
     torch.cuda.synchronize()
     got2 = dw2.cpu().numpy().reshape(O, K, K, C).transpose(0, 3, 1, 2)
-    assert_close(got2, 2 * want_dw, 1e-2, 2e-2 * np.abs(want_dw).max(), 'wgrad atomic path %s' % (case,))
+    assert_close(got2, 2 * want_dw, 1e-2, 2e-2 * np.abs(want_dw).max(), 'wgrad without scratch %s' % (case,))
 
 
 def test_fc_as_conv_and_bias_grad():
@@ -339,13 +388,23 @@ def test_sgd_and_weight_transpose():
     assert torch.equal(wp[..., :O], wt) and float(wp[..., O:].abs().sum()) == 0
 
 
+CONV_DMA_BM = {1: 128, 2: 128, 3: 256, 4: 128, 5: 64, 6: 64, 7: 256, 8: 128, 9: 128}
+
+
 @pytest.mark.parametrize('N,H,C,O,K,bm,res', [(3, 17, 64, 192, 1, '64', False), (2, 24, 128, 256, 3, '128', True), (5, 9, 64, 128, 3, '64', True),
-                                              (4, 32, 256, 320, 1, '128', False)])
-def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch):
+                                              (4, 32, 256, 320, 1, '128', False), (2, 24, 128, 256, 3, 'dma3', True), (3, 17, 64, 192, 1, 'dma6', False),
+                                              (4, 32, 256, 320, 1, 'dma4', False), (5, 9, 64, 128, 3, 'dma8', True), (2, 24, 128, 256, 3, 'dma7', True)])
+def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch, conv_tuning):
     """sn_conv_fwd_stats: same output as sn_conv_fwd, and the per-row-tile partials sum to the statistics of the STORED
-    fp16 tensor (what sn_bn_stats would read back); both tile heights, ragged M / Cout tiles, residual epilogue."""
+    fp16 tensor (what sn_bn_stats would read back); register-staged kernel at both tile heights and LDS-DMA configurations
+    with 2 / 4 waves along M, ragged M / Cout tiles, residual epilogue."""
     hip = _hip()
-    monkeypatch.setenv('SNIPER_CONV_BM', bm)
+    if bm.startswith('dma'):
+        hip.call('sn_conv_tune', int(bm[3:]))
+        bm = str(CONV_DMA_BM[int(bm[3:])])
+    else:
+        hip.call('sn_conv_tune', 0)
+        monkeypatch.setenv('SNIPER_CONV_BM', bm)
     rs = np.random.RandomState(N * H + O)
     x = rs.standard_normal((N, H, H, C)).astype(np.float32)
     w = (rs.standard_normal((O, K * K, C)) / np.sqrt(K * K * C)).astype(np.float32)
@@ -388,12 +447,17 @@ def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch):
 
 
 @pytest.mark.parametrize('N,H,C,O,K,bm,act', [(3, 17, 128, 192, 1, '64', 1), (2, 24, 128, 256, 3, '128', 1), (4, 12, 192, 64, 3, '64', 0),
-                                              (2, 16, 320, 128, 1, '128', 2)])
-def test_conv_dgrad_bn_epilogue(N, H, C, O, K, bm, act, monkeypatch):
+                                              (2, 16, 320, 128, 1, '128', 2), (2, 24, 128, 256, 3, 'dma1', 1), (3, 17, 128, 192, 1, 'dma5', 1)])
+def test_conv_dgrad_bn_epilogue(N, H, C, O, K, bm, act, monkeypatch, conv_tuning):
     """sn_conv_dgrad_bn: same dx as sn_conv_dgrad, and partials that make sn_bn_backward_blocks reproduce sn_bn_backward
     (dx of the BatchNorm below, dgamma, dbeta) -- ReLU / none / ReLU6 masks, both tile heights, ragged tiles."""
     hip = _hip()
-    monkeypatch.setenv('SNIPER_CONV_BM', bm)
+    if bm.startswith('dma'):
+        hip.call('sn_conv_tune', int(bm[3:]))
+        bm = str(CONV_DMA_BM[int(bm[3:])])
+    else:
+        hip.call('sn_conv_tune', 0)
+        monkeypatch.setenv('SNIPER_CONV_BM', bm)
     rs = np.random.RandomState(N + H + C)
     M = N * H * H
     dy = torch.from_numpy(rs.standard_normal((N, H, H, O)).astype(np.float32)).to(dev()).half()
@@ -780,7 +844,9 @@ def test_stem_conv_3x3_wgrad_packed():
     dy = rs.standard_normal(tuple(yt.shape)).astype(np.float32)
     yt.backward(torch.from_numpy(f16r(dy)))
     dw = torch.zeros((O, K, KWP * 4), dtype=torch.float32, device=dev())
-    hip.call('sn_conv_stem_wgrad', to_nhwc_f16(dy), xp, dw, N, Hp, Wp, Ho, Wo, O, O, K, KWP, s, hip.stream())
+    need = hip.query('sn_conv_stem_wgrad_workspace_bytes', N, Ho, Wo, O, K, KWP)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dw.device)
+    hip.call('sn_conv_stem_wgrad', to_nhwc_f16(dy), xp, dw, N, Hp, Wp, Ho, Wo, O, O, K, KWP, s, ws, need, hip.stream())
     got = dw.cpu().numpy().reshape(O, K, KWP, 4)
     want = wt.grad.numpy().transpose(0, 2, 3, 1)
     assert_close(got[:, :, :K, :3], want, 1e-2, 1e-2 * np.abs(want).max(), 'stem wgrad')
