@@ -111,10 +111,61 @@ def build_reference_cpu_nms(force=False):
     return out
 
 
+# (file, old, new): the only edits made to the lib2to3 output -- py2 integer divisions that py3 turns into floats
+_PY3_FIXES = (("lib/data_utils/data_workers.py", "chip_size / cfg.network.RPN_FEAT_STRIDE", "chip_size // cfg.network.RPN_FEAT_STRIDE"),)
+_PY3_TREES = ("lib", "symbols", "configs")
+_PY3_FILES = ("main_train.py", "main_test.py", "init.py")
+
+
+def build_reference_py3(force=False):
+    """oracle/_ref/py3/: the reference's OWN Python (main_train.py, main_test.py, init.py, lib/, symbols/, configs/) run
+    through ``lib2to3`` -- a derived artefact like the shared objects above (git-ignored, shipped to the GPU box), so that
+    the acceptance test (tests/acceptance_main_train.py: main_train.py's __main__ block executed over sniper_amd's mxnet
+    shim on the GPU) can run where /root/reference does not exist.  Only .py / .yml files are translated / carried; no
+    reference file enters the git history."""
+    if not have_reference():
+        return None
+    import shutil
+
+    out = os.path.join(REF_OUT, "py3")
+    stamp = os.path.join(out, ".built")
+    if not force and os.path.exists(stamp):
+        return out
+    if os.path.isdir(out):
+        shutil.rmtree(out)
+    os.makedirs(out)
+    for f in _PY3_FILES:
+        shutil.copy(os.path.join(REF, f), os.path.join(out, f))
+    for tree in _PY3_TREES:
+        for root, dirs, files in os.walk(os.path.join(REF, tree)):
+            dirs[:] = [d for d in dirs if d not in ("pycocotools", "__pycache__")]
+            rel = os.path.relpath(root, REF)
+            os.makedirs(os.path.join(out, rel), exist_ok=True)
+            for f in files:
+                if f.endswith((".py", ".yml")):
+                    shutil.copy(os.path.join(root, f), os.path.join(out, rel, f))
+    subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for rel, old, new in _PY3_FIXES:
+        path = os.path.join(out, rel)
+        with open(path) as fh:
+            src = fh.read()
+        assert old in src, (rel, old)
+        with open(path, "w") as fh:
+            fh.write(src.replace(old, new))
+    for root, dirs, files in os.walk(out):
+        os.chmod(root, 0o755)
+        for f in files:
+            os.chmod(os.path.join(root, f), 0o644)
+    with open(stamp, "w") as fh:
+        fh.write("lib2to3 of %s\n" % REF)
+    return out
+
+
 def build_all(force=False):
     build_restatement(force)
     build_reference(force)
     build_reference_cpu_nms(force)
+    build_reference_py3(force)
 
 
 if __name__ == "__main__":

@@ -1190,3 +1190,23 @@ class CustomStep(Step):
         self.op.forward(self.ex.is_train, ['write'] * len(outs), ins, outs, [])
         for o, h in zip(self.outs, outs):
             o.t.copy_(torch.from_numpy(h.asnumpy()))
+        self._host = (ins, outs)
+
+    def backward(self):
+        """CustomOp.backward on the host (box_annotator_ohem.py:80-83 assigns zeros): out_grad carries the gradients that
+        reached the outputs (zeros where none did -- `need_top_grad=False` plugins ignore them anyway), every input that
+        wants a gradient receives the plugin's in_grad."""
+        from ..mx import ndarray as nd
+        if not any(v.needs_grad for v in self.ins):
+            for o in self.outs:
+                o.grad = None
+            return
+        ins, outs = self._host
+        out_grad = [nd.NDArray(o.grad.float().cpu().numpy().reshape(o.shape)) if o.grad is not None else nd.zeros(o.shape) for o in self.outs]
+        in_grad = [nd.zeros(v.shape) for v in self.ins]
+        self.op.backward(['write'] * len(in_grad), out_grad, ins, outs, in_grad, [])
+        for v, g in zip(self.ins, in_grad):
+            if v.needs_grad:
+                self.ex.add_grad(v, torch.from_numpy(np.ascontiguousarray(g.asnumpy(), np.float32)).to(self.ex.device), 'f32')
+        for o in self.outs:
+            o.grad = None
