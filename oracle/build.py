@@ -112,7 +112,10 @@ def build_reference_cpu_nms(force=False):
 
 
 # (file, old, new): the only edits made to the lib2to3 output -- py2 integer divisions that py3 turns into floats
-_PY3_FIXES = (("lib/data_utils/data_workers.py", "chip_size / cfg.network.RPN_FEAT_STRIDE", "chip_size // cfg.network.RPN_FEAT_STRIDE"),)
+_PY3_FIXES = (("lib/data_utils/data_workers.py", "chip_size / cfg.network.RPN_FEAT_STRIDE", "chip_size // cfg.network.RPN_FEAT_STRIDE"),
+              ("lib/iterators/MNIteratorBase.py", "self.n_per_gpu = batch_size / nGPUs", "self.n_per_gpu = batch_size // nGPUs"),
+              ("lib/iterators/MNIteratorE2E.py", "self.crop_size[1] / self.cfg.network.RPN_FEAT_STRIDE", "self.crop_size[1] // self.cfg.network.RPN_FEAT_STRIDE"),
+              ("lib/iterators/MNIteratorE2E.py", "self.crop_size[0] / self.cfg.network.RPN_FEAT_STRIDE", "self.crop_size[0] // self.cfg.network.RPN_FEAT_STRIDE"))
 _PY3_TREES = ("lib", "symbols", "configs")
 _PY3_FILES = ("main_train.py", "main_test.py", "init.py")
 

@@ -161,7 +161,7 @@ def infer_node(node, ins, shapes_of_var):
     if op == 'Custom':
         from ..mx import operator as _operator
         prop = _operator.get_prop(a.get('op_type'), a)
-        _, outs, _ = prop.infer_shape([list(s) for s in ins])
+        outs = prop.infer_shape([list(s) for s in ins])[1]      # (in, out) or (in, out, aux): CustomOpProp allows both
         return [tuple(o) for o in outs], par
     raise NotImplementedError('shape inference for %s' % op)
 

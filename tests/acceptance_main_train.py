@@ -23,6 +23,7 @@ of the same chips bit for bit (labels, weights; targets to 1e-6).
 
     python tests/acceptance_main_train.py out.json
 """
+import copy
 import json
 import os
 import runpy
@@ -135,6 +136,7 @@ def _pretrained(mx, work):
 
 def main(out_json, n_images=3):
     import numpy as np
+    out_json = os.path.abspath(out_json)
     work = tempfile.mkdtemp(prefix='sniper_accept_')
     mx = _install_environment(work)
     os.chdir(PY3)
@@ -153,9 +155,10 @@ def main(out_json, n_images=3):
     def recording_worker(self, data):
         seed = 1000 + len(recorded)
         np.random.seed(seed)
+        keep = copy.deepcopy(data) if len(recorded) < 6 else None      # the worker shifts / scales its box arrays in place
         out = ref_worker(self, data)
-        if len(recorded) < 6:
-            recorded.append((seed, data, out))
+        if keep is not None:
+            recorded.append((seed, keep, out))
         return out
 
     dw.anchor_worker.worker = recording_worker
@@ -172,9 +175,10 @@ def main(out_json, n_images=3):
         cb = k.get('batch_end_callback')
         cbs = cb if isinstance(cb, (list, tuple)) else [cb]
 
-        def count(param):
-            batches.append(int(param.nbatch))
-        k['batch_end_callback'] = [c for c in cbs if c is not None] + [count]
+        def count(param):      # ahead of the reference's Speedometer, which resets the metrics after it has logged them
+            names, vals = param.eval_metric.get()
+            batches.append((int(param.nbatch), {n: float(v) for n, v in zip(names, vals)}))
+        k['batch_end_callback'] = [count] + [c for c in cbs if c is not None]
         return _fit(self, train_data, *a, **k)
 
     mx.mod.Module.fit = fit
@@ -183,8 +187,8 @@ def main(out_json, n_images=3):
 
     res = {'batches': len(batches), 'iterator': type(g['train_iter']).__module__ + '.' + type(g['train_iter']).__name__,
            'symbol': type(g['sym_inst']).__module__, 'n_chips': int(len(g['train_iter'])) if hasattr(g['train_iter'], '__len__') else None}
-    names, vals = g['eval_metrics'].get()
-    res['metrics'] = {n: float(v) for n, v in zip(names, vals)}
+    res['metrics'] = batches[-1][1]          # running values at the last batch of the epoch
+    res['metrics_first'] = batches[0][1]
     # parameters moved away from the checkpoint they were initialised from
     arg_now, aux_now = g['mod'].get_params()
     arg0 = g['arg_params']
@@ -228,6 +232,10 @@ def main(out_json, n_images=3):
             'target_maxdiff': float(np.abs(ours['bbox_target'][0].cpu().numpy() - dense_t).max()),
             'gt_equal': bool(np.array_equal(ours['gt_boxes'][0].cpu().numpy(), _np(out[3]).astype(np.float32))),
             'n_fg': int((label == 1).sum()), 'n_bg': int((label == 0).sum()),
+            'label_ndiff': int((ours['label'][0].cpu().numpy().reshape(-1) != label.astype(np.float32)).sum()),
+            'ours_fg_bg': [int((ours['label'][0] == 1).sum()), int((ours['label'][0] == 0).sum())],
+            'gt_maxdiff': float(np.abs(ours['gt_boxes'][0].cpu().numpy() - _np(out[3]).astype(np.float32)).max()),
+            'gt_rows': [int((_np(out[3])[:, 0] >= 0).sum()), int((ours['gt_boxes'][0].cpu().numpy()[:, 0] >= 0).sum())],
         })
     res['anchor_labels'] = cmp
     with open(out_json, 'w') as fh:
