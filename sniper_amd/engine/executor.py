@@ -35,7 +35,7 @@ def _pad8(n):
 class Val(object):
     """One tensor of the graph.  fmt 'act': fp16 channels-last, t has shape (N,H,W,C) (2-D logical
     tensors use H=W=1); fmt 'f32': fp32, reference order, t has the logical shape."""
-    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer')
+    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer', 'grad_alias')
 
     def __init__(self, name, shape, fmt):
         self.name, self.shape, self.fmt = name, tuple(shape), fmt
@@ -46,6 +46,7 @@ class Val(object):
         self.stem = None     # (src f32 NCHW Val, scale, shift) for a BN-folded image input
         self.consumers = 0
         self.producer = None  # the Step whose output this is
+        self.grad_alias = None   # the Val that was handed the SAME gradient tensor by a residual add (Executor.grad_slot)
 
     def nhwc(self):
         s = self.shape
@@ -214,6 +215,15 @@ class Executor(object):
         if v.grad is None:
             v.grad = self.empty(v.t.shape, v.t.dtype)
             return v.grad, False
+        # copy on write: the tensor is also the (not yet consumed) gradient of the residual add's other operand.  In ResNet /
+        # MobileNetV2 that operand's producer has run its backward and dropped the tensor by now (no copy); any other
+        # graph order gets a private copy instead of a silently corrupted dY.
+        p = getattr(v, 'grad_alias', None)
+        if p is not None:
+            v.grad_alias = None
+            if p.grad is not None and p.grad.data_ptr() == v.grad.data_ptr():
+                p.grad_alias = None
+                v.grad = v.grad.clone()
         if self._side_reads and v.grad.untyped_storage().data_ptr() in self._side_reads:
             ev = torch.cuda.Event()
             ev.record(self.side_stream)

@@ -141,6 +141,13 @@ class BatchNormStep(Step):
         # gamma/beta keeps its folded scale/shift
         if not (only_trainable and self.global_stats and not self.gamma.trainable and not self.beta.trainable):
             self._global_ready = False
+            if self.global_stats:
+                # fold the moving statistics NOW (persistent buffers): a forward pass that is a hipGraph replay never comes
+                # back to Python, so a lazy recompute after set_params / a checkpoint load would keep the stale scale / shift
+                g = None if self.fix_gamma else self.gamma.master
+                hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
+                         self.shift, hip.stream())
+                self._global_ready = True
 
     def _use_batch_stats(self):
         return self.ex.is_train and not self.global_stats
@@ -772,6 +779,8 @@ class BinaryStep(Step):
         if op in ('_plus', 'elemwise_add'):
             ex.add_grad(self.lhs, g, fmt)
             ex.add_grad(self.rhs, g, fmt)
+            if self.lhs.grad is not None and self.lhs.grad is self.rhs.grad:      # one tensor, two owners: see Executor.grad_slot
+                self.lhs.grad_alias, self.rhs.grad_alias = self.rhs, self.lhs
         elif op == '_minus':
             ex.add_grad(self.lhs, g, fmt)
             if self.rhs.needs_grad:

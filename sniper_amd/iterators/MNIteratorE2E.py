@@ -13,12 +13,15 @@ per phase for the whole roidb (chip_worker), and the per-batch anchor labelling 
 ``sn_anchor_assign`` call whose outputs stay in HBM -- there is no multiprocessing pool and no pickling
 (the reference's Pool(64).map round trips, :51-63,173).
 
-Image pixels: the reference decodes and resizes JPEGs with OpenCV (im_worker, data_workers.py:80-121).
-OpenCV does not exist here and the benchmark is defined on synthetic chips, so
-pixels come from ``im_source(roidb_entry, crop, flipped) -> (3,H,W) float32``; the default source
-is the seeded N(0, 50^2) generator.
+Image pixels: the reference decodes and resizes JPEGs with OpenCV (im_worker, data_workers.py:80-121).  The default
+source is the GPU ``im_worker`` (sniper_amd/data/im_worker.py: ``roidb[i]['image']`` decoded once, flip + crop + bilinear
+resize + mean subtraction written straight into the batch tensor by ``sn_im_prepare``); a roidb entry whose image cannot
+be opened is an error, not noise.  The benchmark is defined on synthetic chips:
+``im_source='synthetic'`` asks for the seeded N(0, 50^2) generator explicitly (bench.py, the smoke test, the GPU tests);
+a callable ``im_source(roidb_entry, crop, flipped) -> (3,H,W) float32`` is accepted too.
 """
 import math
+import zlib
 
 import numpy as np
 import torch
@@ -32,9 +35,12 @@ from ..data.mask_utils import encode_chip_masks
 
 
 def synthetic_im_source(chip_hw):
-    def src(r, crop, flipped, _cache={}):
-        key = (r.get('image'), float(crop[0][0]), float(crop[0][1]), crop[4])
-        rs = np.random.RandomState(abs(hash(key)) % (2 ** 31))
+    """Seeded N(0, 50^2) chips keyed on (image, crop origin, scale index, flip): a CRC of the key, not hash() -- str hashes
+    are salted per process, and every rank / run must see the same pixels."""
+    def src(r, crop, flipped):
+        key = repr((r.get('image') if isinstance(r.get('image'), str) else None, float(crop[0][0]), float(crop[0][1]),
+                    int(crop[4]), bool(flipped)))
+        rs = np.random.RandomState(zlib.crc32(key.encode()) & 0x7FFFFFFF)
         return (rs.standard_normal((3, chip_hw[0], chip_hw[1])) * 50.0).astype(np.float32)
     return src
 
@@ -56,7 +62,12 @@ class MNIteratorE2E(mx.io.DataIter):
             self.label_name.append('gt_masks')         # encoded polygons (B, 100, 500) (reference :31-32)
         self.chip_worker = chip_worker(config, crop_size[0])
         self.anchors = AnchorAssigner(config, crop_size[0])
-        self.im_source = im_source or synthetic_im_source(crop_size)
+        if im_source is None:           # the reference's behaviour: read roidb[i]['image'] (im_worker, data_workers.py:80-121)
+            from ..data.im_worker import im_worker
+            self.im_worker, self.im_source = im_worker(config, crop_size=crop_size[0]), None
+        else:
+            self.im_worker = None
+            self.im_source = synthetic_im_source(crop_size) if im_source == 'synthetic' else im_source
         self.epiter = 0
         self.seed = 0
         self.batch = None
@@ -153,7 +164,11 @@ class MNIteratorE2E(mx.io.DataIter):
         srange = np.zeros((n, 2), np.float32)
         chipinfo = np.zeros((n, 3), np.float32)
         worker_data = []
-        ims = np.zeros((n, 3, self.crop_size[0], self.crop_size[1]), np.float32)
+        dev = hip.require_gpu()
+        if self.im_worker is not None:      # chips are written in HBM by sn_im_prepare, one launch per chip
+            ims = torch.zeros((n, 3, self.crop_size[0], self.crop_size[1]), dtype=torch.float32, device=dev)
+        else:
+            ims = np.zeros((n, 3, self.crop_size[0], self.crop_size[1]), np.float32)
         for k, (r, cid) in enumerate(zip(roidb, cropids)):
             crop = r['crops'][cid]
             cur_crop, im_scale, height, width, scalei = crop
@@ -165,14 +180,17 @@ class MNIteratorE2E(mx.io.DataIter):
             chipinfo[k] = [height, width, im_scale]
             worker_data.append([[self.crop_size[0], self.crop_size[1], im_scale], cur_crop, im_scale, nids, gtids,
                                 r['boxes'][gtids, :], r['boxes'], r['max_classes'][gtids].reshape(-1, 1)])
-            im = self.im_source(r, crop, r.get('flipped', False))
-            h, w = min(im.shape[1], self.crop_size[0]), min(im.shape[2], self.crop_size[1])
-            ims[k, :, :h, :w] = im[:, :h, :w]
+            if self.im_worker is not None:
+                self.im_worker.worker([r['image'], crop, r.get('flipped', False)], ims[k])
+            else:
+                im = self.im_source(r, crop, r.get('flipped', False))
+                h, w = min(im.shape[1], self.crop_size[0]), min(im.shape[2], self.crop_size[1])
+                ims[k, :, :h, :w] = im[:, :h, :w]
         out = self.anchors.assign(worker_data, seed=self.seed)
         self.seed += 1
-        dev = hip.require_gpu()
-        self.data = [mx.nd.NDArray(torch.from_numpy(ims).to(dev))] if self.cfg.TRAIN.ONLY_PROPOSAL else \
-            [mx.nd.NDArray(torch.from_numpy(ims).to(dev)), mx.nd.NDArray(torch.from_numpy(srange).to(dev)),
+        d_ims = ims if isinstance(ims, torch.Tensor) else torch.from_numpy(ims).to(dev)
+        self.data = [mx.nd.NDArray(d_ims)] if self.cfg.TRAIN.ONLY_PROPOSAL else \
+            [mx.nd.NDArray(d_ims), mx.nd.NDArray(torch.from_numpy(srange).to(dev)),
              mx.nd.NDArray(torch.from_numpy(chipinfo).to(dev))]
         self.label = [mx.nd.NDArray(out['label']), mx.nd.NDArray(out['bbox_target']), mx.nd.NDArray(out['bbox_weight'])]
         if not self.cfg.TRAIN.ONLY_PROPOSAL:

@@ -1,5 +1,6 @@
 """``mx.callback``, ``mx.lr_scheduler``, ``mx.model``, ``mx.random`` subsets."""
 import logging
+import os
 import time
 
 import numpy as np
@@ -71,7 +72,9 @@ def save_checkpoint(prefix, epoch, symbol, arg_params, aux_params):
     d = {('arg:%s' % k): v for k, v in arg_params.items()}
     d.update({('aux:%s' % k): v for k, v in aux_params.items()})
     name = '%s-%04d.params' % (prefix, epoch)
-    nd.save(name, d)
+    tmp = '%s.tmp.%d' % (name, os.getpid())          # readers (and a second writer) never see a torn file
+    nd.save(tmp, d)
+    os.replace(tmp, name)
     logging.info('Saved checkpoint to "%s"', name)
 
 

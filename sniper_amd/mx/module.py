@@ -153,7 +153,22 @@ class Module(object):
         self._aux_params = {k: (v.asnumpy() if hasattr(v, 'asnumpy') else np.asarray(v)) for k, v in aux.items()}
         for ex in self._exes.values():
             ex.set_params(self._arg_params, self._aux_params)
+        self._broadcast_params()
         self.params_initialized = True
+
+    def _broadcast_params(self):
+        """Data parallel: every replica starts from rank 0's parameters (what kvstore.init + pull does in the reference's
+        Module) -- mx.random / np.random draws of the head initialisers differ between processes otherwise."""
+        d = _dist()
+        if d is None or d.get_world_size() == 1:
+            return
+        for ex in self._exes.values():
+            d.broadcast(ex.arena_master, src=0)
+            for t in ex.aux.values():
+                d.broadcast(t, src=0)
+            ex.refresh_compute_copies()
+        arg, aux = self.exe.get_params()
+        self._arg_params, self._aux_params = arg, aux
 
     def set_params(self, arg_params, aux_params, allow_missing=False, force_init=True, allow_extra=True):
         self.init_params(None, arg_params, aux_params, allow_missing, force_init)
@@ -282,6 +297,30 @@ class Module(object):
     def update_metric(self, eval_metric, labels):
         eval_metric.update(labels, self.get_outputs())
 
+    def _sync_epoch(self, train_data, epoch):
+        """Data parallel with a GLOBAL-batch iterator (slice_inputs): every rank builds the epoch's chip database itself, from
+        numpy's global RNG (chip stride, chip permutations, negative-chip choice, index shuffle -- MNIteratorE2E.reset).  All
+        ranks must build the SAME one, or rank r's slice r belongs to a different batch and the per-step all-reduces pair
+        different steps: rank 0's seed is broadcast, numpy is re-seeded, the iterator reset, and the epoch length checked."""
+        d = _dist()
+        if d is None or d.get_world_size() == 1 or not self.slice_inputs:
+            return False
+        dev = getattr(self, '_device', None) or torch.device('cpu')
+        t = torch.zeros(1, dtype=torch.int64, device=dev)
+        if self.rank == 0:
+            t[0] = int(np.random.randint(0, 2 ** 31 - 1))
+        d.broadcast(t, src=0)
+        np.random.seed((int(t.item()) + epoch) % (2 ** 31 - 1))
+        train_data.reset()
+        n = torch.tensor([len(train_data), -len(train_data)], dtype=torch.int64, device=dev) if hasattr(train_data, '__len__') \
+            else None
+        if n is not None:
+            d.all_reduce(n, op=d.ReduceOp.MAX)
+            if int(n[0]) != -int(n[1]):
+                raise RuntimeError('data-parallel ranks built epochs of different length (%d..%d batches worth of chips): the '
+                                   'iterators are not synchronised' % (-int(n[1]), int(n[0])))
+        return True
+
     # ---- training loop (main_train.py:143-146)
     def fit(self, train_data, eval_data=None, eval_metric='acc', epoch_end_callback=None, batch_end_callback=None,
             kvstore='local', optimizer='sgd', optimizer_params=(('learning_rate', 0.01),), eval_end_callback=None,
@@ -299,7 +338,10 @@ class Module(object):
             if hasattr(eval_metric, 'reset'):
                 eval_metric.reset()
             nbatch = 0
-            train_data.reset() if epoch > begin_epoch else None
+            if self._sync_epoch(train_data, epoch):
+                pass                              # the iterator was re-seeded and reset on every rank
+            elif epoch > begin_epoch:
+                train_data.reset()
             for data_batch in train_data:
                 self.forward_backward(data_batch)
                 self.update()
@@ -313,5 +355,9 @@ class Module(object):
                     self.logger.info('Epoch[%d] Train-%s=%f', epoch, name, val)
             self.logger.info('Epoch[%d] Time cost=%.3f', epoch, time.time() - tic)
             arg, aux = self.get_params()
-            for cb in cbs(epoch_end_callback):
-                cb(epoch, self.symbol, arg, aux)
+            if self.rank == 0:                    # replicas are identical: one writer (do_checkpoint / the symbols' checkpoint_callback)
+                for cb in cbs(epoch_end_callback):
+                    cb(epoch, self.symbol, arg, aux)
+            d = _dist()
+            if d is not None and d.get_world_size() > 1:
+                d.barrier()

@@ -38,7 +38,7 @@ class Trainer(object):
         cfg.TRAIN.USE_NEG_CHIPS = n_proposals > 0
         np.random.seed(seed)
         self.roidb = make_roidb(n_images, seed=seed, n_proposals=n_proposals, with_masks=bool(cfg.TRAIN.WITH_MASK))
-        self.iter = MNIteratorE2E(self.roidb, cfg, batch_size=batch_images, nGPUs=1)
+        self.iter = MNIteratorE2E(self.roidb, cfg, batch_size=batch_images, nGPUs=1, im_source='synthetic')   # synthetic chips
         # main_train.py:83-84: the symbol class is named by the config
         import importlib
         name = cfg.get('symbol', 'resnet_mx_101_e2e')

@@ -48,8 +48,35 @@ def _worker(rank, world_size, port, out):
     import sniper_amd.mx as mx
     m = mx.mod.Module(mx.sym.Variable('x'), data_names=['x'], label_names=None)
     ok_local = m.world == world_size and m._local((8, 3, 4, 4)) == (4, 3, 4, 4)
+    # epoch synchronisation: every rank builds its epoch from numpy's global RNG; unsynchronised ranks would slice different
+    # global batches.  Module._sync_epoch re-seeds from rank 0 and resets the iterator: identical order everywhere.
+    class FakeIter(object):
+        def __init__(self, n):
+            self.n, self.order = n, None
+
+        def reset(self):
+            self.order = np.random.permutation(self.n)
+
+        def __len__(self):
+            return self.n
+    m._device = torch.device('cpu')
+    np.random.seed(1234 + 77 * rank)                      # ranks start out of sync, as separately launched processes do
+    it = FakeIter(16)
+    assert m._sync_epoch(it, 0)
+    o = torch.from_numpy(it.order.copy())
+    lo, hi = o.clone(), o.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    ok_sync = bool(torch.equal(lo, hi))
+    m._sync_epoch(it, 1)
+    ok_sync = ok_sync and not np.array_equal(it.order, o.numpy())      # a new epoch is a new order
+    try:
+        m._sync_epoch(FakeIter(16 + 4 * rank), 2)                      # ranks disagree on the epoch length
+        ok_len = False
+    except RuntimeError:
+        ok_len = True
     dist.barrier()
-    out[rank] = int(ok_sum) + 2 * int(ok_slice) + 4 * int(ok_time) + 8 * int(ok_local)
+    out[rank] = int(ok_sum) + 2 * int(ok_slice) + 4 * int(ok_time) + 8 * int(ok_local) + 16 * int(ok_sync) + 32 * int(ok_len)
     dist.destroy_process_group()
 
 
@@ -63,7 +90,7 @@ def test_two_rank_gradient_exchange_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0, 'rank exited with %s' % p.exitcode
-    assert dict(out) == {0: 15, 1: 15}, dict(out)
+    assert dict(out) == {0: 63, 1: 63}, dict(out)
 
 
 def test_single_process_is_a_no_op():

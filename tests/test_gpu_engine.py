@@ -252,22 +252,57 @@ def test_iterator_contract():
     import sniper_amd.mx as mx
     from sniper_amd import config as cfgmod
     from sniper_amd.iterators import MNIteratorE2E
+    from sniper_amd.iterators.MNIteratorE2E import synthetic_im_source
     from sniper_amd.synthetic import make_roidb
     cfg = cfgmod.res101_e2e(batch_images=4)
+    roidb = make_roidb(12, seed=3, n_proposals=300)
+    # the default image source reads roidb[i]['image'] (im_worker, data_workers.py:80-121): an image that cannot be opened is an
+    # error -- training never silently fits noise to real labels
+    with pytest.raises((FileNotFoundError, OSError)):
+        MNIteratorE2E([dict(r) for r in roidb], cfg, batch_size=4, nGPUs=1)
+    rs = np.random.RandomState(0)
+    for r in roidb:
+        r['image'] = rs.randint(0, 256, (r['height'], r['width'], 3)).astype(np.uint8)      # decoded BGR image
     np.random.seed(3)
-    it = MNIteratorE2E(make_roidb(12, seed=3, n_proposals=300), cfg, batch_size=4, nGPUs=1)
+    it = MNIteratorE2E(roidb, cfg, batch_size=4, nGPUs=1)
     assert [k for k, _ in it.provide_data] == ['data', 'valid_ranges', 'im_info']
     assert dict(it.provide_label)['label'] == (4, 21 * 32 * 32) and dict(it.provide_label)['gt_boxes'] == (4, 100, 5)
     assert len(it) % 4 == 0 and len(it) >= it.n_chips
     n = 0
+    means = np.asarray(cfg.network.PIXEL_MEANS, np.float32)
     for batch in it:
         lab = batch.label[0].asnumpy()
         assert set(np.unique(lab)).issubset({-1.0, 0.0, 1.0})
         assert ((lab == 1).sum(1) <= 128).all() and ((lab >= 0).sum(1) <= 256).all()
+        data = batch.data[0].asnumpy()
+        for k, wd in enumerate(batch.worker_data):
+            (x1, y1, x2, y2), sc = [int(v) for v in wd[1]], float(wd[2])
+            h, w = min(512, int((y2 - y1) * sc)), min(512, int((x2 - x1) * sc))
+            chip = data[k]
+            # pixels of the image crop, mean-subtracted (uniform noise: per-channel mean ~ 127.5 - PIXEL_MEANS), zero padding outside
+            assert abs(float(chip[:, :h - 1, :w - 1].mean()) - float(127.5 - means.mean())) < 6.0
+            assert float(np.abs(chip[:, h + 1:, :]).max(initial=0)) == 0 and float(np.abs(chip[:, :, w + 1:]).max(initial=0)) == 0
+            assert float(chip[:, :h - 1, :w - 1].std()) > 20
         n += 1
         if n >= 3:
             break
     assert n == 3
+    # the synthetic source must be asked for, and is a pure function of (image name, crop, scale, flip) -- not of the process
+    src = synthetic_im_source((512, 512))
+    r0 = {'image': 'synthetic_000000.jpg'}
+    crop = (np.array([10.0, 20.0, 300.0, 400.0]), 1.5, 512, 512, 1)
+    a = src(r0, crop, False)
+    assert a.shape == (3, 512, 512) and float(a[0, 0, 0]) == float(src(r0, crop, False)[0, 0, 0])
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from sniper_amd.iterators.MNIteratorE2E import synthetic_im_source as s;"
+            "print(repr(float(s((512, 512))({'image': 'synthetic_000000.jpg'}, (np.array([10.0, 20.0, 300.0, 400.0]), 1.5, 512, 512, 1), False)[0, 0, 0])))")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = subprocess.run([sys.executable, '-c', code % root], stdout=subprocess.PIPE, text=True, env=dict(os.environ, PYTHONHASHSEED='12345'))
+    assert float(other.stdout.strip().splitlines()[-1]) == float(a[0, 0, 0])
+    it2 = MNIteratorE2E(make_roidb(6, seed=4), cfg, batch_size=4, nGPUs=1, im_source='synthetic')
+    assert float(np.abs(it2.batch.data[0].asnumpy()).std()) > 30
 
 
 def test_hip_graph_replay_matches_eager(monkeypatch):
