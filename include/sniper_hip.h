@@ -195,8 +195,10 @@ size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_str
                                      int stride, int pad, int dil);
 int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride, int Cout,
                   int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws, size_t ws_bytes, sn_stream_t stream);
-/* bias gradient: db[c] += sum_rows dy[r][c] */
-int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, sn_stream_t stream);
+/* bias gradient: db[c] += sum_rows dy[r][c].  Row blocks leave partial sums in `ws` (sn_bias_grad_workspace_bytes) and are added in
+ * block order -- deterministic, no atomics; without scratch one block per 64 channels walks all rows. */
+size_t sn_bias_grad_workspace_bytes(long rows, int C);
+int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, void *ws, size_t ws_bytes, sn_stream_t stream);
 
 /* Stem: NCHW fp32 images -> zero padded NHWC4 fp16 with the bn_data affine folded in (:402-404). */
 int sn_pack_stem_input(const float *x_nchw, void *out, int N, int C, int H, int W, int Hp, int Wp, int pad_t, int pad_l,
@@ -227,13 +229,14 @@ int sn_bn_backward_blocks(const float *partials, int nblk, const void *dy, const
 
 /* Depthwise 3x3 convolution (Convolution with num_group == channels; mobilenetv2_e2e.py:27-43,57-66), channels-last
  * fp16, weights [C][KH*KW] fp16.  dgrad adds `accumulate` (may be NULL / alias dx); wgrad accumulates (+=) into fp32
- * dw [C][KH*KW]. */
+ * dw [C][KH*KW] through per-block partials in `ws` summed in block order (deterministic, no atomics). */
 int sn_dwconv_fwd(const void *x, const void *w, void *y, int N, int H, int W, int C, int in_pix_stride, int out_pix_stride, int KH,
                   int KW, int stride, int pad, int dil, sn_stream_t stream);
 int sn_dwconv_dgrad(const void *dy, const void *w, const void *accumulate, void *dx, int N, int H, int W, int C, int dy_pix_stride,
                     int acc_pix_stride, int dx_pix_stride, int KH, int KW, int stride, int pad, int dil, sn_stream_t stream);
+size_t sn_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil);
 int sn_dwconv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int C, int dy_pix_stride, int x_pix_stride,
-                    int KH, int KW, int stride, int pad, int dil, sn_stream_t stream);
+                    int KH, int KW, int stride, int pad, int dil, void *ws, size_t ws_bytes, sn_stream_t stream);
 /* clip(lo, hi) (mx.sym.clip; relu6) forward, or backward = (lo <= ref <= hi ? a : 0) [+ accumulate]. */
 int sn_clip_f16(const void *a, const void *ref, const void *accumulate, void *y, long rows, int C, int ps_a, int ps_ref, int ps_acc,
                 int ps_y, float lo, float hi, int backward, sn_stream_t stream);

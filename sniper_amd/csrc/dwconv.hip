@@ -104,26 +104,25 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const half_t *__restr
 }
 
 // dw[c][tap] += sum_pix dy[pix][c] * x[src(pix, tap)][c].  A thread owns 8 channels for its whole life (72 fp32
-// accumulators) and walks output pixels; the block folds its threads in LDS (ds_add_f32) and issues one global
-// atomic per (channel, tap).
-constexpr int kDwChunks = 64;  // 8-channel chunks per block (512 channels): LDS 512*9*4 = 18 KB
+// accumulators) and walks output pixels; the block folds its row lanes through LDS in lane order and writes ONE partial
+// per (channel, tap) to its slab [pixel block][C][9]; dwconv_wgrad_finish_kernel adds the slabs to dw in block order.
+// No atomics anywhere: the same bits every run (the previous version folded with ds_add_f32 + global atomics).
+constexpr int kDwChunks = 32;  // 8-channel chunks per block (256 channels): LDS rpp * cb * 72 * 4 B <= 72 KB
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const half_t *__restrict__ dy, const half_t *__restrict__ x,
-                                                           float *__restrict__ dw, int N, int H, int W, int C, int dy_ps, int x_ps,
+                                                           float *__restrict__ part, int N, int H, int W, int C, int dy_ps, int x_ps,
                                                            int Ho, int Wo, int stride, int pad, int dil, int pix_per_block) {
-  __shared__ float red[kDwChunks * 8 * kT];
+  __shared__ float red[256 * 8 * kT];
   const int cpr = C >> 3;
   const int cb = cpr < kDwChunks ? cpr : kDwChunks, rpp = 256 / cb;
-  const int rl = threadIdx.x / cb, chunk = blockIdx.y * kDwChunks + (int)(threadIdx.x - rl * cb);
+  const int rl = threadIdx.x / cb, lc = (int)(threadIdx.x - rl * cb), chunk = blockIdx.y * kDwChunks + lc;
   const bool on = rl < rpp && chunk < cpr;
-  for (int k = threadIdx.x; k < kDwChunks * 8 * kT; k += 256) red[k] = 0.f;
-  __syncthreads();
+  float acc[8][kT];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[j][t] = 0.f;
   if (on) {
     const int ch = chunk * 8;
-    float acc[8][kT];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int t = 0; t < kT; ++t) acc[j][t] = 0.f;
     const long M = (long)N * Ho * Wo;
     const long m0 = (long)blockIdx.x * pix_per_block, m1 = m0 + pix_per_block < M ? m0 + pix_per_block : M;
     for (long m = m0 + rl; m < m1; m += rpp) {
@@ -145,15 +144,31 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const half_t *__restr
         }
       }
     }
-    float *r = red + (size_t)(chunk - blockIdx.y * kDwChunks) * 8 * kT;
+  }
+  // [row lane][local chunk][8 channels][9 taps]
+  if (rl < rpp) {
+    float *r = red + ((size_t)rl * cb + lc) * 8 * kT;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int t = 0; t < kT; ++t) atomicAdd(r + j * kT + t, acc[j][t]);
+      for (int t = 0; t < kT; ++t) r[j * kT + t] = acc[j][t];
   }
   __syncthreads();
-  const int nch = (cpr - blockIdx.y * kDwChunks < kDwChunks ? cpr - blockIdx.y * kDwChunks : kDwChunks) * 8;
-  for (int k = threadIdx.x; k < nch * kT; k += 256) atomicAdd(dw + (size_t)blockIdx.y * kDwChunks * 8 * kT + k, red[k]);
+  const int nloc = cpr - blockIdx.y * kDwChunks < cb ? cpr - blockIdx.y * kDwChunks : cb;   // chunks of this block that exist
+  float *po = part + ((size_t)blockIdx.x * C + (size_t)blockIdx.y * kDwChunks * 8) * kT;
+  for (int k = threadIdx.x; k < nloc * 8 * kT; k += 256) {
+    float sum = 0.f;
+    for (int q = 0; q < rpp; ++q) sum += red[(size_t)q * cb * 8 * kT + k];
+    po[k] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_wgrad_finish_kernel(const float *__restrict__ part, int nblk, long n, float *__restrict__ dw) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += part[(size_t)k * n + e];
+  dw[e] += s;
 }
 
 static int dw_check(const void *a, const void *b, const void *c, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
@@ -193,20 +208,40 @@ SN_EXPORT int sn_dwconv_dgrad(const void *dy, const void *w, const void *accumul
   return SN_OK;
 }
 
+static int dw_wgrad_blocks(long M, int C, int *pix_per_block) {
+  const int cpr = C / 8, cb = cpr < kDwChunks ? cpr : kDwChunks, rpp = 256 / cb;
+  long blocks = (M + (long)rpp * 16 - 1) / ((long)rpp * 16);   // >= 16 pixels per thread
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  *pix_per_block = (int)((M + blocks - 1) / blocks);
+  return (int)((M + *pix_per_block - 1) / *pix_per_block);
+}
+
+SN_EXPORT size_t sn_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return 0;
+  const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  int ppb;
+  return sn_align(sizeof(float) * (size_t)dw_wgrad_blocks((long)N * Ho * Wo, C, &ppb) * C * kT);
+}
+
 SN_EXPORT int sn_dwconv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int C, int dy_pix_stride,
-                              int x_pix_stride, int KH, int KW, int stride, int pad, int dil, sn_stream_t stream) {
+                              int x_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws, size_t ws_bytes,
+                              sn_stream_t stream) {
   if (int rc = dw_check(dy, x, dw, N, H, W, C, KH, KW, stride, pad, dil, "sn_dwconv_wgrad")) return rc;
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   SN_REQUIRE(Ho > 0 && Wo > 0 && dy_pix_stride % 8 == 0 && x_pix_stride % 8 == 0, "sn_dwconv_wgrad: bad strides");
   const long M = (long)N * Ho * Wo;
-  const int cpr = C / 8, cb = cpr < kDwChunks ? cpr : kDwChunks, rpp = 256 / cb;
-  long blocks = (M + (long)rpp * 16 - 1) / ((long)rpp * 16);   // >= 16 pixels per thread
-  if (blocks > 512) blocks = 512;
-  if (blocks < 1) blocks = 1;
-  const int ppb = (int)((M + blocks - 1) / blocks);
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)((M + ppb - 1) / ppb), sn_div_up(cpr, kDwChunks)), dim3(256), 0,
-                     sn_stream(stream), (const half_t *)dy, (const half_t *)x, dw, N, H, W, C, dy_pix_stride, x_pix_stride, Ho, Wo,
-                     stride, pad, dil, ppb);
+  int ppb;
+  const int blocks = dw_wgrad_blocks(M, C, &ppb);
+  SN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)blocks * C * kT,
+             "sn_dwconv_wgrad: needs sn_dwconv_wgrad_workspace_bytes(...) of scratch (per-block partials, summed in order)");
+  hipStream_t s = sn_stream(stream);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)blocks, sn_div_up(C / 8, kDwChunks)), dim3(256), 0, s, (const half_t *)dy,
+                     (const half_t *)x, (float *)ws, N, H, W, C, dy_pix_stride, x_pix_stride, Ho, Wo, stride, pad, dil, ppb);
+  SN_CHECK_LAUNCH();
+  const long n = (long)C * kT;
+  hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)ws, blocks, n, dw);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -937,9 +937,11 @@ SN_EXPORT int sn_ew_f32(const float *a, const float *b, float *out, long n, int 
 }
 
 // bias gradient: db[c] += sum over rows of dy[r][c]   (dy fp16 or fp32, row stride ld)
+// Row blocks write partial sums [row block][C]; bias_grad_finish_kernel adds them to db in block order: no atomics, the
+// same bits every run.  Without scratch one block per 64 channels walks all rows and adds its sum to db itself.
 template <typename T>
-__global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dy, float *__restrict__ db, long rows, int C, int ld,
-                                                        long rows_per_block) {
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dy, float *__restrict__ db, float *__restrict__ part,
+                                                        long rows, int C, int ld, long rows_per_block) {
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -949,20 +951,56 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dy
   __shared__ float red[4][64];
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < C) atomicAdd(&db[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rl == 0 && c < C) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part) part[(size_t)blockIdx.y * C + c] = t;
+    else db[c] += t;          // single row block: this thread is the only writer of db[c]
+  }
 }
 
-SN_EXPORT int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, sn_stream_t stream) {
-  SN_REQUIRE(dy && db && rows > 0 && C > 0, "sn_bias_grad: bad arguments");
+__global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float *__restrict__ part, int nblk, int C, float *__restrict__ db) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += part[(size_t)k * C + c];
+  db[c] += s;
+}
+
+static int bias_grad_blocks(long rows, long *rows_per_block) {
   int by = (int)((rows + 255) / 256);
   if (by > 512) by = 512;
-  const long rpb = (rows + by - 1) / by;
-  by = (int)((rows + rpb - 1) / rpb);
+  if (by < 1) by = 1;
+  *rows_per_block = (rows + by - 1) / by;
+  return (int)((rows + *rows_per_block - 1) / *rows_per_block);
+}
+
+SN_EXPORT size_t sn_bias_grad_workspace_bytes(long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  long rpb;
+  const int by = bias_grad_blocks(rows, &rpb);
+  return by > 1 ? sn_align(sizeof(float) * (size_t)by * C) : 0;
+}
+
+SN_EXPORT int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, int dtype, void *ws, size_t ws_bytes,
+                           sn_stream_t stream) {
+  SN_REQUIRE(dy && db && rows > 0 && C > 0, "sn_bias_grad: bad arguments");
+  long rpb;
+  int by = bias_grad_blocks(rows, &rpb);
+  float *part = nullptr;
+  if (by > 1) {
+    if (ws && ws_bytes >= sizeof(float) * (size_t)by * C) part = (float *)ws;
+    else { by = 1; rpb = rows; }       // no scratch: one (slow) owner per channel, still deterministic
+  }
   dim3 grid(sn_div_up(C, 64), by);
+  hipStream_t s = sn_stream(stream);
   if (dtype == 0)
-    hipLaunchKernelGGL((bias_grad_kernel<half_t>), grid, dim3(256), 0, sn_stream(stream), (const half_t *)dy, db, rows, C, ld, rpb);
+    hipLaunchKernelGGL((bias_grad_kernel<half_t>), grid, dim3(256), 0, s, (const half_t *)dy, db, part, rows, C, ld, rpb);
   else
-    hipLaunchKernelGGL((bias_grad_kernel<float>), grid, dim3(256), 0, sn_stream(stream), (const float *)dy, db, rows, C, ld, rpb);
+    hipLaunchKernelGGL((bias_grad_kernel<float>), grid, dim3(256), 0, s, (const float *)dy, db, part, rows, C, ld, rpb);
   SN_CHECK_LAUNCH();
+  if (part) {
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(sn_div_up(C, 256)), dim3(256), 0, s, (const float *)part, by, C, db);
+    SN_CHECK_LAUNCH();
+  }
   return SN_OK;
 }

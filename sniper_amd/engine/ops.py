@@ -306,6 +306,13 @@ def _wgrad(ex, dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil):
     hip.call('sn_conv_wgrad', dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil, ws, need, hip.stream())
 
 
+def _bias_grad(ex, dy, db, rows, C, ld):
+    """sn_bias_grad with the executor's scratch (ordered partial sums, no atomics); same stream as the weight gradient before it."""
+    need = hip.query('sn_bias_grad_workspace_bytes', rows, C)
+    ws = ex.ws.get(need) if need else None
+    hip.call('sn_bias_grad', dy, db, rows, C, ld, 0, ws, need, hip.stream())
+
+
 class _GemmLike(Step):
     """Shared by Convolution and FullyConnected.  Sub-classes fill geometry in setup_geom()."""
 
@@ -363,7 +370,7 @@ class _GemmLike(Step):
             if self.w.trainable:
                 self.launch_wgrad(dy, Op, x)
             if self.b is not None and self.b.trainable:
-                hip.call('sn_bias_grad', dy, self.b.grad, self.N * self.Ho * self.Wo, self.O, Op, 0, hip.stream())
+                _bias_grad(ex, dy, self.b.grad, self.N * self.Ho * self.Wo, self.O, Op)
         if self.w.trainable or (self.b is not None and self.b.trainable):
             ex.on_side(param_grads, keep=(dy, x))
         if self.x.needs_grad:
@@ -503,8 +510,9 @@ class ConvolutionStep(_GemmLike):
                      self.k[0], self.KWP, self.s[0], ws, need, hip.stream())
             return
         if self.depthwise:
+            need = hip.query('sn_dwconv_wgrad_workspace_bytes', self.N, self.H, self.W, self.C, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0])
             hip.call('sn_dwconv_wgrad', dy, x, self.w.grad, self.N, self.H, self.W, self.C, Op, self.C, self.k[0], self.k[1],
-                     self.s[0], self.p[0], self.d[0], hip.stream())
+                     self.s[0], self.p[0], self.d[0], self.ex.ws.get(need), need, hip.stream())
             return
         _wgrad(self.ex, dy, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, self.O, Op, self.k[0], self.k[1],
                self.s[0], self.p[0], self.d[0])
@@ -593,7 +601,7 @@ class DeformableConvolutionStep(Step):
             if self.w.trainable:
                 _wgrad(ex, dy, self.col, self.w.grad, M, 1, 1, K, K, self.O, Op, 1, 1, 1, 0, 1)
             if self.b is not None and self.b.trainable:
-                hip.call('sn_bias_grad', dy, self.b.grad, M, self.O, Op, 0, hip.stream())
+                _bias_grad(ex, dy, self.b.grad, M, self.O, Op)
         if self.w.trainable or (self.b is not None and self.b.trainable):
             ex.on_side(param_grads, keep=(dy,))
         if self.x.needs_grad or self.off.needs_grad:

@@ -225,9 +225,18 @@ def test_fc_as_conv_and_bias_grad():
     assert_close(y.cpu().numpy(), want, 1e-2, 1e-2 * np.abs(want).max(), 'fc fwd')
     dy = rs.standard_normal((M, O)).astype(np.float32)
     dyd = torch.from_numpy(dy).to(dev())
-    db = torch.zeros(O, dtype=torch.float32, device=dev())
-    hip.call('sn_bias_grad', dyd, db, M, O, O, 1, hip.stream())
+    need = hip.query('sn_bias_grad_workspace_bytes', M, O)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev())
+    runs = []
+    for rep in range(3):         # ordered partial sums: bit-identical every run, with or without scratch of its own order
+        db = torch.zeros(O, dtype=torch.float32, device=dev())
+        hip.call('sn_bias_grad', dyd, db, M, O, O, 1, ws, need, hip.stream())
+        runs.append(db.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
     assert_close(db.cpu().numpy(), dy.sum(0), 1e-4, 1e-3, 'bias grad')
+    db1 = torch.zeros(O, dtype=torch.float32, device=dev())
+    hip.call('sn_bias_grad', dyd, db1, M, O, O, 1, None, 0, hip.stream())
+    assert_close(db1.cpu().numpy(), dy.sum(0), 1e-4, 1e-3, 'bias grad without scratch')
     # wgrad of an FC needs fp16 dy with an 8-aligned row stride: pad 98 -> 104
     dy16 = torch.zeros((M, 104), dtype=torch.float16, device=dev())
     dy16[:, :O] = dyd.half()
@@ -778,8 +787,14 @@ def test_depthwise_conv_vs_torch(N, C, H, W, s):
     assert_close(from_nhwc(dx), want_dx, 1e-2, 1e-2 * np.abs(want_dx).max(), 'dw dgrad')
     hip.call('sn_dwconv_dgrad', dyd, wd, dx, dx, N, H, W, C, C, C, C, 3, 3, s, 1, 1, hip.stream())
     assert_close(from_nhwc(dx), 2 * want_dx, 2e-2, 2e-2 * np.abs(want_dx).max(), 'dw dgrad accumulate')
-    dw = torch.zeros((C, 9), dtype=torch.float32, device=dev())
-    hip.call('sn_dwconv_wgrad', dyd, xd, dw, N, H, W, C, C, C, 3, 3, s, 1, 1, hip.stream())
+    need = hip.query('sn_dwconv_wgrad_workspace_bytes', N, H, W, C, 3, 3, s, 1, 1)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    runs = []
+    for rep in range(3):         # per-block partials summed in block order: the same bits every run
+        dw = torch.zeros((C, 9), dtype=torch.float32, device=dev())
+        hip.call('sn_dwconv_wgrad', dyd, xd, dw, N, H, W, C, C, C, 3, 3, s, 1, 1, ws, need, hip.stream())
+        runs.append(dw.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
     want_dw = wt.grad.numpy().reshape(C, 9)
     assert_close(dw.cpu().numpy(), want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'dw wgrad')
 
