@@ -297,6 +297,103 @@ def dpsroi_pool_backward(dout, data, rois, trans, P, S, scale, trans_std=0.0, gr
     return d_data, d_trans
 
 
+# ---- the same operator as three sparse sampling matrices (for BASELINE sizes: R = 6000 RoIs take minutes in the loops above).
+# Row (r, ph, pw), column (b, y, x):  A = bilinear weights / valid-sample count,  Gx / Gy = d(sample)/dx, /dy weights / count.
+# forward  out[r, :, ph, pw] = A   @ data[(b, y, x), channels of the bin]
+# backward d_data           += A.T @ dout;   d_trans[r, 0|1, ph, pw] = <Gx|Gy @ data, dout> * trans_std * roi_w|roi_h
+# Sample coordinates are computed in float32 exactly as _roi_bins / dpsroi_pool do; the products are then carried in float64
+# (the loops multiply float32 weights into float32 data first), so the two agree to ~1e-6, not to the bit:
+# tests/test_oracle_graph_cpu.py pins this restatement to the loop definition.
+def _dpsroi_operators(rois, trans, B, H, W, P, S, scale, trans_std):
+    import scipy.sparse as sp
+    f32 = np.float32
+    R = rois.shape[0]
+    rois = np.asarray(rois, np.float32)
+    rnd = lambda v: (np.floor(np.abs(v) + f32(0.5)) * np.sign(v)).astype(f32)
+    sw, sh = rnd(rois[:, 1]) * f32(scale) - f32(0.5), rnd(rois[:, 2]) * f32(scale) - f32(0.5)
+    ew, eh = (rnd(rois[:, 3]) + f32(1)) * f32(scale) - f32(0.5), (rnd(rois[:, 4]) + f32(1)) * f32(scale) - f32(0.5)
+    rw, rh = np.maximum(ew - sw, f32(0.1)), np.maximum(eh - sh, f32(0.1))
+    bw, bh = (rw / f32(P)).astype(f32), (rh / f32(P)).astype(f32)
+    idx = np.arange(P, dtype=f32)
+    if trans is not None:
+        tx = (np.asarray(trans, f32)[:, 0] * f32(trans_std)).astype(f32)
+        ty = (np.asarray(trans, f32)[:, 1] * f32(trans_std)).astype(f32)
+    else:
+        tx = ty = np.zeros((R, P, P), f32)
+    ws = (idx[None, None, :] * bw[:, None, None] + sw[:, None, None] + tx * rw[:, None, None]).astype(f32)      # (R, ph, pw)
+    hs = (idx[None, :, None] * bh[:, None, None] + sh[:, None, None] + ty * rh[:, None, None]).astype(f32)
+    ssw, ssh = (bw / f32(S)).astype(f32), (bh / f32(S)).astype(f32)
+    b = rois[:, 0].astype(np.int64)
+    rows = np.arange(R * P * P).reshape(R, P, P)
+    cnt = np.zeros((R, P, P), np.int64)
+    rr, cc, va, vx, vy = [], [], [], [], []
+    for ih in range(S):
+        for iw in range(S):
+            w = (ws + f32(iw) * ssw[:, None, None]).astype(f32)
+            h = (hs + f32(ih) * ssh[:, None, None]).astype(f32)
+            ok = ~((w < -0.5) | (w > W - 0.5) | (h < -0.5) | (h > H - 0.5))
+            w = np.minimum(np.maximum(w, f32(0.0)), f32(W - 1.0))
+            h = np.minimum(np.maximum(h, f32(0.0)), f32(H - 1.0))
+            x0, x1, y0, y1 = np.floor(w).astype(np.int64), np.ceil(w).astype(np.int64), np.floor(h).astype(np.int64), np.ceil(h).astype(np.int64)
+            dx, dy = (w - x0).astype(f32).astype(np.float64), (h - y0).astype(f32).astype(np.float64)
+            cnt += ok
+            base = b[:, None, None] * H
+            for (yy, xx, wa, wx, wy) in ((y0, x0, (1 - dx) * (1 - dy), -(1 - dy), -(1 - dx)), (y0, x1, dx * (1 - dy), (1 - dy), -dx),
+                                         (y1, x0, (1 - dx) * dy, -dy, (1 - dx)), (y1, x1, dx * dy, dy, dx)):
+                rr.append(rows[ok]); cc.append(((base + yy) * W + xx)[ok]); va.append(wa[ok]); vx.append(wx[ok]); vy.append(wy[ok])
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    inv = 1.0 / np.maximum(cnt, 1).reshape(-1)
+    shape = (R * P * P, B * H * W)
+    mk = lambda v: sp.diags(inv) @ sp.csr_matrix((np.concatenate(v), (rr, cc)), shape=shape)
+    return mk(va), mk(vx), mk(vy), rw.astype(np.float64), rh.astype(np.float64)
+
+
+def _ps_groups(G, P):
+    """bins (ph, pw) by the map group (gh, gw) they read (position-sensitive pooling); one group holding all bins for G = 1"""
+    groups = {}
+    for ph in range(P):
+        for pw in range(P):
+            gh, gw = min(max(ph * G // P, 0), G - 1), min(max(pw * G // P, 0), G - 1)
+            groups.setdefault((gh, gw), []).append(ph * P + pw)
+    return groups
+
+
+def dpsroi_pool_fast(data, rois, trans, P, S, scale, trans_std=0.0, group_size=1):
+    B, C, H, W = data.shape
+    G = int(group_size)
+    D, R = C // (G * G), rois.shape[0]
+    A, _, _, _, _ = _dpsroi_operators(rois, trans, B, H, W, P, S, scale, trans_std)
+    flat = np.ascontiguousarray(np.asarray(data, np.float64).transpose(0, 2, 3, 1)).reshape(B * H * W, C)
+    out = np.zeros((R, P * P, D))
+    for (gh, gw), bins in _ps_groups(G, P).items():
+        ch = (np.arange(D) * G + gh) * G + gw
+        rsel = (np.arange(R)[:, None] * (P * P) + np.asarray(bins)[None, :]).reshape(-1)
+        out[:, bins, :] = (A[rsel] @ flat[:, ch]).reshape(R, len(bins), D)
+    return out.transpose(0, 2, 1).reshape(R, D, P, P)
+
+
+def dpsroi_pool_backward_fast(dout, data, rois, trans, P, S, scale, trans_std=0.0, group_size=1):
+    B, C, H, W = data.shape
+    G = int(group_size)
+    D, R = C // (G * G), rois.shape[0]
+    A, GX, GY, rw, rh = _dpsroi_operators(rois, trans, B, H, W, P, S, scale, trans_std)
+    flat = np.ascontiguousarray(np.asarray(data, np.float64).transpose(0, 2, 3, 1)).reshape(B * H * W, C)
+    dflat = np.zeros((B * H * W, C))
+    do = np.asarray(dout, np.float64).reshape(R, D, P * P).transpose(0, 2, 1)          # (R, bins, D)
+    d_trans = None if trans is None else np.zeros((R, 2, P * P))
+    for (gh, gw), bins in _ps_groups(G, P).items():
+        ch = (np.arange(D) * G + gh) * G + gw
+        rsel = (np.arange(R)[:, None] * (P * P) + np.asarray(bins)[None, :]).reshape(-1)
+        dv = np.ascontiguousarray(do[:, bins, :]).reshape(-1, D)
+        dflat[:, ch] += A[rsel].T @ dv
+        if trans is not None:
+            sub = flat[:, ch]
+            d_trans[:, 0, bins] = ((GX[rsel] @ sub) * dv).sum(1).reshape(R, len(bins)) * trans_std * rw[:, None]
+            d_trans[:, 1, bins] = ((GY[rsel] @ sub) * dv).sum(1).reshape(R, len(bins)) * trans_std * rh[:, None]
+    d_data = dflat.reshape(B, H, W, C).transpose(0, 3, 1, 2)
+    return d_data, (None if trans is None else d_trans.reshape(R, 2, P, P))
+
+
 # ---------------------------------------------------------------------------------------------
 # DeformableConvolution v1 sampling (call site :124-128): column tensor (N, Ho, Wo, T, C)
 # ---------------------------------------------------------------------------------------------

@@ -451,7 +451,10 @@ def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
         g, w = p.to_reference(p.grad.detach().cpu().numpy()), wgrads[name]
         rel = float(np.linalg.norm(g.astype(np.float64) - w) / (np.linalg.norm(w) + 1e-20))
         report.append('%-44s relL2 %.5f' % (name, rel))
-        if not rel <= tol_grad:
+        # the learned-offset parameters of the deformable convolutions sit behind the bilinear-sampling derivative, a DIFFERENCE
+        # of neighbouring fp16 activations: cancellation amplifies the storage rounding (measured 1.03e-2 on one 72-element
+        # bias at 2 chips); everything else is held to tol_grad
+        if not rel <= (1.5 * tol_grad if '_offset_' in name and 'stage4' in name else tol_grad):
             bad.append(report[-1])
         checked += 1
     print('\n'.join(report))
@@ -481,13 +484,15 @@ def test_mobilenetv2_c1_parity_vs_cpu_reference_ops():
     rs = np.random.RandomState(11)
     P, AUX = _init_params(sym, shapes, rs)
     inp = _train_inputs(rs, B, A, F, extra=('crowd_boxes',))
-    checked, ov = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=2e-2)
+    checked, ov = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=1e-2)
     assert checked == 71       # 53 trunk convolutions + 4 head convolutions and 5 FCs with their biases
     assert (ov[('multi_proposal_target', 1)] > 0).sum() >= 1, 'the synthetic GT must produce some foreground RoIs'
 
 
-def test_r101_c2_network_parity_vs_cpu_reference_ops():
-    """The BASELINE C2/C3 network (ResNet-101 C4 + deformable C5 + RPN + deformable PS-RoI heads) at 2 chips, same
+@pytest.mark.parametrize('B', [2, 20])
+def test_r101_c2_network_parity_vs_cpu_reference_ops(B):
+    """The BASELINE C2/C3 network (ResNet-101 C4 + deformable C5 + RPN + deformable PS-RoI heads) at 2 chips and at the C2 batch
+    of 20 chips per GPU (the launch shapes, tile configurations and K-splits of the benchmark), same
     teacher-forced end-to-end comparison: covers the frozen stem (bn_data folded into the packed 7x7 conv), max-pool,
     the 33 bottlenecks with BN+ReLU fusion and in-kernel gradient accumulation, the three deformable convolutions
     (sampling + offsets), Concat, and both RoI poolings."""
@@ -496,7 +501,7 @@ def test_r101_c2_network_parity_vs_cpu_reference_ops():
     from sniper_amd.engine.executor import Executor
     from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
     from sniper_amd.train import fixed_param_names
-    B, A, F = 2, 21, 32
+    A, F = 21, 32
     cfg = cfgmod.res101_e2e(batch_images=B)
     sym = rn.resnet_mx_101_e2e(momentum=0.995).get_symbol_rcnn(cfg)
     shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
@@ -513,22 +518,23 @@ def test_r101_c2_network_parity_vs_cpu_reference_ops():
     AUX['bn_data_moving_var'][:] = 1.0 - 2e-5      # bn_data == identity: the image stays fp16-representable
     P['bn_data_beta'][:] = 0.0
     inp = _train_inputs(rs, B, A, F)
-    checked, _ = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=2e-2)
+    checked, _ = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=1e-2)
     assert checked >= 250
 
 
 
 
-def test_r101_c4_rfcn_head_parity_vs_cpu_reference_ops():
+@pytest.mark.parametrize('B', [2, 16])
+def test_r101_c4_rfcn_head_parity_vs_cpu_reference_ops(B):
     """BASELINE config C4: the R101 trunk with the position-sensitive R-FCN head (group_size 7 deformable PS-RoI pooling
-    of 7*7*81 / 7*7*4 maps with pooled offsets, bin vote by global average pooling), 2 chips, teacher-forced against
-    oracle/graph_cpu.py like C1 / C2."""
+    of 7*7*81 / 7*7*4 maps with pooled offsets, bin vote by global average pooling), 2 chips and the C4 batch of 16 chips
+    per GPU, teacher-forced against oracle/graph_cpu.py like C1 / C2."""
     import os
     from sniper_amd import config as cfgmod
     from sniper_amd.engine.executor import Executor
     from sniper_amd.symbols.faster import resnet_mx_101_e2e_rfcn as rf
     from sniper_amd.train import fixed_param_names
-    B, A, F = 2, 21, 32
+    A, F = 21, 32
     cfg = cfgmod.res101_e2e(batch_images=B)
     sym = rf.resnet_mx_101_e2e_rfcn(momentum=0.995).get_symbol_rcnn(cfg)
     shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
@@ -548,7 +554,7 @@ def test_r101_c4_rfcn_head_parity_vs_cpu_reference_ops():
     AUX['bn_data_moving_var'][:] = 1.0 - 2e-5
     P['bn_data_beta'][:] = 0.0
     inp = _train_inputs(rs, B, A, F)
-    checked, ov = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=2e-2)
+    checked, ov = _forced_parity(sym, ex, P, AUX, inp, tol_fwd=2e-3, tol_grad=1e-2)
     assert checked >= 250
     names = [n for n, p in ex.params.items() if p.trainable]
     assert all(k in names for k in ('rfcn_cls_weight', 'rfcn_bbox_weight', 'rfcn_cls_offset_t_weight', 'rfcn_bbox_offset_t_bias'))

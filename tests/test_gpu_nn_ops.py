@@ -272,16 +272,16 @@ def test_batchnorm_train_fwd_bwd():
         if relu:
             yt = torch.relu(yt)
         yt.backward(torch.from_numpy(f16r(dy)))
-        assert_close(from_nhwc(y), yt.detach().numpy(), 1e-2, 2e-2, 'bn fwd C=%d' % C)
+        assert_close(from_nhwc(y), yt.detach().numpy(), 1e-2, 1e-2 * float(yt.detach().abs().max()), 'bn fwd C=%d' % C)
         xm = f16r(x).transpose(1, 0, 2, 3).reshape(C, -1)
         assert_close(rm.cpu().numpy(), 0.1 * xm.mean(1), 1e-3, 1e-4, 'running mean')
         assert_close(rv.cpu().numpy(), 0.9 + 0.1 * xm.var(1), 1e-3, 1e-4, 'running var')
         dx, dg, db = torch.empty_like(xd), f(C), f(C)
         hip.call('sn_bn_backward', dyd, xd, None, dx, M, C, C, C, C, C, scale, shift, mean, invstd, relu, ws, dg, db, hip.stream())
         torch.cuda.synchronize()
-        assert_close(dg.cpu().numpy(), gt.grad.numpy(), 2e-2, 2e-2 * np.abs(gt.grad.numpy()).max(), 'dgamma')
-        assert_close(db.cpu().numpy(), bt.grad.numpy(), 2e-2, 2e-2 * np.abs(bt.grad.numpy()).max(), 'dbeta')
-        assert_close(from_nhwc(dx), xt.grad.numpy(), 2e-2, 2e-2 * np.abs(xt.grad.numpy()).max(), 'bn dx')
+        assert_close(dg.cpu().numpy(), gt.grad.numpy(), 1e-2, 1e-2 * np.abs(gt.grad.numpy()).max(), 'dgamma')
+        assert_close(db.cpu().numpy(), bt.grad.numpy(), 1e-2, 1e-2 * np.abs(bt.grad.numpy()).max(), 'dbeta')
+        assert_close(from_nhwc(dx), xt.grad.numpy(), 1e-2, 1e-2 * np.abs(xt.grad.numpy()).max(), 'bn dx')
 
 
 def test_bn_global_maxpool_ew_layout_ops():
@@ -827,7 +827,7 @@ def test_clip_and_bn_relu6():
     gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
     yt = torch.clamp(Fnn.batch_norm(xt, None, None, gt, bt, True, 0.0, 1e-5), 0, 6)
     yt.backward(torch.from_numpy(f16r(dy)))
-    assert_close(from_nhwc(y), yt.detach().numpy(), 1e-2, 2e-2, 'bn relu6 fwd')
+    assert_close(from_nhwc(y), yt.detach().numpy(), 1e-2, 1e-2 * float(yt.detach().abs().max()), 'bn relu6 fwd')
     dg, db = f(C), f(C)
     hip.call('sn_bn_backward', dyd, xd, None, dx, M, C, C, C, C, C, scale, shift, mean, invstd, 2, ws, dg, db, hip.stream())
     assert_close(db.cpu().numpy(), bt.grad.numpy(), 3e-2, 3e-2 * np.abs(bt.grad.numpy()).max(), 'bn relu6 dbeta')

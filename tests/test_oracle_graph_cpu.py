@@ -104,3 +104,30 @@ def test_position_sensitive_pooling_is_the_diagonal_of_group1_pooling():
         assert np.allclose(dd, dd1, atol=1e-12)
         assert (dt is None and dt1 is None) or np.allclose(dt, dt1, atol=1e-12)
     assert np.abs(out).max() > 0 and np.abs(dd).max() > 0 and np.abs(dt).max() > 0
+
+
+def test_dpsroi_sparse_operator_form_equals_the_loop_definition():
+    """oracle/nn.py dpsroi_pool_fast / dpsroi_pool_backward_fast (three sparse sampling matrices; used at BASELINE sizes, where
+    the loop definition takes minutes) against dpsroi_pool / dpsroi_pool_backward: group_size 1 and 3, with and without learned
+    offsets, RoIs hanging over every border, degenerate (sub-pixel) RoIs."""
+    from oracle import nn as onn
+    rs = np.random.RandomState(0)
+    for G, C, P in ((1, 16, 7), (3, 36, 6), (7, 49 * 3, 7)):
+        B, H, W, S, R = 2, 12, 14, 4, 15
+        data = rs.standard_normal((B, C, H, W)).astype(np.float32)
+        c, wh = rs.uniform(0, 110, (R, 2)), rs.uniform(4, 90, (R, 2))
+        rois = np.concatenate((rs.randint(0, B, (R, 1)), c - wh / 2, c + wh / 2), 1).astype(np.float32)
+        rois[0, 1:] = [-30, -20, 5, 8]
+        rois[1, 1:] = [100, 90, 140, 130]
+        rois[2, 1:] = [33.2, 47.6, 33.4, 47.9]
+        D = C // (G * G)
+        for tr in (None, (rs.standard_normal((R, 2, P, P)) * 0.6).astype(np.float32)):
+            a = onn.dpsroi_pool(data, rois, tr, P, S, 1 / 8., 0.1, G)
+            b = onn.dpsroi_pool_fast(data, rois, tr, P, S, 1 / 8., 0.1, G)
+            assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max())
+            dout = rs.standard_normal((R, D, P, P))
+            d1, t1 = onn.dpsroi_pool_backward(dout, data, rois, tr, P, S, 1 / 8., 0.1, G)
+            d2, t2 = onn.dpsroi_pool_backward_fast(dout, data, rois, tr, P, S, 1 / 8., 0.1, G)
+            assert np.abs(d1 - d2).max() <= 1e-6 * max(1.0, np.abs(d1).max())
+            if tr is not None:
+                assert np.abs(t1 - t2).max() <= 1e-5 * max(1.0, np.abs(t1).max())
