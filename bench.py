@@ -10,14 +10,27 @@ backbone, RPN, MultiProposalTarget, deformable PS-RoI pooling, heads, losses) ->
 all-reduce (RCCL, N > 1) -> multi-precision SGD update.  Every GPU owns an independent chip
 minibatch (weak scaling, no sync-BN); value = N * B * K / max-over-ranks time.
 
+NOT inside the step: the epoch chip database (chip generation / box assignment, a1-a4 of SURVEY section 8) and image
+decoding / resizing -- they run once per epoch / ahead of the step and the chips are resident when the clock starts.
+
 Extra objects on the JSON line:
-  roofline      the dominant kernel family (implicit-GEMM MFMA convolution: forward + data gradient +
-                weight gradient launches) measured live with HIP events on the launch stream:
-                achieved = algorithmic FLOPs of those launches / their summed duration, peak = 2.5 PFLOP/s
-                dense fp16 MFMA (MI355X_MICROARCH.md).
-  cpu_baseline  the reference's CPU iterator path (chip extraction + box assignment + RPN anchor
-                labelling; oracle/ restatement of lib/data_utils/data_workers.py) timed on this node's
-                host cores on a bounded sample, in chips/s.  kind "port".
+  roofline      the dominant kernel family (implicit-GEMM MFMA convolution: forward + data gradient + weight gradient
+                launches) measured live with HIP events recorded on the stream each kernel is launched on, in extra untimed
+                steps run eagerly (the timed region replays hipGraphs, inside which nothing can be bracketed):
+                  achieved / frac        IN SITU: the step as it is timed -- weight gradients on the side stream, overlapping the
+                                         data-gradient chain.  Sum of algorithmic FLOPs / sum of the launches' durations; this
+                                         is the figure `rocprofv3 --kernel-trace --stats` of this command reproduces
+                                         (profiles/r02_bench_kernel_stats.csv: FLOPs / summed conv-kernel time).
+                  achieved_isolated      the same launches on ONE stream (a launch's duration is its own).
+                  step_tflops            conv FLOPs of a step / the timed ms_per_step (end to end, everything else included).
+                peak = 2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).  traffic = HBM bytes per conv launch from rocprofv3 --pmc
+                passes, reported only when they were collected on THIS build of the convolution sources (else null).
+  cpu_baseline  the reference's CPU iterator path (chip extraction + box assignment + RPN anchor labelling; oracle/
+                restatement of lib/data_utils/data_workers.py) timed on this node's host cores on a bounded sample, chips/s,
+                kind "port"; it times the DATA PATH only and is a reported baseline, never a speed-up claim.  `c1` inside it:
+                BASELINE configs[0] -- MobileNetV2 Faster-RCNN, 2 x 512 x 512 chips, one training step (forward + backward)
+                through the reference-semantics CPU operators of oracle/graph_cpu.py.
+  inference     BASELINE configs[4] (AutoFocus inference, `inf images/sec`); --no-inference skips it.
 """
 import argparse
 import json
@@ -97,14 +110,29 @@ class ConvProfiler(object):
         return tot_ms, tot_fl, per
 
 
+def conv_sources_hash():
+    """Identity of the convolution kernels a PMC profile was collected on (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, 'sniper_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.startswith('conv') and f.endswith(('.hip', '.h')):
+            with open(os.path.join(csrc, f), 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes per conv-family launch from the committed rocprofv3 --pmc passes of this same command
     (tools/pmc_traffic.py -> profiles/pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
-    as MI355X_MICROARCH.md section HBM prescribes for gfx950).  None when no such profile has been collected."""
+    as MI355X_MICROARCH.md section HBM prescribes for gfx950).  None when no profile exists FOR THIS BUILD of the
+    convolution sources: a stale constant is not a measurement."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as fh:
             d = json.load(fh)
+        if d.get('conv_sources_hash') != conv_sources_hash():
+            return None
         return d.get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         return None
@@ -127,9 +155,58 @@ def cpu_baseline(seconds_target=15.0):
         chips = pool.map(_cpu_image_chips, range(10 ** 6, 10 ** 6 + n_img), chunksize=4)
         dt = time.time() - t0
     n_chips = int(sum(chips))
-    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'port',
+    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'port', 'scope': 'data path only (a3-a6 of SURVEY section 8): '
+            'a reported baseline, not comparable with the training-step throughput above',
             'sample': '%d synthetic images -> %d chips: chip_extractor + box_assigner + anchor_worker (oracle/data_path.py, '
                       'restating lib/data_utils/data_workers.py) under multiprocessing.Pool(%d), %.1f s' % (n_img, n_chips, P, dt)}
+
+
+def cpu_c1_step():
+    """BASELINE configs[0]: MobileNetV2 Faster-RCNN, 1 scale, 2 x 512 x 512 synthetic chips through reference-semantics CPU
+    operators (oracle/graph_cpu.py: torch-CPU fp32 for the standard operators, oracle/nn.py for the fork-resident ones) --
+    one training step, forward + backward.  (MXNet-CPU itself cannot be installed here: SURVEY section 8(d).)"""
+    from oracle import graph_cpu
+    from sniper_amd import config as cfgmod
+    from sniper_amd.symbols.faster import mobilenetv2_e2e as mn
+    B, A, F = 2, 15, 16
+    cfg = cfgmod.mobilenetv2_e2e(batch_images=B)
+    sym = mn.mobilenetv2_e2e().get_symbol_rcnn(cfg)
+    shapes = dict(data=(B, 3, 512, 512), valid_ranges=(B, 2), im_info=(B, 3), label=(B, A * F * F),
+                  bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F), gt_boxes=(B, 100, 5), crowd_boxes=(B, 10, 5))
+    rs = np.random.RandomState(11)
+    args, _, auxs = sym.infer_shape(**shapes)
+    P, AUX = {}, {}
+    for name, shp in zip(sym.list_arguments(), args):
+        if name in shapes:
+            continue
+        if name.endswith('_gamma'):
+            P[name] = rs.uniform(0.5, 0.9, shp).astype(np.float32)
+        elif name.endswith(('_beta', '_bias')):
+            P[name] = np.zeros(shp, np.float32)
+        else:
+            P[name] = (rs.standard_normal(shp) * (0.01 if name.startswith(('rpn_', 'fc_', 'cls_', 'bbox_')) else
+                                                  np.sqrt(2.0 / np.prod(shp[1:])))).astype(np.float32)
+    for name, shp in zip(sym.list_auxiliary_states(), auxs):
+        AUX[name] = np.ones(shp, np.float32) if name.endswith('_var') else np.zeros(shp, np.float32)
+    gt = -np.ones((B, 100, 5), np.float32)
+    for b in range(B):
+        c, wh = rs.uniform(60, 450, (40, 2)), rs.uniform(40, 320, (40, 2))
+        gt[b, :40, :4] = np.clip(np.concatenate((c - wh / 2, c + wh / 2), 1), 0, 511)
+        gt[b, :40, 4] = rs.randint(1, 81, 40)
+    inp = dict(data=(rs.standard_normal((B, 3, 512, 512)) * 50).astype(np.float32), valid_ranges=np.array([[0, 512]] * B, np.float32),
+               im_info=np.array([[512, 512, 1.0]] * B, np.float32),
+               label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.9, 0.07, 0.03]).astype(np.float32),
+               bbox_target=(rs.standard_normal((B, 4 * A, F, F)) * 0.3).astype(np.float32),
+               bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.05).astype(np.float32), gt_boxes=gt,
+               crowd_boxes=-np.ones((B, 10, 5), np.float32))
+    t0 = time.time()
+    outs, _ = graph_cpu.run(sym, P, AUX, inp)
+    dt = time.time() - t0
+    assert all(np.isfinite(o).all() for o in outs)
+    return {'metric': 'train chips/sec (512x512, MobileNetV2, CPU)', 'value': round(B / dt, 3), 'unit': 'chips/s',
+            'seconds_per_step': round(dt, 2), 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': 'BASELINE configs[0]: 1 training step (forward + backward) of MobileNetV2 Faster-RCNN on 2 x 512 x 512 synthetic '
+                      'chips through oracle/graph_cpu.py (torch-CPU fp32 + oracle/nn.py), %d torch threads' % torch.get_num_threads()}
 
 
 def _cpu_image_chips(i):
@@ -189,7 +266,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=20, help='chips per GPU (BASELINE C2: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--inference', action='store_true', help='also measure BASELINE config C5 (inf images/sec) on rank 0')
+    ap.add_argument('--inference', action='store_true', help='(default on rank 0 at N = 1; kept for old command lines)')
+    ap.add_argument('--no-inference', action='store_true', help='skip BASELINE config C5 (inf images/sec)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -246,28 +324,51 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
-    # ---- roofline of the dominant kernel family, live HIP-event timing (untimed extra steps)
-    roof = None
-    # the timed region replays hipGraphs; for per-launch HIP events the same step is run eagerly (same kernels,
-    # same stream), bracketing every conv-family launch.  EVERY rank runs these two extra steps: a step contains the
-    # gradient all-reduce, and a collective entered by rank 0 alone would never return.
+    # ---- host cost of one step with an idle device: enqueue only, nothing waited for (host_dt above is throttled by the
+    # launch queue once the host runs ahead of the device, so it is an upper bound, not the host's own time)
+    sync()
+    t1 = time.perf_counter()
+    step(0)
+    host_idle_ms = (time.perf_counter() - t1) * 1e3
+    sync()
     ex = tr.mod.exe
+    graphs_used = bool(ex.use_graphs and ex._graph_fb is not None)
+
+    # ---- roofline of the dominant kernel family, live HIP-event timing (untimed extra steps)
+    # The timed region replays hipGraphs; for per-launch HIP events the same step is run eagerly (same kernels, same
+    # streams), bracketing every conv-family launch with events on the stream it is launched on.  EVERY rank runs these
+    # extra steps: a step contains the gradient all-reduce, and a collective entered by rank 0 alone would never return.
     saved = (ex.use_graphs, ex._graph_fb, ex._graph_up)
     ex.use_graphs, ex._graph_fb, ex._graph_up = False, None, None
-    side, ex.use_side_stream = ex.use_side_stream, False      # one stream: a launch's duration is its own
-    with ConvProfiler() as prof:
-        for i in range(2):
-            step(i)
-        tot_ms, tot_fl, per = prof.summary()
+    side = ex.use_side_stream
+
+    def profile(side_stream):
+        ex.use_side_stream = side_stream
+        step(0)                                     # settle (allocations of the eager path)
+        with ConvProfiler() as prof:
+            for i in range(2):
+                step(i)
+            return prof.summary()
+    tot_ms, tot_fl, per = profile(side)             # in situ: the stream assignment of the timed region
+    iso_ms, iso_fl, iso_per = profile(False)        # one stream: a launch's duration is its own
     ex.use_graphs, ex._graph_fb, ex._graph_up = saved
     ex.use_side_stream = side
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    roof = {'bound': 'mfma', 'kernel': 'conv_igemm_p2_kernel<DGRAD,BM> / conv_wgrad_tr_kernel (+ conv_igemm_kernel for narrow layers): sn_conv_fwd, sn_conv_dgrad, sn_conv_wgrad',
+    isolated = iso_fl / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
+    n_launch = sum(v[0] for v in per.values())
+    roof = {'bound': 'mfma',
+            'kernel': 'conv_dma_kernel<DGRAD,BM,BN,...> / conv_igemm_p2_kernel / conv_wgrad_tr_kernel / wgrad_{flat,taps}_dma_kernel '
+                      '(+ conv_igemm_kernel for narrow layers, wgrad_reduce_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_wgrad',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
+            'mode': 'in situ (eager replay of the timed step, weight gradients on the side stream: %s); sum of launch durations as '
+                    'rocprofv3 --kernel-trace --stats reports them' % bool(side),
+            'achieved_isolated': round(isolated, 2), 'frac_isolated': round(isolated / MFMA_PEAK_TFLOPS, 4),
+            'step_tflops': round(tot_fl / 2 / (ms_per_step * 1e-3) / 1e12, 2),
             'traffic': pmc_traffic(),
-            'launches_per_step': sum(v[0] for v in per.values()) // 2,
-            'avg_launch_ms': round(tot_ms / max(1, sum(v[0] for v in per.values())), 4),
+            'launches_per_step': n_launch // 2,
+            'avg_launch_ms': round(tot_ms / max(1, n_launch), 4),
             'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
+            'conv_ms_per_step_isolated': round(iso_ms / 2, 3),
             'by_entry': {k: {'launches': v[0] // 2, 'ms_per_step': round(v[1] / 2, 3),
                              'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in per.items()}}
     cpu = None
@@ -276,19 +377,25 @@ def main():
             cpu = cpu_baseline()
         except Exception as e:   # the baseline is a report, never a reason to lose the measurement
             cpu = {'value': None, 'unit': 'chips/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+        try:
+            cpu['c1'] = cpu_c1_step()
+        except Exception as e:   # noqa: BLE001
+            cpu['c1'] = {'value': None, 'sample': 'failed: %r' % (e,)}
     if rank == 0:
         out = {
             'metric': 'train chips/sec (512x512, R101)', 'value': round(value, 2), 'unit': 'chips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 3),
+            'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 3), 'host_enqueue_idle_device_ms': round(host_idle_ms, 3),
+            'graphs': graphs_used, 'rpn_heads_dtype': 'f16 MFMA operands, f32 accumulate (reference: f32 after its Cast, resnet_mx_101_e2e.py:250-252)',
             'config': {'workload': 'ResNet-101 Faster-RCNN SNIPER 3-scale, batch %d x 512x512 fp16 per GPU (BASELINE configs[1]); '
-                                   'step = GPU anchor labelling + fwd + bwd + grad all-reduce + SGD; f16 MFMA operands, f32 '
-                                   'accumulation / losses / master weights' % args.batch,
+                                   'step = GPU anchor labelling + fwd + bwd + grad all-reduce + SGD on HBM-resident chips (epoch chip generation / box '
+                                   'assignment and image decode+resize are outside the step); f16 MFMA operands, f32 accumulation / losses / '
+                                   'master weights' % args.batch,
                        'chips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
             'roofline': roof, 'cpu_baseline': cpu,
         }
-        if args.inference and world == 1:
+        if not args.no_inference and world == 1:
             out['inference'] = bench_inference()
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -119,14 +119,14 @@ class _DPSROIPool(torch.autograd.Function):
         d, r = data.detach().double().numpy(), rois.detach().numpy().astype(np.float32)
         t = None if trans is None else trans.detach().numpy().astype(np.float32)
         ctx.args = (d, r, t, P, S, scale, tstd, G)
-        # the loop definition up to a few hundred RoIs, its sparse-operator form (pinned to it by tests) at BASELINE sizes
-        fn = onn.dpsroi_pool if r.shape[0] <= 700 else onn.dpsroi_pool_fast
+        # the loop definition up to 64 RoIs, its sparse-operator form (pinned to it by tests) at BASELINE sizes
+        fn = onn.dpsroi_pool if r.shape[0] <= 64 else onn.dpsroi_pool_fast
         return torch.from_numpy(fn(d, r, t, P, S, scale, tstd, G)).float()
 
     @staticmethod
     def backward(ctx, g):
         d, r, t, P, S, scale, tstd, G = ctx.args
-        fn = onn.dpsroi_pool_backward if r.shape[0] <= 700 else onn.dpsroi_pool_backward_fast
+        fn = onn.dpsroi_pool_backward if r.shape[0] <= 64 else onn.dpsroi_pool_backward_fast
         dd, dt = fn(g.double().numpy(), d, r, t, P, S, scale, tstd, G)
         return (torch.from_numpy(dd).float(), None, (None if dt is None else torch.from_numpy(dt).float()), None, None, None,
                 None, None)

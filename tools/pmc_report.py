@@ -1,0 +1,80 @@
+"""Per-kernel HBM traffic and achieved bandwidth from two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, --pmc WRITE_SIZE;
+they do not fit one pass on gfx950) of one command:
+
+    python tools/pmc_report.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> out.json [name filter, comma separated]
+
+For every kernel: launches, average duration (kernel trace of the FETCH pass), HBM bytes fetched / written per launch and
+(fetch + write) / duration in GB/s.  Corrections as MI355X_MICROARCH.md section HBM prescribes: both counters are in KiB; on
+gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read, so it is doubled; WRITE_SIZE is used as reported
+(uncalibrated).  Traffic served by the 256 MB Infinity Cache appears to be counted, so for small working sets the figure
+is an upper bound of what reached HBM."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(.*', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'_Z\d+([A-Za-z_0-9]+?)(I[A-Z].*|P.*|v)?$', name)
+    if name.startswith('_Z'):
+        m = re.match(r'_Z(\d+)', name)
+        n = int(m.group(1))
+        return name[2 + len(m.group(1)):][:n]
+    return name.strip()
+
+
+def counters(d, counter):
+    out = {}
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection*.csv'), recursive=True):
+        with open(f, newline='') as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') != counter:
+                    continue
+                e = out.setdefault(short(row.get('Kernel_Name', '')), [0.0, 0])
+                e[0] += float(row['Counter_Value'])
+                e[1] += 1
+    return out
+
+
+def durations(d):
+    out = {}
+    for f in glob.glob(os.path.join(d, '**', '*kernel_trace*.csv'), recursive=True):
+        with open(f, newline='') as fh:
+            for row in csv.DictReader(fh):
+                e = out.setdefault(short(row.get('Kernel_Name', '')), [0.0, 0])
+                e[0] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+                e[1] += 1
+    return out
+
+
+def main():
+    fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    flt = [s for s in (sys.argv[4].split(',') if len(sys.argv) > 4 else []) if s]
+    fetch, write, dur = counters(fdir, 'FETCH_SIZE'), counters(wdir, 'WRITE_SIZE'), durations(fdir)
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        if flt and not any(s in k for s in flt):
+            continue
+        fv, fn = fetch.get(k, [0.0, 0])
+        wv, wn = write.get(k, [0.0, 0])
+        dv, dn = dur.get(k, [0.0, 0])
+        fb, wb = 2.0 * fv * 1024.0 / max(fn, 1), wv * 1024.0 / max(wn, 1)
+        us = dv / max(dn, 1) / 1e3
+        res[k] = {'launches': max(fn, wn), 'avg_us': round(us, 2), 'fetch_bytes_per_launch': round(fb), 'write_bytes_per_launch': round(wb),
+                  'hbm_gb_per_s': round((fb + wb) / (us * 1e-6) / 1e9, 1) if us > 0 else None}
+    doc = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); KiB -> bytes, FETCH_SIZE x2 '
+                     '(gfx950 correction, MI355X_MICROARCH.md); durations from the kernel trace of the FETCH pass (profiled clocks)',
+           'peak_gb_per_s': 8000, 'kernels': res}
+    with open(out, 'w') as fh:
+        json.dump(doc, fh, indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -(kv[1]['avg_us'] * kv[1]['launches'])):
+        print('%-44s n %5d  %9.1f us  fetch %11d  write %11d  %8s GB/s' % (k[:44], v['launches'], v['avg_us'], v['fetch_bytes_per_launch'],
+                                                                          v['write_bytes_per_launch'], v['hbm_gb_per_s']))
+
+
+if __name__ == '__main__':
+    main()

@@ -11,7 +11,8 @@ import json
 import os
 import sys
 
-FAMILY = ('conv_igemm_p2_kernel', 'conv_igemm_kernel', 'conv_wgrad_tr_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_kernel')
+FAMILY = ('conv_dma_kernel', 'conv_igemm_p2_kernel', 'conv_igemm_kernel', 'conv_wgrad_tr_kernel', 'conv_wgrad_kernel', 'wgrad_flat_dma_kernel',
+          'wgrad_taps_dma_kernel', 'wgrad_reduce_kernel')
 
 
 def collect(d, counter):
@@ -50,7 +51,9 @@ def main():
         per[k] = {'launches': n, 'fetch_bytes_per_launch': round(fb), 'write_bytes_per_launch': round(wb)}
         tot_b += (fb + wb) * n
         tot_n += n
-    res = {'hbm_bytes_per_launch': round(tot_b / max(tot_n, 1)), 'launches': tot_n, 'by_kernel': per,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import conv_sources_hash
+    res = {'hbm_bytes_per_launch': round(tot_b / max(tot_n, 1)), 'launches': tot_n, 'conv_sources_hash': conv_sources_hash(), 'by_kernel': per,
            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 2 '
                      '--warmup 1 --no-cpu-baseline`; KiB -> bytes, FETCH_SIZE x2 (gfx950 correction)'}
     with open(out, 'w') as fh:
