@@ -154,6 +154,26 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
     }
   };
 
+  // ---- the epilogue's residual tile is requested NOW: its (cold) latency then hides under the K loop instead of standing
+  // between the last MFMA and the stores (measured on the stage-3 expansion, K = 256: 54.6 -> us with the loads in the
+  // epilogue, 32 us for the same layer without a residual).  Ordinary loads retire in order with the LDS-DMA requests, so
+  // the first counted vmcnt of the loop also covers them.
+  const bool vec = (p.out_ps % 4 == 0) && (p.Nout % 4 == 0) && (!p.res || p.res_ps % 4 == 0);
+  constexpr bool kPre = MI * NI <= 16;      // 2 VGPRs per fragment; the 256 x 256 tile has none to spare
+  half4 rpre[kPre ? MI : 1][kPre ? NI : 1];
+  const bool pre_res = kPre && p.res != nullptr && vec;
+  if constexpr (kPre) if (pre_res) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) {
+        const int n = n0 + wn * WTN + jn * 16 + (lane >> 4) * 4;
+        rpre[i][jn] = (m < p.M && n < p.Nout) ? *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.res_ps + n) : half4{0, 0, 0, 0};
+      }
+    }
+  }
+
   // ---- pipeline: stages t+1 .. t+S-1 in flight under compute(t); one barrier per K-step
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
@@ -179,7 +199,6 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   }
 
   // ---- epilogue: lane (fr, fq) holds, for each (i, jn), pixel m = ..+fr and channels n = ..+fq*4 .. +3
-  const bool vec = (p.out_ps % 4 == 0) && (p.Nout % 4 == 0) && (!p.res || p.res_ps % 4 == 0);
   float st_s[NI][4], st_q[NI][4];        // BatchNorm statistics of this lane's output channels (host: only with `vec`)
 #pragma unroll
   for (int jn = 0; jn < NI; ++jn)
@@ -201,7 +220,12 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
           const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         }
-        if (p.res) {
+        if constexpr (kPre) {
+          if (pre_res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rpre[i][jn][r];
+          }
+        } else if (p.res) {
           const half4 rv = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.res_ps + n);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];

@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float *__re
 
 static int bias_grad_blocks(long rows, long *rows_per_block) {
   int by = (int)((rows + 255) / 256);
-  if (by > 512) by = 512;
+  if (by > 96) by = 96;      // the finish kernel walks the row blocks serially per channel
   if (by < 1) by = 1;
   *rows_per_block = (rows + by - 1) / by;
   return (int)((rows + *rows_per_block - 1) / *rows_per_block);

@@ -148,7 +148,10 @@ class Executor(object):
         # dY, the weight gradient is needed only by the optimizer, and most R101 layers have too few tiles to fill 256
         # CUs on their own (a 3x3 256->256 weight gradient is 36 tiles before K-splitting).
         self.side_stream = None
-        self.use_side_stream = for_training and os.environ.get('SNIPER_WGRAD_STREAM', '1') != '0' and self.device.type == 'cuda'
+        # Off by default since round 2: measured on MI355X (profiles/r02_*), the overlap buys nothing (30.15 ms with, 29.72 ms
+        # without) -- both streams' kernels fill the chip -- while every kernel's duration inflates (conv family 25.3 -> 18.8 ms
+        # summed).  SNIPER_WGRAD_STREAM=1 turns it back on.
+        self.use_side_stream = for_training and os.environ.get('SNIPER_WGRAD_STREAM', '0') == '1' and self.device.type == 'cuda'
         self._keepalive = []
         self._side_reads = set()     # storages the side stream may still be reading (see grad_slot)
         self._graph_fb = self._graph_up = None

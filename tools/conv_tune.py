@@ -63,6 +63,9 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--cfgs', default='0,1,2,3,4,5,6,7,8,9')
     ap.add_argument('--only', default='')
+    ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (> L2 + Infinity Cache = 288): '
+                    'every launch then reads operands no XCD has cached, as in the training step, where the producer of a tensor '
+                    'ran on other XCDs and 30 ms of other traffic separate two uses of a weight')
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(',')]
     d = torch.device('cuda', 0)
@@ -85,25 +88,35 @@ def main():
         M = N * Ho * Wo
         fl = 2.0 * M * O * C * K * K
         Op = (O + 7) // 8 * 8
-        x, w = h(N, H, W, C), h(O, K * K, C)
-        y = torch.empty((N, Ho, Wo, O), dtype=torch.float16, device=d)
-        dy = h(N, Ho, Wo, Op)
-        wt = h(C, K * K, Op)
-        dx = torch.empty_like(x)
+        per_set = 2 * (N * H * W * C + O * K * K * C + N * Ho * Wo * O)
+        nbuf = max(1, min(64, -(-a.cold * (1 << 20) // per_set))) if a.cold else 1
+        xs, ws_ = [h(N, H, W, C) for _ in range(nbuf)], [h(O, K * K, C) for _ in range(nbuf)]
+        ys = [torch.empty((N, Ho, Wo, O), dtype=torch.float16, device=d) for _ in range(nbuf)]
+        dys, wts = [h(N, Ho, Wo, Op) for _ in range(nbuf)], [h(C, K * K, Op) for _ in range(nbuf)]
+        dxs = [torch.empty_like(xs[0]) for _ in range(nbuf)]
+        x, w, y, dy, wt, dx = xs[0], ws_[0], ys[0], dys[0], wts[0], dxs[0]
+        ctr = [0]
         for direction, cnt in (('fwd', nf), ('dgrad', nd)):
             if cnt == 0:
                 continue
             if direction == 'fwd':
-                run = lambda: hip.call('sn_conv_fwd', x, w, None, None, y, N, H, W, C, C, O, O, O, K, K, s, p, dl, 0, 0, hip.stream())
+                def run():
+                    i = ctr[0] % nbuf
+                    ctr[0] += 1
+                    hip.call('sn_conv_fwd', xs[i], ws_[i], None, None, ys[i], N, H, W, C, C, O, O, O, K, K, s, p, dl, 0, 0, hip.stream())
                 out = y
             else:
-                run = lambda: hip.call('sn_conv_dgrad', dy, wt, None, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
+                def run():
+                    i = ctr[0] % nbuf
+                    ctr[0] += 1
+                    hip.call('sn_conv_dgrad', dys[i], wts[i], None, dxs[i], N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
                 out = dx
             ref = None
             row = {}
             for c in cfgs:
                 hip.call('sn_conv_tune', c)
                 out.zero_()
+                ctr[0] = 0
                 try:
                     run()
                     torch.cuda.synchronize()
@@ -116,7 +129,7 @@ def main():
                     err = 0.0
                 else:
                     err = float((o - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
-                us = timeit(run, a.iters)
+                us = timeit(run, max(a.iters, 2 * nbuf) if a.cold else a.iters)
                 row[c] = (us, err)
             hip.call('sn_conv_tune', -1)
             bc = min(row, key=lambda c: row[c][0])
