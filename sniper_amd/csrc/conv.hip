@@ -489,13 +489,37 @@ SN_EXPORT int sn_conv_tune(int cfg) {
 
 // Built-in choice for a layer that qualifies for the pipelined kernels: M output pixels, Nout channels, nk 64-deep K-steps.
 // Table measured on MI355X with tools/conv_tune.py (profiles/r02_conv_tune.txt).
-static int conv_dma_choice(int M, int Nout, int nk) {
+static int conv_dma_choice_warm(int M, int Nout, int nk) {
+  // table 1: tools/conv_tune.py on L2-warm operands (profiles/r02_conv_tune.txt)
   const long t128 = (long)sn_div_up(M, 128) * sn_div_up(Nout, 128), t64 = (long)sn_div_up(M, 64) * sn_div_up(Nout, 128);
   if (Nout <= 128) return nk >= 64 ? 5 : 6;          // one column tile: 64-row tiles, deeper ring for long contractions
   if (t128 >= 3840 && nk >= 8) return 7;              // >= 3.75 tiles of 256 x 256 per CU: the tile with the least LDS / L2 bytes per FLOP
   if (nk >= 128) return (Nout >= 1024 && M < 8192) ? 4 : 1;
   if (t64 <= 2560) return 6;                          // <= 10 resident 64 x 128 workgroups per CU over the launch: 3 per CU co-resident
   return 1;
+}
+
+static int conv_dma_choice_cold(int M, int Nout, int nk) {
+  // table 2: tools/conv_tune.py --cold 600 --insitu (profiles/r02_conv_tune_insitu.txt): operands no XCD has cached and the
+  // epilogues the training step uses (BatchNorm statistics, residual / accumulate)
+  const long t128 = (long)sn_div_up(M, 128) * sn_div_up(Nout, 128);
+  if (Nout <= 128) return nk >= 64 ? 5 : 6;
+  if (t128 >= 3840 && nk >= 8) return 7;
+  if (Nout <= 256) return M <= 32768 ? 4 : 1;           // 128 x 256: the whole channel range in one tile, A panel fetched once
+  if (Nout <= 512 && M <= 32768 && nk >= 16) return 7;  // stage 4 / RPN / deformable GEMM at 20 480 pixels: 160 tiles of 256 x 256
+  if (nk >= 128 || M < 8192) return (Nout >= 1024 && M < 8192) ? 4 : 1;   // FC over 6000 RoIs
+  return 1;
+}
+
+// SNIPER_CONV_TABLE = 1 | 2 picks the table; SNIPER_CONV_N128 / _N256 / _N512 / _NBIG override the configuration of a whole
+// output-width class (A/B runs of bench.py: the step itself is the only measurement that includes what precedes each launch).
+static int conv_dma_choice(int M, int Nout, int nk) {
+  static const int table = env_int("SNIPER_CONV_TABLE", 1);
+  static const int o128 = env_int("SNIPER_CONV_N128", -1), o256 = env_int("SNIPER_CONV_N256", -1),
+                   o512 = env_int("SNIPER_CONV_N512", -1), obig = env_int("SNIPER_CONV_NBIG", -1);
+  const int o = Nout <= 128 ? o128 : Nout <= 256 ? o256 : Nout <= 512 ? o512 : obig;
+  if (o >= 0) return o;
+  return table == 2 ? conv_dma_choice_cold(M, Nout, nk) : conv_dma_choice_warm(M, Nout, nk);
 }
 
 static ConvPlan conv_plan(const ConvParams &p) {

@@ -14,6 +14,8 @@
 // float32 arithmetic identical to devIoU (nms_kernel.cu:24-32): compiled with -ffp-contract=off.
 #include "common.h"
 
+#include <stdlib.h>
+
 __device__ __forceinline__ float dev_iou(const float *a, const float *b) {
   const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
   const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
@@ -119,6 +121,90 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(const unsigned l
   if (tid == 0) nkeep[b] = nk_s;
 }
 
+// ---- lazy variant for max_keep << N (MultiProposal / MultiProposalTarget: the first 300 survivors of 6000 sorted boxes).
+// The full bitmask is 18 M IoUs and 4.5 MB per image of which the scan then reads the rows of 300 survivors; here one
+// workgroup per image walks the candidates 64 at a time and stops at max_keep survivors:
+//   1. every candidate of the chunk against the survivors so far (kept boxes live in LDS; wave w takes survivors w, w+4, ...,
+//      lane = candidate, ballot -> 64-bit "dead" word per wave);
+//   2. the 64 x 64 upper triangle inside the chunk (wave w computes columns 16 w .. 16 w + 15 of every row);
+//   3. wave 0 resolves the chunk sequentially on those diagonal words exactly as nms_scan_kernel does and appends the new
+//      survivors (boxes to LDS, indices to `keep`).
+// Same predicate (dev_iou(a, b) > thresh, symmetric bit for bit), same greedy order -> the same survivor list as the
+// mask + scan pair; work ~ (candidates examined) x (survivors) instead of N^2 / 2.
+constexpr int kLazyMaxKeep = 1024;
+
+__global__ __launch_bounds__(256) void nms_lazy_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ n_per, int N,
+                                                       int dim, float thresh, int max_keep, int32_t *__restrict__ keep,
+                                                       int32_t *__restrict__ nkeep) {
+  __shared__ float kb[kLazyMaxKeep * 4];
+  __shared__ float cand[64 * 4];
+  __shared__ unsigned long long dead_w[4];
+  __shared__ unsigned dpart[4][64];
+  __shared__ int nk_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = n_per ? min(n_per[b], N) : N;
+  const float *bb = boxes + (size_t)b * N * dim;
+  int32_t *kp = keep + (size_t)b * max_keep;
+  if (tid == 0) nk_s = 0;
+  __syncthreads();
+  const int nchunks = (n + 63) / 64;
+  for (int c = 0; c < nchunks; ++c) {
+    const int nk = nk_s;
+    if (nk >= max_keep) break;
+    const int row = c * 64 + lane, csize = min(n - c * 64, 64);
+    if (wave == 0 && lane < csize) {
+      const float *p = bb + (size_t)row * dim;
+      cand[lane * 4 + 0] = p[0]; cand[lane * 4 + 1] = p[1]; cand[lane * 4 + 2] = p[2]; cand[lane * 4 + 3] = p[3];
+    }
+    __syncthreads();
+    const bool in = lane < csize;
+    float me[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in) { me[0] = cand[lane * 4]; me[1] = cand[lane * 4 + 1]; me[2] = cand[lane * 4 + 2]; me[3] = cand[lane * 4 + 3]; }
+    // 1. suppressed by an earlier survivor?
+    bool dead = false;
+    for (int k = wave; k < nk; k += 4) dead = dead || (dev_iou(kb + k * 4, me) > thresh);
+    const unsigned long long dw = __ballot(dead && in);
+    if (lane == 0) dead_w[wave] = dw;
+    // 2. this wave's 16 columns of the chunk's upper triangle
+    unsigned bits = 0u;
+    if (in) {
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = wave * 16 + jj;
+        if (j > lane && j < csize && dev_iou(me, cand + j * 4) > thresh) bits |= 1u << jj;
+      }
+    }
+    dpart[wave][lane] = bits;
+    __syncthreads();
+    // 3. sequential resolution of the chunk (wave 0), as in nms_scan_kernel
+    if (wave == 0) {
+      const unsigned long long diag = (unsigned long long)dpart[0][lane] | ((unsigned long long)dpart[1][lane] << 16) |
+                                      ((unsigned long long)dpart[2][lane] << 32) | ((unsigned long long)dpart[3][lane] << 48);
+      const unsigned long long alive = __ballot(in) & ~(dead_w[0] | dead_w[1] | dead_w[2] | dead_w[3]);
+      unsigned long long sup = 0ull, kept = 0ull;
+      int nk2 = nk;
+      for (int r = 0; r < 64; ++r) {  // wave-uniform loop
+        const unsigned long long d =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(diag >> 32), r) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)(diag & 0xffffffffu), r);
+        const bool take = ((alive >> r) & 1ull) && !((sup >> r) & 1ull) && nk2 < max_keep;
+        if (take) {
+          kept |= 1ull << r;
+          sup |= d;
+          ++nk2;
+        }
+      }
+      if ((kept >> lane) & 1ull) {
+        const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
+        kb[pos * 4 + 0] = me[0]; kb[pos * 4 + 1] = me[1]; kb[pos * 4 + 2] = me[2]; kb[pos * 4 + 3] = me[3];
+        kp[pos] = row;
+      }
+      if (lane == 0) nk_s = nk2;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) nkeep[b] = nk_s;
+}
+
 SN_EXPORT size_t sn_nms_workspace_bytes(int B, int N) {
   const size_t cb = (size_t)sn_div_up(N > 0 ? N : 1, 64);
   return sn_align((size_t)(B > 0 ? B : 1) * (size_t)(N > 0 ? N : 1) * cb * sizeof(unsigned long long));
@@ -135,7 +221,13 @@ SN_EXPORT int sn_nms_batch(const float *d_boxes, const int32_t *d_n, int B, int 
     SN_HIP(hipMemsetAsync(d_nkeep, 0, sizeof(int32_t) * B, s));
     return SN_OK;
   }
-  SN_REQUIRE(d_boxes && d_ws && d_keep, "sn_nms_batch: null pointer");
+  SN_REQUIRE(d_boxes && d_keep, "sn_nms_batch: null pointer");
+  if (max_keep <= kLazyMaxKeep && max_keep * 4 <= N && !getenv("SNIPER_NMS_FULL")) {
+    hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(256), 0, s, d_boxes, d_n, N, dim, thresh, max_keep, d_keep, d_nkeep);
+    SN_CHECK_LAUNCH();
+    return SN_OK;
+  }
+  SN_REQUIRE(d_ws, "sn_nms_batch: the full-mask path needs sn_nms_workspace_bytes(B, N) of scratch");
   const int cb = sn_div_up(N, 64);
   SN_REQUIRE((size_t)cb * sizeof(unsigned long long) <= 64 * 1024, "sn_nms_batch: N=%d too large for the LDS scan", N);
   // The scan reads mask words of rows it keeps for columns >= the row's own block; every such

@@ -112,6 +112,48 @@ def test_nms_survivor_sets_bit_exact():
     assert list(map(int, cpu_nms.cpu_nms(two, th))) == [0]
 
 
+def test_nms_lazy_kernel_equals_full_mask_and_oracle(monkeypatch):
+    """nms_lazy_kernel (max_keep << N: the proposal op's 6000 -> 300) against the full bitmask + scan pair (SNIPER_NMS_FULL=1)
+    and the oracle: identical survivor lists on sparse boxes (300 reached within a few chunks), on dense clusters (fewer
+    than max_keep survivors: every chunk is walked), with ragged per-image counts, and at the max_keep boundary."""
+    import torch
+    from sniper_amd import hip
+    rs = np.random.RandomState(17)
+
+    def run(ds, n_per, th, mk, full):
+        if full:
+            monkeypatch.setenv('SNIPER_NMS_FULL', '1')
+        else:
+            monkeypatch.delenv('SNIPER_NMS_FULL', raising=False)
+        B, N, _ = ds.shape
+        d = hip.dev(ds)
+        keep = torch.full((B, mk), -1, dtype=torch.int32, device=d.device)
+        nk = torch.empty((B,), dtype=torch.int32, device=d.device)
+        ws = torch.empty(hip.query('sn_nms_workspace_bytes', B, N), dtype=torch.uint8, device=d.device)
+        npd = hip.dev(np.asarray(n_per, np.int32)) if n_per is not None else None
+        hip.call('sn_nms_batch', d, npd, B, N, 5, float(th), mk, ws, keep, nk, hip.stream())
+        return keep.cpu().numpy(), nk.cpu().numpy()
+
+    def dense(n):      # a few hundred clusters of near-duplicates: far fewer survivors than candidates
+        c = rs.uniform(0, 512, (40, 2))[rs.randint(0, 40, n)] + rs.normal(0, 3, (n, 2))
+        wh = np.exp(rs.normal(np.log(60), 0.15, (n, 2)))
+        return np.concatenate((c - wh / 2, c + wh / 2, np.sort(rs.uniform(0, 1, (n, 1)), 0)[::-1]), 1).astype(np.float32)
+
+    cases = [(np.stack([_np_sorted(rs, 6000) for _ in range(3)]), None, 0.7, 300),
+             (np.stack([dense(6000), dense(6000)]), None, 0.7, 300),
+             (np.stack([_np_sorted(rs, 2000), dense(2000), _np_sorted(rs, 2000)]), [2000, 1337, 64], 0.5, 100),
+             (np.stack([_np_sorted(rs, 1024)]), None, 0.3, 256), (np.stack([dense(4096)]), [4096], 0.7, 1024)]
+    for ds, n_per, th, mk in cases:
+        k_lazy, n_lazy = run(ds, n_per, th, mk, full=False)
+        k_full, n_full = run(ds, n_per, th, mk, full=True)
+        assert np.array_equal(n_lazy, n_full), (n_lazy, n_full)
+        for b in range(ds.shape[0]):
+            n = ds.shape[1] if n_per is None else n_per[b]
+            want = oracle.nms_sorted(ds[b, :n], th, mk)
+            assert int(n_lazy[b]) == len(want)
+            assert np.array_equal(k_lazy[b, :len(want)], want) and np.array_equal(k_full[b, :len(want)], want)
+
+
 def test_nms_host_abi_drop_in():
     """sn_nms_host has the reference's _nms() signature (lib/nms/gpu_nms.hpp)."""
     import ctypes

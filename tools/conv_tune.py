@@ -66,6 +66,9 @@ def main():
     ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (> L2 + Infinity Cache = 288): '
                     'every launch then reads operands no XCD has cached, as in the training step, where the producer of a tensor '
                     'ran on other XCDs and 30 ms of other traffic separate two uses of a weight')
+    ap.add_argument('--insitu', action='store_true', help='call the layers the way the training step does: forward with the '
+                    'BatchNorm-statistics epilogue (sn_conv_fwd_stats; + residual on the 1x1 expansions), data gradient '
+                    'accumulating into the trunk gradient where Nout = 4 K')
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(',')]
     d = torch.device('cuda', 0)
@@ -99,17 +102,27 @@ def main():
         for direction, cnt in (('fwd', nf), ('dgrad', nd)):
             if cnt == 0:
                 continue
+            expand = K == 1 and s == 1 and O == 4 * C          # conv3 of a bottleneck: residual add in the epilogue
+            reduce_ = K == 1 and s == 1 and C == 4 * O         # conv1: its data gradient accumulates into the trunk gradient
             if direction == 'fwd':
+                part = torch.empty((4096, 2, O), dtype=torch.float32, device=d)
+                ress = [h(N, Ho, Wo, O) for _ in range(nbuf)] if (a.insitu and expand) else None
+
                 def run():
                     i = ctr[0] % nbuf
                     ctr[0] += 1
-                    hip.call('sn_conv_fwd', xs[i], ws_[i], None, None, ys[i], N, H, W, C, C, O, O, O, K, K, s, p, dl, 0, 0, hip.stream())
+                    if a.insitu and hip.query('sn_conv_fwd_stats_blocks', N, H, W, C, C, O, O, O if ress else 0, K, K, s, p, dl) > 0:
+                        hip.call('sn_conv_fwd_stats', xs[i], ws_[i], None, ress[i] if ress else None, ys[i], N, H, W, C, C, O, O,
+                                 O if ress else 0, K, K, s, p, dl, 0, part, hip.stream())
+                    else:
+                        hip.call('sn_conv_fwd', xs[i], ws_[i], None, None, ys[i], N, H, W, C, C, O, O, O, K, K, s, p, dl, 0, 0, hip.stream())
                 out = y
             else:
                 def run():
                     i = ctr[0] % nbuf
                     ctr[0] += 1
-                    hip.call('sn_conv_dgrad', dys[i], wts[i], None, dxs[i], N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
+                    acc = dxs[(i + 1) % nbuf] if (a.insitu and reduce_) else None
+                    hip.call('sn_conv_dgrad', dys[i], wts[i], acc, dxs[i], N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
                 out = dx
             ref = None
             row = {}
@@ -128,7 +141,8 @@ def main():
                     ref = o.clone()
                     err = 0.0
                 else:
-                    err = float((o - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+                    # (in-situ mode accumulates into buffers earlier runs wrote: outputs are compared in the plain mode only)
+                    err = 0.0 if a.insitu else float((o - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
                 us = timeit(run, max(a.iters, 2 * nbuf) if a.cold else a.iters)
                 row[c] = (us, err)
             hip.call('sn_conv_tune', -1)

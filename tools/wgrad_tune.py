@@ -37,7 +37,7 @@ LAYERS = [
     ('fc_new_2 1024->1024 x6000', 0, 0, 1024, 1024, 1, 1, 0, 1, 1),
     ('fc cls 1024->81 x6000', 0, 0, 1024, 81, 1, 1, 0, 1, 1),
 ]
-MODES = [(-1, -1, 0), (0, 0, 512), (0, 0, 256), (2, 3, 512), (2, 4, 256), (2, 4, 512)]
+MODES = [(-1, -1, 0), (0, 0, 512), (0, 0, 256), (0, 0, 384), (2, 4, 512), (2, 4, 256), (3, 3, 512)]
 
 
 def timeit(fn, iters, warm=3):
@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
+    ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (see tools/conv_tune.py)')
     a = ap.parse_args()
     d = torch.device('cuda', 0)
     B = a.batch
@@ -90,10 +91,14 @@ def main():
         Ho, Wo = (H + 2 * p - dl * (K - 1) - 1) // s + 1, (W + 2 * p - dl * (K - 1) - 1) // s + 1
         fl = 2.0 * N * Ho * Wo * O * C * K * K
         Op = (O + 7) // 8 * 8
-        x = h(N, H, W, C)
-        dy = h(N, Ho, Wo, Op)
+        per_set = 2 * (N * H * W * C + N * Ho * Wo * Op)
+        nbuf = max(1, min(64, -(-a.cold * (1 << 20) // per_set))) if a.cold else 1
+        xs, dys = [h(N, H, W, C) for _ in range(nbuf)], [h(N, Ho, Wo, Op) for _ in range(nbuf)]
         if Op != O:
-            dy[..., O:] = 0
+            for t_ in dys:
+                t_[..., O:] = 0
+        x, dy = xs[0], dys[0]
+        ctr = [0]
         cos = torch.arange(0, O, max(1, O // 7), device=d)[:8]
         cis = torch.arange(0, C, max(1, C // 5), device=d)[:6]
         ref = reference_samples(x, dy, K, s, p, dl, Ho, Wo, cos, cis)
@@ -103,7 +108,11 @@ def main():
             need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, dl)
             wsb = torch.empty(max(need, 16), dtype=torch.uint8, device=d)
             dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=d)
-            run = lambda: hip.call('sn_conv_wgrad', dy, x, dw, N, H, W, C, C, O, Op, K, K, s, p, dl, wsb, need, hip.stream())
+            def run():
+                i = ctr[0] % nbuf
+                ctr[0] += 1
+                hip.call('sn_conv_wgrad', dys[i], xs[i], dw, N, H, W, C, C, O, Op, K, K, s, p, dl, wsb, need, hip.stream())
+            ctr[0] = 0
             run()
             torch.cuda.synchronize()
             got = dw[cos][:, :, cis]
@@ -112,7 +121,7 @@ def main():
                 base, dself = dw.clone(), 0.0
             else:
                 dself = float((dw - base).abs().max() / base.abs().max().clamp_min(1e-6))
-            us = timeit(run, a.iters)
+            us = timeit(run, max(a.iters, 2 * nbuf))
             row[m] = (us, err, dself)
         hip.call('sn_conv_wgrad_tune', -1, -1, 0)
         cells = ' '.join('%s:%7.1f%s' % ('%d/%d/%d' % m, row[m][0], '' if (row[m][1] < 2e-3 and row[m][2] < 2e-3) else '!ERR(ref %.1e self %.1e)' % row[m][1:])
