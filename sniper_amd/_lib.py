@@ -11,7 +11,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, "..", "include", "sniper_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libsniper_hip.so")
+# SNIPER_HIP_LIB: another build of the same library (A/B runs of whole programs: tools/conv_ab.sh)
+LIB_PATH = os.environ.get("SNIPER_HIP_LIB") or os.path.join(_HERE, "lib", "libsniper_hip.so")
 
 _SCALARS = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,

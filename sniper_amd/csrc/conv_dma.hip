@@ -30,6 +30,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, half_t *dst, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
 }
 
+// sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), result in every lane: four VALU adds with DPP operands
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) instead of four ds_bpermute round trips per value
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of its half row (the other quad)
+  return dpp_add<0x140>(v);   // row_mirror: lane i <-> 15 - i (the other half row)
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -287,11 +300,8 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
     for (int jn = 0; jn < NI; ++jn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          st_s[jn][r] += __shfl_xor(st_s[jn][r], off, 64);
-          st_q[jn][r] += __shfl_xor(st_q[jn][r], off, 64);
-        }
+        st_s[jn][r] = row16_sum(st_s[jn][r]);
+        st_q[jn][r] = row16_sum(st_q[jn][r]);
       }
     float *red = reinterpret_cast<float *>(lds);   // [wm][2][BN]
     __syncthreads();

@@ -1,28 +1,36 @@
 #!/bin/bash
-# SQ counters of the conv kernels on the RPN-sized problem (rocprofv3 --pmc, kernel-trace only).
+# SQ / TCC counters of the convolution kernels IN SITU (one profiled bench.py step sequence per counter set; rocprofv3 --pmc with
+# --kernel-trace only).  Output: gpurun_out/pmc_conv_insitu.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 ROOT=$(pwd)
 mkdir -p gpurun_out
-rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCC|TCP|TA)_[A-Z0-9_]+" | sort -u > gpurun_out/counters.txt
-cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCC|TCP|TA|TD|GRBM)_[A-Za-z0-9_]+" | sort -u > gpurun_out/counters.txt
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$ROOT/gpurun_out/pmc_conv$i" -o c -- python "$ROOT/tools/microbench.py" --only rpn --quick > "$ROOT/gpurun_out/pmc_conv$i.log" 2>&1
-  echo "set $i exit $?"
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$ROOT/gpurun_out/pmc_conv$i" -o c -- \
+      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference > "$ROOT/gpurun_out/pmc_conv$i.log" 2>&1; echo "set $i exit $?")
 done
-cd "$ROOT" && python - <<'PY'
-import csv, glob, collections
-for d in ('gpurun_out/pmc_conv1', 'gpurun_out/pmc_conv2'):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+python - <<'PY' > gpurun_out/pmc_conv_insitu.txt
+import csv, glob, collections, re
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); dur = collections.defaultdict(list)
+for d in sorted(glob.glob('gpurun_out/pmc_conv[0-9]')):
     for f in glob.glob(d + '/**/*counter_collection*.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'][:60]
-            if 'conv' not in k: continue
+            k = re.sub(r'\(.*', '', r['Kernel_Name'])[:64]
+            if 'conv' not in k and 'wgrad' not in k and 'bn_' not in k: continue
             acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
-    for k, v in acc.items():
-        print(k)
-        for c, x in sorted(v.items()):
-            print('   %-28s %14.0f per launch' % (c, x / max(n[(k, c)], 1)))
+    for f in glob.glob(d + '/**/*kernel_trace*.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r'\(.*', '', r['Kernel_Name'])[:64]
+            dur[k].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+for k, v in sorted(acc.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
+    d_ = dur.get(k, [0])
+    print('%s   launches %d  avg %.1f us' % (k, len(d_), sum(d_) / max(len(d_), 1) / 1e3))
+    for c, x in sorted(v.items()):
+        print('   %-28s %16.0f per launch' % (c, x / max(n[(k, c)], 1)))
 PY
+head -150 gpurun_out/pmc_conv_insitu.txt
+find gpurun_out/pmc_conv[0-9] -name "*.csv" -size +6M -delete
