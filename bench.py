@@ -96,11 +96,27 @@ class ConvProfiler(object):
     def __exit__(self, *exc):
         self.hip.call = self.orig
 
+    @staticmethod
+    def bracket_overhead_ms(n=64):
+        """What an EMPTY event bracket measures on this stream (event-to-event latency): subtracted from every launch's
+        bracket so that the sum is the kernels' time, the quantity rocprofv3 --stats reports."""
+        ev = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        v = sorted(a.elapsed_time(b) for a, b in ev)
+        return v[len(v) // 2]
+
     def summary(self):
         torch.cuda.synchronize()
+        over = self.bracket_overhead_ms()
+        self.overhead_ms = over
         tot_ms, tot_fl, per = 0.0, 0.0, {}
         for name, fl, e0, e1 in self.records:
-            ms = e0.elapsed_time(e1)
+            ms = max(e0.elapsed_time(e1) - over, 0.0)
             tot_ms += ms
             tot_fl += fl
             d = per.setdefault(name, [0, 0.0, 0.0])
@@ -348,7 +364,9 @@ def main():
         with ConvProfiler() as prof:
             for i in range(2):
                 step(i)
-            return prof.summary()
+            res = prof.summary()
+            profile.overhead_us = prof.overhead_ms * 1e3
+            return res
     tot_ms, tot_fl, per = profile(side)             # in situ: the stream assignment of the timed region
     iso_ms, iso_fl, iso_per = profile(False)        # one stream: a launch's duration is its own
     ex.use_graphs, ex._graph_fb, ex._graph_up = saved
@@ -363,7 +381,7 @@ def main():
             'mode': 'in situ (eager replay of the timed step, weight gradients on the side stream: %s); sum of launch durations as '
                     'rocprofv3 --kernel-trace --stats reports them' % bool(side),
             'achieved_isolated': round(isolated, 2), 'frac_isolated': round(isolated / MFMA_PEAK_TFLOPS, 4),
-            'step_tflops': round(tot_fl / 2 / (ms_per_step * 1e-3) / 1e12, 2),
+            'step_tflops': round(tot_fl / 2 / (ms_per_step * 1e-3) / 1e12, 2), 'event_bracket_overhead_us': round(profile.overhead_us, 2),
             'traffic': pmc_traffic(),
             'launches_per_step': n_launch // 2,
             'avg_launch_ms': round(tot_ms / max(1, n_launch), 4),
