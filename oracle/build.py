@@ -87,14 +87,14 @@ _CPU_NMS_PATCH = ((112, 'np.float thresh', 'float thresh'), (120, 'np.int_t', 'n
 
 def build_reference_cpu_nms(force=False):
     """oracle/_ref/cpu_nms*.so from lib/nms/cpu_nms.pyx (cpu_soft_nms verbatim, cpu_nms with _CPU_NMS_PATCH)."""
+    out = os.path.join(REF_OUT, "cpu_nms" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not force and os.path.exists(out):
+        return out                      # (the GPU box has the prebuilt module and no reference checkout)
     if not have_reference():
         return None
     import numpy
 
     os.makedirs(REF_OUT, exist_ok=True)
-    out = os.path.join(REF_OUT, "cpu_nms" + sysconfig.get_config_var("EXT_SUFFIX"))
-    if not force and os.path.exists(out):
-        return out
     with open(os.path.join(REF, "lib", "nms", "cpu_nms.pyx")) as fh:
         lines = fh.read().split("\n")
     for ln, old, new in _CPU_NMS_PATCH:
@@ -148,6 +148,14 @@ def build_reference_py3(force=False):
                 if f.endswith((".py", ".yml")):
                     shutil.copy(os.path.join(root, f), os.path.join(out, rel, f))
     subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # lib/inference.py is imported as the TOP-LEVEL module `inference` (main_test.py:14, with lib/ on sys.path); lib2to3's import
+    # fixer, seeing lib/__init__.py, turned its imports of the sibling packages into relative ones -- put them back
+    import re
+    inf = os.path.join(out, "lib", "inference.py")
+    with open(inf) as fh:
+        src = fh.read()
+    with open(inf, "w") as fh:
+        fh.write(re.sub(r"^from \.(\w)", r"from \1", src, flags=re.M))
     for rel, old, new in _PY3_FIXES:
         path = os.path.join(out, rel)
         with open(path) as fh:

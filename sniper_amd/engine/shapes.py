@@ -135,7 +135,8 @@ def infer_node(node, ins, shapes_of_var):
     if op == 'MultiProposal':
         cp = ins[0]
         post = int(a.get('rpn_post_nms_top_n', 300))
-        return [(cp[0] * post, 5), (cp[0] * post, 1)], par
+        # scores are 1-D: the reference's only consumer stacks `cscores[0:n, np.newaxis]` beside (n, 4) boxes (lib/inference.py:389-391)
+        return [(cp[0] * post, 5), (cp[0] * post,)], par
     if op == 'MultiProposalTarget':
         cp = ins[0]
         post = int(a.get('rpn_post_nms_top_n', 300))

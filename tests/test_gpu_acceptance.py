@@ -1,4 +1,4 @@
-"""-m gpu: the reference's own main_train.py executed over sniper_amd (tests/acceptance_main_train.py) -- SURVEY section 8(b):
+"""-m gpu: the reference's own main_train.py and main_test.py executed over sniper_amd (tests/acceptance_main_{train,test}.py) -- SURVEY section 8(b):
 "run them over our mxnet shim -- this *is* the acceptance test".  The reference's Python travels to the GPU box as the
 lib2to3 artefact oracle/_ref/py3 (oracle/build.py::build_reference_py3; git-ignored like the compiled reference modules)."""
 import json
@@ -42,6 +42,51 @@ def test_reference_main_train_runs_unchanged(tmp_path):
     assert len(res['anchor_labels']) >= 2
     for c in res['anchor_labels']:
         assert c['label_equal'] and c['weight_equal'] and c['gt_equal'] and c['target_maxdiff'] <= 1e-6, c
+
+
+def test_reference_main_test_runs_unchanged(tmp_path):
+    """main_test.py:32-61 -> lib/inference.py imdb_detection_wrapper / detect_scale_worker / Tester over the shim: three test
+    scales, per-scale pickles, valid-range aggregation, soft-NMS through the cpu_nms mirror (bit-equal to the reference's compiled
+    cpu_nms.pyx on the recorded calls)."""
+    if not os.path.isfile(os.path.join(ROOT, 'oracle', '_ref', 'py3', 'main_test.py')):
+        pytest.skip('oracle/_ref/py3 not built (python -m oracle.build where the reference checkout exists)')
+    out = str(tmp_path / 'acceptance_test.json')
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'acceptance_main_test.py'), out], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-6000:]
+    res = json.load(open(out))
+    assert res['evaluated'] and res['classes'] == 81 and res['images'] == res['n_images'] and res['outputs_finite']
+    # every test scale of the yml ran (three different input extents reached Module.forward) and cached its detections
+    assert len(res['forward_shapes']) >= 3, res['forward_shapes']
+    for d in ('dets_scale_1400x2000', 'dets_scale_800x1280', 'dets_scale_480x512'):
+        assert d in res['scales'] and res['scales'][d]['dets'] > 0, res['scales']
+        assert res['scales'][d]['min_score'] > 1e-3                    # Tester.get_detections' score threshold (inference.py:290)
+    assert 'dets_final/detections.pkl' in res['result_files'] and res['final_pickle_equal']
+    assert res['shape_ok'] and res['finite'] and res['in_bounds']
+    # MAX_PER_IMAGE = 200 (yml:177) keeps scores >= the 200th largest: ties may add a few
+    assert all(0 < n <= 220 for n in res['dets_per_image']), res['dets_per_image']
+    assert res['nms_replayed'] >= 10 and res['nms_bit_equal'] == res['nms_replayed'], res
+
+
+def test_reference_main_test_extracts_proposals(tmp_path):
+    """TEST.EXTRACT_PROPOSALS: main_test.py:58-59 -> imdb_proposal_extraction_wrapper / proposal_scale_worker /
+    Tester.extract_proposals (lib/inference.py:556-609,531-553,372-408) with the reference's MNIteratorTest and
+    get_symbol_rpn(is_train=False); writes the `<DATASET>_<image set>_rpn.pkl` negative-chip proposal file (list of (n, 5) float32
+    [x1, y1, x2, y2, score], the format lib/dataset/imdb.py:81-118 reads back)."""
+    if not os.path.isfile(os.path.join(ROOT, 'oracle', '_ref', 'py3', 'main_test.py')):
+        pytest.skip('oracle/_ref/py3 not built (python -m oracle.build where the reference checkout exists)')
+    out = str(tmp_path / 'acceptance_props.json')
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'acceptance_main_test.py'), out, '--proposals'], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-6000:]
+    res = json.load(open(out))
+    assert res['proposal_files'] == ['COCO_synthetic_val_rpn.pkl'] and res['images'] == res['n_images']
+    assert res['shapes'] == [[900, 5]] * res['n_images'] and res['dtype'] == 'float32'        # 3 scales x N_PROPOSAL_PER_SCALE (yml:250)
+    assert res['in_bounds'] and res['scores_sorted']
+    assert res['scale_files'] == ['props_scale_1400x2000', 'props_scale_480x512', 'props_scale_800x1280']
+    assert len(res['forward_shapes']) >= 3
 
 
 def _ohem_numpy(cls_score, bbox_pred, labels, bbox_targets, bbox_weights, k):
