@@ -511,18 +511,34 @@ static int conv_dma_choice_cold(int M, int Nout, int nk) {
   return 1;
 }
 
-// SNIPER_CONV_TABLE = 1 | 2 picks the table; SNIPER_CONV_N128 / _N256 / _N512 / _NBIG override the configuration of a whole
+static int conv_dma_choice_balanced(int M, int Nout, int nk) {
+  // table 3: tools/conv_tune.py --insitu with the 160-row tiles in the candidate set (profiles/r02_conv_tune_insitu_v3.txt).
+  // tools/conv_trace.py shows why they win at 20 chips: a K-step's operand delivery is an LDS-DMA issue cost per wave, so a
+  // CU wants >= 8 waves in K loops (two 4-wave workgroups) and every CU the same number of tiles -- 20 480 pixels / 160 = 128
+  // row tiles = 256 / 512 / 1024 / 2048 workgroups for 256 / 512 / 1024 / 2048 output channels, 81 920 / 160 = 512.
+  const long t128 = (long)sn_div_up(M, 128) * sn_div_up(Nout, 128);
+  if (t128 >= 3840 && nk >= 8) return 7;              // the long-K data gradients (RPN, deformable GEMM, fc_new_1): 256 x 256
+  if (Nout < 128) return nk >= 64 ? 5 : 6;           // narrow heads: one partial column tile
+  if (M < 8192) return (Nout >= 1024 && nk >= 128) ? 4 : 6;   // FullyConnected over 6000 RoIs
+  if (nk <= 1) return 6;                              // stage 1: a single K-step, all epilogue
+  return 14;
+}
+
+// SNIPER_CONV_TABLE = 1 | 2 | 3 picks the table; SNIPER_CONV_N128 / _N256 / _N512 / _NBIG override the configuration of a whole
 // output-width class (A/B runs of bench.py: the step itself is the only measurement that includes what precedes each launch).
-static int conv_dma_choice(int M, int Nout, int nk) {
-  static const int table = env_int("SNIPER_CONV_TABLE", 1);
+static int conv_dma_choice(int M, int Nout, int nk, bool dgrad) {
+  // default: forward layers from the balanced table, data gradients from table 1 -- whole-step A/B on one box
+  // (tools/conv_ab.sh): tables (fwd, dgrad) = (1, 1) 29.44 ms, (3, 3) 29.16 ms, (3, 1) 28.60 ms
+  static const int table_f = env_int("SNIPER_CONV_TABLE", 3), table_d = env_int("SNIPER_CONV_TABLE_DGRAD", table_f == 3 ? 1 : table_f);
+  const int table = dgrad ? table_d : table_f;
   static const int o128 = env_int("SNIPER_CONV_N128", -1), o256 = env_int("SNIPER_CONV_N256", -1),
                    o512 = env_int("SNIPER_CONV_N512", -1), obig = env_int("SNIPER_CONV_NBIG", -1);
   const int o = Nout <= 128 ? o128 : Nout <= 256 ? o256 : Nout <= 512 ? o512 : obig;
   if (o >= 0) return o;
-  return table == 2 ? conv_dma_choice_cold(M, Nout, nk) : conv_dma_choice_warm(M, Nout, nk);
+  return table == 3 ? conv_dma_choice_balanced(M, Nout, nk) : table == 2 ? conv_dma_choice_cold(M, Nout, nk) : conv_dma_choice_warm(M, Nout, nk);
 }
 
-static ConvPlan conv_plan(const ConvParams &p) {
+static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {
   // Layers whose taps are whole 64-channel K-steps and 16-byte addressable take a pipelined kernel; narrow outputs
   // (stage1 / RPN heads) and the packed stem stay on conv_igemm_kernel.
   ConvPlan q = {0, 0, 0, 0, 0u, 0u};
@@ -532,7 +548,7 @@ static ConvPlan conv_plan(const ConvParams &p) {
       !getenv("SNIPER_CONV_V1")) {
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
-    const int cfg = g_conv_cfg >= 0 ? g_conv_cfg : conv_dma_choice(p.M, p.Nout, p.KH * p.KW * (p.Cin / 64));
+    const int cfg = g_conv_cfg >= 0 ? g_conv_cfg : conv_dma_choice(p.M, p.Nout, p.KH * p.KW * (p.Cin / 64), dgrad);
     if (cfg > 0) {
       const ConvDmaConfig c = conv_dma_config(cfg);
       q.dma = cfg;
@@ -552,7 +568,7 @@ static ConvPlan conv_plan(const ConvParams &p) {
 
 template <bool DGRAD>
 static int conv_launch(const ConvParams &p, hipStream_t s) {
-  const ConvPlan pl = conv_plan(p);
+  const ConvPlan pl = conv_plan(p, DGRAD);
   if (pl.dma) {
     ConvParams q = p;
     q.x_bytes = pl.x_bytes;
@@ -612,7 +628,7 @@ SN_EXPORT int sn_conv_fwd_stats_blocks(int N, int H, int W, int Cin, int in_pix_
   conv_fwd_params(p, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH,
                   KW, stride, pad, dil, 0, 0);
   if (p.Ho <= 0 || p.Wo <= 0 || Cout % 4 != 0 || out_pix_stride % 4 != 0 || (res_pix_stride % 4) != 0) return 0;
-  const ConvPlan pl = conv_plan(p);
+  const ConvPlan pl = conv_plan(p, false);
   return pl.bm ? pl.mtiles : 0;
 }
 
@@ -683,7 +699,7 @@ SN_EXPORT int sn_conv_dgrad_bn_blocks(int N, int H, int W, int Cin, int dx_pix_s
   conv_dgrad_params(p, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, dx_pix_stride, Cout, dy_pix_stride, acc_pix_stride, KH, KW,
                     stride, pad, dil, 0);
   if (p.H <= 0 || p.W <= 0 || Cin % 4 != 0 || dx_pix_stride % 4 != 0 || acc_pix_stride % 4 != 0) return 0;
-  const ConvPlan pl = conv_plan(p);
+  const ConvPlan pl = conv_plan(p, true);
   return pl.bm ? pl.mtiles : 0;
 }
 

@@ -27,6 +27,7 @@ struct ConvParams {
   const half_t *bn_x = nullptr;
   const float *bn_scale = nullptr, *bn_shift = nullptr, *bn_mean = nullptr;
   int bn_x_ps = 0, bn_act = 0;
+  unsigned long long *trace = nullptr;   // phase timeline of every workgroup (tools/conv_trace.py; SNIPER_CONV_TRACE), normally null
   float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
                        // STORED fp16 values (what bn_stats_kernel would read back), or null
 };
@@ -34,7 +35,7 @@ struct ConvParams {
 
 // LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: 1..kConvDmaConfigs, see conv_dma_config().
 struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };
-constexpr int kConvDmaConfigs = 9;
+constexpr int kConvDmaConfigs = 14;
 ConvDmaConfig conv_dma_config(int cfg);
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
 

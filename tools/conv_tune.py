@@ -61,7 +61,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--cfgs', default='0,1,2,3,4,5,6,7,8,9')
+    ap.add_argument('--cfgs', default='0,1,2,3,4,5,6,7,8,9,10,11,12,13,14')
     ap.add_argument('--only', default='')
     ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (> L2 + Infinity Cache = 288): '
                     'every launch then reads operands no XCD has cached, as in the training step, where the producer of a tensor '
