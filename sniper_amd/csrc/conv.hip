@@ -511,7 +511,7 @@ static int conv_dma_choice_cold(int M, int Nout, int nk) {
   return 1;
 }
 
-static int conv_dma_choice_balanced(int M, int Nout, int nk) {
+static int conv_dma_choice_balanced(int M, int Nout, int nk, bool dgrad) {
   // table 3: tools/conv_tune.py --insitu with the 160-row tiles in the candidate set (profiles/r02_conv_tune_insitu_v3.txt).
   // tools/conv_trace.py shows why they win at 20 chips: a K-step's operand delivery is an LDS-DMA issue cost per wave, so a
   // CU wants >= 8 waves in K loops (two 4-wave workgroups) and every CU the same number of tiles -- 20 480 pixels / 160 = 128
@@ -520,22 +520,25 @@ static int conv_dma_choice_balanced(int M, int Nout, int nk) {
   if (t128 >= 3840 && nk >= 8) return 7;              // the long-K data gradients (RPN, deformable GEMM, fc_new_1): 256 x 256
   if (Nout < 128) return nk >= 64 ? 5 : 6;           // narrow heads: one partial column tile
   if (M < 8192) return (Nout >= 1024 && nk >= 128) ? 4 : 6;   // FullyConnected over 6000 RoIs
+  static const int bal = env_int("SNIPER_CONV_BAL", 14), bal_d = env_int("SNIPER_CONV_BAL_D", 16);
   if (nk <= 1) return 6;                              // stage 1: a single K-step, all epilogue
-  return 14;
+  return dgrad ? bal_d : bal;
 }
 
 // SNIPER_CONV_TABLE = 1 | 2 | 3 picks the table; SNIPER_CONV_N128 / _N256 / _N512 / _NBIG override the configuration of a whole
 // output-width class (A/B runs of bench.py: the step itself is the only measurement that includes what precedes each launch).
 static int conv_dma_choice(int M, int Nout, int nk, bool dgrad) {
-  // default: forward layers from the balanced table, data gradients from table 1 -- whole-step A/B on one box
-  // (tools/conv_ab.sh): tables (fwd, dgrad) = (1, 1) 29.44 ms, (3, 3) 29.16 ms, (3, 1) 28.60 ms
-  static const int table_f = env_int("SNIPER_CONV_TABLE", 3), table_d = env_int("SNIPER_CONV_TABLE_DGRAD", table_f == 3 ? 1 : table_f);
+  // default: the balanced table for both directions, 160 x 128 tiles with 4 waves (cfg 14) forward and 8 waves (cfg 16) for the
+  // data gradients -- whole-step A/B on one box each (tools/conv_ab.sh, profiles/r02_ab_balanced_tiles.txt):
+  //   tables (fwd, dgrad) = (1, 1) 29.44 ms, (3, 3) 29.16, (3, 1) 28.60 with cfg 14 everywhere and 8-byte epilogue stores;
+  //   with 16-byte stores: (3, 1) 26.93 ms, (3, 3 / dgrad cfg 16) 26.60, (3, 3 / dgrad cfg 14) 27.59, (3, 3 / dgrad cfg 17) 26.76
+  static const int table_f = env_int("SNIPER_CONV_TABLE", 3), table_d = env_int("SNIPER_CONV_TABLE_DGRAD", table_f);
   const int table = dgrad ? table_d : table_f;
   static const int o128 = env_int("SNIPER_CONV_N128", -1), o256 = env_int("SNIPER_CONV_N256", -1),
                    o512 = env_int("SNIPER_CONV_N512", -1), obig = env_int("SNIPER_CONV_NBIG", -1);
   const int o = Nout <= 128 ? o128 : Nout <= 256 ? o256 : Nout <= 512 ? o512 : obig;
   if (o >= 0) return o;
-  return table == 3 ? conv_dma_choice_balanced(M, Nout, nk) : table == 2 ? conv_dma_choice_cold(M, Nout, nk) : conv_dma_choice_warm(M, Nout, nk);
+  return table == 3 ? conv_dma_choice_balanced(M, Nout, nk, dgrad) : table == 2 ? conv_dma_choice_cold(M, Nout, nk) : conv_dma_choice_warm(M, Nout, nk);
 }
 
 static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {

@@ -54,10 +54,17 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   constexpr int NW = WMW * WNW, T = 64 * NW, BK = 64;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;   // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;
-  constexpr int AGW = BM / 8 / NW, BGW = BN / 8 / NW;   // 8-row DMA groups per wave
+  constexpr int PA = BM / 8, PB = BN / 8;               // 8-row DMA groups (1 KB pieces) of the two operand tiles
+  constexpr int AGW = (PA + NW - 1) / NW, BGW = (PB + NW - 1) / NW;   // ... per wave
   constexpr int L = AGW + BGW;                          // DMA instructions per wave per stage
   constexpr int STAGE = (BM + BN) * BK;                 // half_t elements per stage
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile / wave shape");
+  constexpr bool kPingPong = NW == 8 && S >= 3;         // see the K loop
+  // Every wave issues exactly L pieces per stage (the counted s_waitcnt needs one number): where the groups do not divide
+  // over the waves, a wave without a group of its own in the last round fetches its previous group once more (same
+  // bytes to the same LDS address).
+  static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile / wave shape");
+  static_assert(PA >= NW * (AGW - 1) + 1 && PB >= NW * (BGW - 1) + 1 && (AGW == 1 ? PA >= NW : true) && (BGW == 1 ? PB >= NW : true),
+                "a wave's repeated piece must exist");
   static_assert((S - 1) * L < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE];
 
@@ -79,9 +86,14 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   int a_base[AGW], a_h[AGW], a_w[AGW];
   bool a_ok[AGW];
   const int HoWo = p.Ho * p.Wo;
+  int a_grp[AGW], b_grp[BGW];          // wave-uniform group index of this wave's i-th piece
+#pragma unroll
+  for (int i = 0; i < AGW; ++i) a_grp[i] = (wave + NW * i < PA) ? wave + NW * i : wave + NW * (i - 1);
+#pragma unroll
+  for (int i = 0; i < BGW; ++i) b_grp[i] = (wave + NW * i < PB) ? wave + NW * i : wave + NW * (i - 1);
 #pragma unroll
   for (int i = 0; i < AGW; ++i) {
-    const int m = m0 + 8 * (wave + NW * i) + lrow;
+    const int m = m0 + 8 * a_grp[i] + lrow;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
     const int img = mm / HoWo, rem = mm - img * HoWo;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
     // LDS row r of the weight tile holds output channel n0 + perm(r): fragment pair (2j, 2j+1), MFMA row ii = 4 fq + rr
     // -> channel 32 j + 8 (ii >> 2) + 4 (jn & 1) + (ii & 3), so that a lane's two accumulators of a pair are EIGHT consecutive
     // channels of its pixel (16-byte epilogue loads / stores).  The permutation lives in the DMA source address only.
-    const int r = 8 * (wave + NW * i) + lrow;
+    const int r = 8 * b_grp[i] + lrow;
     const int n = n0 + (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
     w_voff[i] = n < p.Nout ? (unsigned)n * wrow_bytes + (unsigned)gchunk * 16u : kOob;
   }
@@ -128,18 +140,18 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   };
   tap_setup();
   // wave-uniform LDS destinations: stage base + group * 1 KB (the DMA adds 16 B per lane)
-  half_t *const a_dst0 = lds + wave * 512, *const b_dst0 = lds + BM * BK + wave * 512;
+  half_t *const b_lds = lds + BM * BK;
   auto issue = [&](int buf) {
     const unsigned cbo = (unsigned)g_kc * (BK * 2), wbo = (unsigned)g_kt * (BK * 2);   // uniform
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb) + cbo, 0, (int)(p.x_bytes - cbo), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb) + wbo, 0, (int)(p.w_bytes - wbo), 0x00020000);
-    half_t *const sa = a_dst0 + buf * STAGE, *const sb = b_dst0 + buf * STAGE;
+    half_t *const sa = lds + buf * STAGE, *const sb = b_lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AGW; ++i)
-      dma16(rx, sa + i * NW * 512, a_voff[i]);
+      dma16(rx, sa + a_grp[i] * 512, a_voff[i]);
 #pragma unroll
     for (int i = 0; i < BGW; ++i)
-      dma16(rw, sb + i * NW * 512, w_voff[i]);
+      dma16(rw, sb + b_grp[i] * 512, w_voff[i]);
     ++g_kt;
     if (++g_kc == kpt) {
       g_kc = 0;
@@ -211,8 +223,17 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
     wait_vmcnt<(S - 2) * L>();          // stage t has landed (this wave's part); S-2 younger stages stay in flight
     __builtin_amdgcn_s_barrier();       // ... everybody's part has, and everybody is done reading buffer `nxt` (stage t-1)
     if (t == 0) stamp(1);
-    issue(nxt);
-    compute(cur);
+    // A wave's instruction stream is in order: while it issues its DMA pieces (tools/probes/dma_rate_probe.hip: ~70 cycles each
+    // under load) it issues no MFMA, and the barrier puts every wave of the workgroup in the same phase.  With two waves
+    // per SIMD (8-wave workgroups: waves w and w + 4 share a SIMD) the upper half therefore multiplies FIRST and fetches
+    // afterwards: one half's MFMAs run under the other half's DMA issue.  Buffer `nxt` is free for the whole K-step.
+    if (kPingPong && wave >= NW / 2) {
+      compute(cur);
+      issue(nxt);
+    } else {
+      issue(nxt);
+      compute(cur);
+    }
     cur = cur + 1 == S ? 0 : cur + 1;
     nxt = nxt + 1 == S ? 0 : nxt + 1;
   }
@@ -416,6 +437,9 @@ static const ConvDmaConfig kCfg[kConvDmaConfigs + 1] = {
     {192, 128, 256, 3, 3 * 320 * 128},   // 12: 120 KB, wave tile 96 x 64: 6000 RoI rows = 32 row tiles
     {160, 256, 256, 3, 3 * 416 * 128},   // 13: 156 KB, wave tile 80 x 128
     {160, 128, 256, 2, 2 * 288 * 128},   // 14: 72 KB, 2 workgroups / CU
+    {160, 128, 512, 3, 3 * 288 * 128},   // 15: 8 waves (2 x 4), wave tile 80 x 32: twice the waves issuing the tile's DMA pieces
+    {160, 128, 512, 2, 2 * 288 * 128},   // 16: the same, 2 workgroups / CU
+    {80, 128, 256, 2, 2 * 208 * 128},    // 17: 52 KB, 3 workgroups / CU, wave tile 80 x 32 (1 x 4 waves)
 };
 
 ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConfigs) ? kCfg[cfg] : kCfg[0]; }
@@ -436,7 +460,7 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
     case 4: launch_one<DGRAD, 128, 256, 2, 4, 3, 2>(p, s); break;
     case 5: launch_one<DGRAD, 64, 128, 2, 2, 3, 2>(p, s); break;
     case 6: launch_one<DGRAD, 64, 128, 2, 2, 2, 3>(p, s); break;
-    case 7: launch_one<DGRAD, 256, 256, 4, 2, 2, 2>(p, s); break;
+    case 7: launch_one<DGRAD, 256, 256, 4, 2, 2, 1>(p, s); break;
     case 8: launch_one<DGRAD, 128, 128, 4, 2, 3, 2>(p, s); break;
     case 9: launch_one<DGRAD, 128, 128, 2, 2, 4, 1>(p, s); break;
     case 10: launch_one<DGRAD, 160, 128, 2, 2, 3, 1>(p, s); break;
@@ -444,6 +468,9 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
     case 12: launch_one<DGRAD, 192, 128, 2, 2, 3, 1>(p, s); break;
     case 13: launch_one<DGRAD, 160, 256, 2, 2, 3, 1>(p, s); break;
     case 14: launch_one<DGRAD, 160, 128, 2, 2, 2, 2>(p, s); break;
+    case 15: launch_one<DGRAD, 160, 128, 2, 4, 3, 1>(p, s); break;
+    case 16: launch_one<DGRAD, 160, 128, 2, 4, 2, 2>(p, s); break;
+    case 17: launch_one<DGRAD, 80, 128, 1, 4, 2, 3>(p, s); break;
     default: SN_REQUIRE(false, "conv_dma_launch: unknown configuration %d", cfg);
   }
   SN_CHECK_LAUNCH();

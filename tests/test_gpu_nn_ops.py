@@ -132,7 +132,7 @@ def test_conv_dgrad_wgrad(case):
 DMA_CASES = [CONV_CASES[i] for i in (0, 2, 3, 8, 9, 11, 12)]
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 15)))
+@pytest.mark.parametrize('cfg', list(range(1, 18)))
 def test_conv_dma_configurations(cfg, conv_tuning):
     """conv_dma_kernel (csrc/conv_dma.hip): each (tile, waves, ring depth) configuration forced on layers with padding taps,
     stride 2, dilation, ragged M / Cout tiles, bias + residual + ReLU and the scalar epilogue, against torch-CPU fp32."""
