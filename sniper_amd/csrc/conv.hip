@@ -859,6 +859,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   const int cpr = (p.Wo + 31) / 32;  // 32-pixel units per (img, oy) row
   const int nunits = p.N * p.Ho * cpr;
   const int u_begin = split * p.units_per_split, u_end = min(nunits, u_begin + p.units_per_split);
+  // phase stamps of thread 0 (shader clock): [0] entry, [1] first tile in LDS, [2] contraction done, [3] stores drained
+  auto stamp = [&](int k) {
+    if (p.trace && tid == 0)
+      p.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   // loader: rows lr, lr+16 of each unit; 16-byte chunk `chunk` of the 128 channels
   const int lr = tid >> 4, chunk = tid & 15;
@@ -976,6 +982,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   lstore(0, ra0, rb0);
   bool fc = gload(ra0, rb0);               // tile 2 in set 0
   __syncthreads();
+  stamp(1);
   while (it_left > 0) {                    // tiles t (LDS[0]), t+1 (set 1), t+2 (set 0) are real, and so is tile t+3
     lstore(1, ra1, rb1);
     const bool fb_next = gload(ra1, rb1);  // tile t+3
@@ -997,6 +1004,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   if (fb) compute(1);
   __syncthreads();
   if (fc) compute(0);
+  stamp(2);
   // The product was formed transposed (X as the MFMA A operand): lane (fr, fq) holds, for each (i, j), output channel
   // co = ..+fr and 4 consecutive input channels ci = ..+fq*4 .. +3 -> one 16-byte store per (i, j).
   // With K-splits the partial tile goes to this split's slab with plain stores (a split without any valid unit
@@ -1024,6 +1032,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
           if (ci + r < p.Cin) q[r] += acc[i][j][r];
       }
     }
+  }
+  if (p.trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
   }
 }
 
@@ -1144,6 +1156,11 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
   }
   p.units_per_split = q.units_per_split;
   hipStream_t s = sn_stream(stream);
+  static const bool trace_armed = getenv("SNIPER_CONV_TRACE") != nullptr;
+  if (trace_armed) {
+    const char *e = getenv("SNIPER_CONV_TRACE_PTR");
+    if (e && *e) p.trace = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 16));
+  }
   if (q.kind) {
     if (int rc = wgrad_dma_launch(p, q.kind, q.stages, q.splits, s)) return rc;
   } else {

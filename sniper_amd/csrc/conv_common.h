@@ -47,6 +47,7 @@ struct WgradParams {
   int N, H, W, Ho, Wo, Cin, Cout, dy_ps, x_ps;
   int KH, KW, stride, pad, dil;
   int units_per_split;  // 32-pixel K chunks handled per blockIdx.z split
+  unsigned long long *trace = nullptr;   // phase timeline (tools/conv_trace.py --wgrad; SNIPER_CONV_TRACE), normally null
   float *slab;          // split-K partials [split][Cout][taps][Cin] (plain stores, reduced by wgrad_reduce_kernel) or null
   size_t slab_stride;   // elements per split
 };

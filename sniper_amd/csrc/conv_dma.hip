@@ -197,17 +197,21 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   constexpr int NP = NI / 2;
   const bool vec4 = (p.out_ps % 4 == 0) && (p.Nout % 4 == 0) && (!p.res || p.res_ps % 4 == 0);
   const bool vec8 = (p.out_ps % 8 == 0) && (p.Nout % 8 == 0) && (!p.res || p.res_ps % 8 == 0);
-  constexpr bool kPre = MI * NI <= 16;      // 2 VGPRs per fragment; the 256 x 256 tile has none to spare
+  constexpr bool kPre = MI * NI <= 20;      // 2 VGPRs per fragment; the 8-fragment-wide tiles have none to spare
   half8 rpre[kPre ? MI : 1][kPre ? NP : 1];
   const bool pre_res = kPre && p.res != nullptr && vec8;
-  if constexpr (kPre) if (pre_res) {
+  // the BatchNorm input a fused backward reduction reads (sn_conv_dgrad_bn) takes the same slot when there is no residual
+  const bool pre_bnx = kPre && p.res == nullptr && p.bn_x != nullptr && p.stats != nullptr && vec8 && p.bn_x_ps % 8 == 0;
+  if constexpr (kPre) if (pre_res || pre_bnx) {
+    const half_t *src = pre_res ? p.res : p.bn_x;
+    const int src_ps = pre_res ? p.res_ps : p.bn_x_ps;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WTM + i * 16 + (lane & 15);
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         const int n = n0 + wn * WTN + jp * 32 + (lane >> 4) * 8;
-        rpre[i][jp] = (m < p.M && n < p.Nout) ? *reinterpret_cast<const half8 *>(p.res + (size_t)m * p.res_ps + n)
+        rpre[i][jp] = (m < p.M && n < p.Nout) ? *reinterpret_cast<const half8 *>(src + (size_t)m * src_ps + n)
                                               : half8{0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
@@ -285,6 +289,28 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   // tiles, and a rolled loop indexes the accumulators dynamically -> scratch)
   auto epilogue = [&](auto path_tag) {
     constexpr int PATH = decltype(path_tag)::value;
+    // fused BatchNorm-backward reduction, 16-byte path: the per-channel constants of this lane's channels are loaded once per
+    // fragment pair, not once per pixel row (narrow tiles only: 24 VGPRs per pair)
+    constexpr bool kBnHoist = PATH == 0 && NP <= 2;
+    float bsc[kBnHoist ? NP : 1][8], bsh[kBnHoist ? NP : 1][8], bmu[kBnHoist ? NP : 1][8];
+    if constexpr (kBnHoist) {
+      if (p.bn_x && p.stats) {
+  #pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          const int n = n0 + wn * WTN + jp * 32 + fq * 8;
+          if (n < p.Nout) {
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + n + 4 * h), sh = *reinterpret_cast<const float4 *>(p.bn_shift + n + 4 * h);
+              const float4 mu = *reinterpret_cast<const float4 *>(p.bn_mean + n + 4 * h);
+              bsc[jp][4 * h] = sc.x; bsc[jp][4 * h + 1] = sc.y; bsc[jp][4 * h + 2] = sc.z; bsc[jp][4 * h + 3] = sc.w;
+              bsh[jp][4 * h] = sh.x; bsh[jp][4 * h + 1] = sh.y; bsh[jp][4 * h + 2] = sh.z; bsh[jp][4 * h + 3] = sh.w;
+              bmu[jp][4 * h] = mu.x; bmu[jp][4 * h + 1] = mu.y; bmu[jp][4 * h + 2] = mu.z; bmu[jp][4 * h + 3] = mu.w;
+            }
+          }
+        }
+      }
+    }
   #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WTM + i * 16 + fr;
@@ -325,8 +351,27 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
             for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
             *reinterpret_cast<half8 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + n) = o;
             if (p.stats) {
-              stats4(m, n, half4{o[0], o[1], o[2], o[3]}, jp, 0);
-              stats4(m, n + 4, half4{o[4], o[5], o[6], o[7]}, jp, 1);
+              bool done = false;
+              if constexpr (kBnHoist) {
+                if (p.bn_x) {
+                  half8 xv;
+                  if constexpr (kPre) xv = pre_bnx ? rpre[i][jp] : *reinterpret_cast<const half8 *>(p.bn_x + (size_t)m * p.bn_x_ps + n);
+                  else xv = *reinterpret_cast<const half8 *>(p.bn_x + (size_t)m * p.bn_x_ps + n);
+  #pragma unroll
+                  for (int r = 0; r < 8; ++r) {
+                    const float xf = (float)xv[r], yv = xf * bsc[jp][r] + bsh[jp][r];
+                    const bool pass = p.bn_act == 0 || (p.bn_act == 1 ? yv > 0.f : (yv >= 0.f && yv <= 6.f));
+                    const float gf = pass ? (float)o[r] : 0.f;
+                    st_s[jp][r] += gf;
+                    st_q[jp][r] += gf * (xf - bmu[jp][r]);
+                  }
+                  done = true;
+                }
+              }
+              if (!done) {
+                stats4(m, n, half4{o[0], o[1], o[2], o[3]}, jp, 0);
+                stats4(m, n + 4, half4{o[4], o[5], o[6], o[7]}, jp, 1);
+              }
             }
           }
         } else if constexpr (PATH == 1) {   // 8-byte groups, each with its own bound (Nout = 84, ...)

@@ -490,9 +490,10 @@ class ConvolutionStep(_GemmLike):
     def _bn_below(self, acc):
         """The batch-statistics BatchNorm whose (activated) output is this convolution's input and nobody else's: the data
         gradient written here is then its complete dL/dy, and the epilogue can carry the backward reduction.
-        Opt-in (SNIPER_FUSE_BN_BWD=1): measured 1.5 % SLOWER end to end -- the epilogue's 8-byte reads of the BatchNorm input
-        cost the data-gradient kernels more (+1.9 ms per step) than the removed reduction pass saves (1.6 ms), DESIGN.md."""
-        if acc is not None or os.environ.get('SNIPER_FUSE_BN_BWD', '0') != '1' or self.x.fmt != 'act':
+        On by default since the epilogue reads the BatchNorm input 16 bytes per lane, prefetched before the K loop, with the
+        per-channel constants hoisted (27.29 -> 26.98 ms per step, same box; with the earlier 8-byte epilogue it cost 1.5 %).
+        SNIPER_FUSE_BN_BWD=0 restores the separate reduction pass."""
+        if acc is not None or os.environ.get('SNIPER_FUSE_BN_BWD', '1') != '1' or self.x.fmt != 'act':
             return None
         bn = self.x.producer
         if type(bn).__name__ != 'BatchNormStep' or bn.sole_consumer is not self.node or bn.global_stats or bn.is_stem:

@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--cfgs', default='1,6')
     ap.add_argument('--only', default='s3 ')
+    ap.add_argument('--wgrad', action='store_true', help='trace conv_wgrad_tr_kernel (weight gradient) instead')
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(',')]
     d = torch.device('cuda', 0)
@@ -51,12 +52,17 @@ def main():
         reduce_ = K == 1 and s == 1 and C == 4 * O
         res = h(N, Ho, Wo, O) if expand else None
         acc = h(N, H, W, C) if reduce_ else None
-        for direction, cnt in (('fwd', nf), ('dgrad', nd)):
+        dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=d)
+        wsb = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, dl) if a.wgrad else 0
+        wsp = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device=d)
+        for direction, cnt in ((('wgrad', nd),) if a.wgrad else (('fwd', nf), ('dgrad', nd))):
             if cnt == 0:
                 continue
 
             def run():
-                if direction == 'fwd':
+                if direction == 'wgrad':
+                    hip.call('sn_conv_wgrad', dy, x, dw, N, H, W, C, C, O, Op, K, K, s, p, dl, wsp, int(wsb), hip.stream())
+                elif direction == 'fwd':
                     if hip.query('sn_conv_fwd_stats_blocks', N, H, W, C, C, O, O, O if res is not None else 0, K, K, s, p, dl) > 0:
                         hip.call('sn_conv_fwd_stats', x, w, None, res, y, N, H, W, C, C, O, O, O if res is not None else 0, K, K, s, p, dl, 0,
                                  part, hip.stream())
@@ -64,8 +70,8 @@ def main():
                         hip.call('sn_conv_fwd', x, w, None, None, y, N, H, W, C, C, O, O, O, K, K, s, p, dl, 0, 0, hip.stream())
                 else:
                     hip.call('sn_conv_dgrad', dy, wt, acc, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
-            for c in cfgs:
-                hip.call('sn_conv_tune', c)
+            for c in ([0] if a.wgrad else cfgs):
+                hip.call('sn_conv_tune', -1 if a.wgrad else c)
                 os.environ['SNIPER_CONV_TRACE_PTR'] = ''
                 for _ in range(2):
                     run()
@@ -84,24 +90,19 @@ def main():
                     os.environ['SNIPER_CONV_TRACE_PTR'] = ''
                     t = trace.cpu().numpy().reshape(-1, 8)
                     t = t[t[:, 0] > 0][:, :5].astype(np.float64)
+                    if a.wgrad:
+                        t[:, 4] = t[:, 3]
                     if not len(t):
                         print('%-26s %-5s cfg %d: no stamps (register-staged kernel chosen)' % (name, direction, c))
                         continue
-                    t0 = t[:, 0].min()
-                    span = t[:, 4].max() - t0
+                    # (the shader clocks of different XCDs are not synchronised: only differences inside one workgroup mean anything)
                     ph = np.diff(t, axis=1)          # entry->first stage, K loop, stores drained, stats/exit
                     life = t[:, 4] - t[:, 0]
-                    # how many workgroups are alive over the launch, sampled at 200 points
-                    grid = np.linspace(t0, t[:, 4].max(), 200)
-                    alive = ((t[:, 0][None, :] <= grid[:, None]) & (t[:, 4][None, :] > grid[:, None])).sum(1)
-                    in_loop = ((t[:, 1][None, :] <= grid[:, None]) & (t[:, 2][None, :] > grid[:, None])).sum(1)
-                    starts = np.sort(t[:, 0] - t0)
-                    print('%-26s %-5s cfg %d %s: %4d WGs, event %.1f us, span %.0f cyc | per WG (median cyc): fill %5.0f  kloop %5.0f  '
-                          'stores %5.0f  tail %5.0f  life %5.0f | alive avg %.0f  in-K-loop avg %.0f | start wave at cyc %s' % (
-                              name, direction, c, 'warm' if warm else 'cold', len(t), e0.elapsed_time(e1) * 1e3, span,
+                    print('%-26s %-5s cfg %2d %s: %4d WGs, event %5.1f us | per WG (median cyc): fill %5.0f  kloop %5.0f  stores %5.0f  '
+                          'tail %5.0f  life %6.0f (p90 %6.0f)' % (
+                              name, direction, c, 'warm' if warm else 'cold', len(t), e0.elapsed_time(e1) * 1e3,
                               np.median(ph[:, 0]), np.median(ph[:, 1]), np.median(ph[:, 2]), np.median(ph[:, 3]), np.median(life),
-                              alive.mean(), in_loop.mean(),
-                              [int(starts[int(q * (len(starts) - 1))]) for q in (0.25, 0.5, 0.75, 1.0)]), flush=True)
+                              np.percentile(life, 90)), flush=True)
             hip.call('sn_conv_tune', -1)
 
 
