@@ -244,11 +244,12 @@ def _cpu_image_chips(i):
     return len(crops)
 
 
-def bench_inference(passes=2):
+def bench_inference(passes=4):
     """BASELINE config C5: ResNet-101 AutoFocus inference, 3-scale coarse-to-fine FocusChip pyramid
     ((480,512) -> (800,1280) -> (1400,2000), batches of 8 / 8 / 2), 8 synthetic 640x480 images, random-init weights.
     One pass = GPU image preparation + forward + box decoding + FocusChips + multi-scale soft-NMS aggregation.
-    Throughput of the last pass (bound executors cached per batch shape, like a resident service)."""
+    Throughput of the last pass (bound executors cached per batch shape and replaying their captured forward, like a resident
+    service: pass 1 binds, pass 2 captures, passes 3.. replay)."""
     import sniper_amd.mx as mx
     from sniper_amd import config as cfgmod
     from sniper_amd.inference import imdb_detection_wrapper

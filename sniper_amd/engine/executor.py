@@ -144,6 +144,11 @@ class Executor(object):
         self.use_graphs = (for_training and os.environ.get('SNIPER_HIP_GRAPHS', '1') != '0' and
                            not any(type(st).__name__ == 'CustomStep' for st in self.steps))
         self.graph_warmup = 2
+        # Inference executors (one per input shape, kept by the Module) replay a captured forward from their third call on:
+        # an eager test-time forward is ~250 launches per batch from Python, host-bound at the finer AutoFocus scales.
+        self.use_infer_graphs = (not for_training and os.environ.get('SNIPER_HIP_GRAPHS', '1') != '0' and
+                                 not any(type(st).__name__ == 'CustomStep' for st in self.steps))
+        self._infer_graph, self._infer_calls = None, 0
         # Weight gradients run on a second HIP stream, concurrently with the data-gradient chain: both consume the same
         # dY, the weight gradient is needed only by the optimizer, and most R101 layers have too few tiles to fill 256
         # CUs on their own (a 3x3 256->256 weight gradient is 36 tiles before K-splitting).
@@ -587,6 +592,24 @@ class Executor(object):
         is_train = self.for_training if is_train is None else is_train
         self.is_train = is_train
         self.load_inputs(inputs)
+        if self.use_infer_graphs and not is_train and self.device.type == 'cuda':
+            if self._infer_graph is not None:
+                self._infer_graph.replay()
+                return self.outputs
+            self._infer_calls += 1
+            if self._infer_calls > 1:            # the first call ran eagerly: lazy allocations, parameter packing
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        self._forward_body()
+                    g.replay()
+                    self._infer_graph = g
+                    return self.outputs
+                except Exception as e:   # noqa: BLE001 -- a capture failure means "keep running eagerly"
+                    warnings.warn('sniper_amd: hipGraph capture of the inference forward failed (%r); running eagerly' % (e,))
+                    self.use_infer_graphs = False
+                    torch.cuda.synchronize()
         self._forward_body()
         return self.outputs
 

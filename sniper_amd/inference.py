@@ -78,6 +78,69 @@ def _valid_range_filter(cls_dets, valid_range):
     return cls_dets[ok, :]
 
 
+def threshold_detections(cscores, cboxes, cls_thresh, num_classes):
+    """Tester.get_detections' score threshold for every class of one chip (lib/inference.py:289-295): list over classes
+    1..num_classes-1 of `hstack(cboxes[inds, 0:4], cscores[inds, j, None])`, inds = where(cscores[:, j] > cls_thresh) -- one mask,
+    one gather and one split instead of a where / hstack pair per class."""
+    mask = (cscores[:, 1:num_classes] > cls_thresh).T            # (classes, RoIs): nonzero() walks a class's RoIs in order
+    cls_idx, roi_idx = np.nonzero(mask)
+    dets = np.hstack((cboxes[roi_idx, 0:4], cscores[roi_idx, cls_idx + 1, np.newaxis]))
+    return np.split(dets, np.cumsum(mask.sum(1))[:-1])
+
+
+def prune_chip_border(per_class, crop, im_width, im_height):
+    """AutoFocus pruning of one chip's detections (lib/inference.py:336-353): translate every class's rows into image coordinates
+    and drop those within 10 px of a chip border that is not an image border (`check_valid`, :236-259).  All classes in one
+    float64 array, one mask; returns the list over classes of (n, 5) float64 arrays."""
+    nc = len(per_class)
+    arrs = [np.asarray(a, np.float64).reshape(-1, 5) for a in per_class]
+    lens = np.fromiter((a.shape[0] for a in arrs), np.int64, nc)
+    big = np.concatenate(arrs)                  # a copy: the inputs keep their chip coordinates
+    big[:, 0] += crop[0]; big[:, 2] += crop[0]
+    big[:, 1] += crop[1]; big[:, 3] += crop[1]
+    ok = Tester._valid_mask(big, crop, im_width, im_height)
+    cls_id = np.repeat(np.arange(nc), lens)
+    kept = np.bincount(cls_id[ok], minlength=nc)
+    return np.split(big[ok], np.cumsum(kept)[:-1])
+
+
+def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes):
+    """The per (image, class) NMS problems of Tester.aggregate (lib/inference.py:170-190): for image i and class j the rows of
+    every scale's every chip that pass that scale's valid range, in (scale, chip, row) order.  Built per image with a handful
+    of array operations (one concatenation, one area mask, one stable sort by class) instead of classes x scales x chips
+    Python iterations; returns the problems in (image, class) order, float32 (n, 5)."""
+    nc = num_classes - 1
+    problems = []
+    for i in range(num_images):
+        parts, cls_ids, oks = [], [], []
+        for all_cls_dets, vr in zip(scale_cls_dets, valid_ranges):
+            for c in range(len(all_cls_dets[1][i])):
+                arrs = [np.asarray(all_cls_dets[j][i][c], np.float32).reshape(-1, 5) for j in range(1, num_classes)]
+                lens = np.fromiter((a.shape[0] for a in arrs), np.int64, nc)
+                if lens.sum() == 0:
+                    continue
+                big = np.concatenate(arrs)
+                areas = (big[:, 3] - big[:, 1]) * (big[:, 2] - big[:, 0])      # float32 products, as _valid_range_filter
+                ok = np.ones(len(big), bool)
+                if vr[0] > 0:
+                    ok &= areas > vr[0] * vr[0]
+                if vr[1] > 0:
+                    ok &= areas <= vr[1] * vr[1]
+                parts.append(big)
+                cls_ids.append(np.repeat(np.arange(nc), lens))
+                oks.append(ok)
+        if not parts:
+            problems.extend(np.empty((0, 5), np.float32) for _ in range(nc))
+            continue
+        big, cid, ok = np.concatenate(parts), np.concatenate(cls_ids), np.concatenate(oks)
+        big, cid = big[ok], cid[ok]
+        order = np.argsort(cid, kind='stable')          # rows of a class stay in (scale, chip, row) order
+        big = big[order]
+        cuts = np.cumsum(np.bincount(cid, minlength=nc))[:-1]
+        problems.extend(np.split(big, cuts))
+    return problems
+
+
 class Tester(object):
     def __init__(self, module, imdb, roidb, test_iter, cfg, rcnn_output_names=None, rpn_output_names=None, logger=None,
                  batch_size=None):
@@ -170,16 +233,7 @@ class Tester(object):
         n_scales = len(scale_cls_dets)
         assert n_scales == len(self.cfg.TEST.VALID_RANGES), 'A valid range should be specified for each test scale'
         all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
-        problems = []
-        for i in range(self.num_images):
-            for j in range(1, self.num_classes):
-                agg = [np.empty((0, 5), np.float32)]
-                for all_cls_dets, valid_range in zip(scale_cls_dets, self.cfg.TEST.VALID_RANGES):
-                    for c in range(len(all_cls_dets[j][i])):
-                        cls_dets = _valid_range_filter(np.asarray(all_cls_dets[j][i][c], np.float32).reshape(-1, 5), valid_range)
-                        if cls_dets.shape[0] > 0:
-                            agg.append(cls_dets)
-                problems.append(np.vstack(agg))
+        problems = aggregate_problems(scale_cls_dets, self.cfg.TEST.VALID_RANGES, self.num_images, self.num_classes)
         final = self.nms_worker.worker_many(problems)          # one batched launch instead of Pool(32).map
         k = 0
         for i in range(self.num_images):
@@ -211,6 +265,20 @@ class Tester(object):
             return False
         return True
 
+    @staticmethod
+    def _valid_mask(dets, chip, im_width, im_height, delta=10):
+        """_check_valid over the rows of `dets` at once (same comparisons, same float64 arithmetic)."""
+        ok = np.ones(len(dets), bool)
+        if chip[0] >= 0.5:
+            ok &= ~(np.abs(dets[:, 0] - chip[0]) < delta)
+        if chip[1] >= 0.5:
+            ok &= ~(np.abs(dets[:, 1] - chip[1]) < delta)
+        if chip[2] < im_width - 0.5:
+            ok &= ~(np.abs(dets[:, 2] - chip[2]) < delta)
+        if chip[3] < im_height - 0.5:
+            ok &= ~(np.abs(dets[:, 3] - chip[3]) < delta)
+        return ok
+
     def get_detections(self, cls_thresh=1e-3, cache_name='cache', evaluate=False, vis=False, vis_path=None, do_pruning=False,
                        autofocus=False, vis_ext='.png'):
         n_chips = [len(r['inference_crops']) for r in self.roidb]
@@ -224,13 +292,13 @@ class Tester(object):
             for i, (cscores, cboxes, im_id, chip_id) in enumerate(zip(scores, boxes, im_ids, chip_ids)):
                 if autofocus:
                     all_maps[im_id][chip_id] = maps[i]
+                # all classes at once: rows grouped by class, RoIs ascending inside a class (= np.where per class, :290-295)
+                per_class = threshold_detections(cscores, cboxes, cls_thresh, self.num_classes)
                 for j in range(1, self.num_classes):
-                    inds = np.where(cscores[:, j] > cls_thresh)[0]
-                    cls_dets = np.hstack((cboxes[inds, 0:4], cscores[inds, j, np.newaxis]))
                     if evaluate:
-                        todo.append((j, im_id, chip_id, cls_dets))
+                        todo.append((j, im_id, chip_id, per_class[j - 1]))
                     else:
-                        all_boxes[j][im_id][chip_id] = cls_dets
+                        all_boxes[j][im_id][chip_id] = per_class[j - 1]
             if evaluate:
                 final = self.nms_worker.worker_many([t[3] for t in todo])
                 for (j, im_id, chip_id, _), d in zip(todo, final):
@@ -246,13 +314,10 @@ class Tester(object):
             if do_pruning:     # project the boxes back to image coordinates, drop those cut by a chip border (:336-353)
                 for im_id, chip_id in set(zip(im_ids.tolist(), chip_ids.tolist())):
                     crop = self.roidb[im_id]['inference_crops'][chip_id]
-                    for j in range(1, self.num_classes):
-                        cls_dets = np.array(all_boxes[j][im_id][chip_id], dtype=np.float64).reshape(-1, 5)
-                        cls_dets[:, 0] += crop[0]; cls_dets[:, 2] += crop[0]
-                        cls_dets[:, 1] += crop[1]; cls_dets[:, 3] += crop[1]
-                        ok = [self._check_valid(d, crop, self.roidb[im_id]['width'], self.roidb[im_id]['height']) for d in cls_dets]
-                        cls_dets = cls_dets[np.array(ok, bool)] if len(ok) else cls_dets
-                        all_boxes[j][im_id][chip_id] = cls_dets if cls_dets.shape[0] > 0 else np.zeros((0, 5))
+                    pruned = prune_chip_border([all_boxes[j][im_id][chip_id] for j in range(1, self.num_classes)], crop,
+                                               self.roidb[im_id]['width'], self.roidb[im_id]['height'])
+                    for j, d in enumerate(pruned):
+                        all_boxes[j + 1][im_id][chip_id] = d
         return all_boxes, all_maps
 
     def extract_proposals(self, n_proposals=300, cache_name='cache', vis=False, vis_ext='.png'):

@@ -105,6 +105,8 @@ class Module(object):
         dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', self.contexts[0].device_id)) % torch.cuda.device_count()
                            if self.world > 1 else self.contexts[0].device_id)
         torch.cuda.set_device(dev)
+        from .. import hip
+        hip.use_device(dev.index)
         self._device = dev
         self._exes = {}          # test-time batches change shape (scale, chip size): one bound executor per input shape
         self.exe = self._exe_for(shapes)

@@ -40,3 +40,98 @@ def test_gmask_chips():
     m[10, 10] = m[10, 14] = 1.0
     chips = gmask(m, 1, 0.5, ms=8, im_width=640, im_height=480, cscale=1.0)
     assert len(chips) == 1 and chips[0][0] <= 10 * 16 - 3 * 16 and chips[0][2] >= 15 * 16
+
+
+def test_border_pruning_mask_equals_the_per_detection_rule():
+    """Tester.get_detections' AutoFocus pruning (lib/inference.py:236-259 `check_valid`, applied per detection at :336-353):
+    the vectorised mask keeps exactly the detections the per-detection rule keeps -- chips at every image border, boxes on,
+    next to and far from each chip border."""
+    from sniper_amd.inference import Tester
+    rs = np.random.RandomState(4)
+    W, H = 640, 480
+    for chip in ([0, 0, 640, 480], [0.4, 0.6, 639.4, 479.6], [100, 50, 400, 300], [0, 120, 320, 480], [320, 0, 640.0, 240]):
+        chip = np.asarray(chip, np.float64)
+        base = rs.uniform(0, 1, (400, 4)) * [W, H, W, H]
+        # snap a third of the coordinates onto / next to the chip borders (the rule's |d - c| < 10 boundary included)
+        for k in range(4):
+            sel = rs.rand(400) < 0.35
+            base[sel, k] = chip[k] + rs.choice([-10.0, -9.999, -3, 0, 3, 9.999, 10.0, 10.001], sel.sum())
+        dets = np.hstack((base, rs.rand(400, 1)))
+        want = np.array([Tester._check_valid(d, chip, W, H) for d in dets], bool)
+        got = Tester._valid_mask(dets, chip, W, H)
+        assert got.dtype == bool and np.array_equal(got, want)
+        if chip[0] < 0.5 and chip[1] < 0.5 and chip[2] >= W - 0.5 and chip[3] >= H - 0.5:
+            assert want.all()                   # a chip that is the whole image prunes nothing
+        else:
+            assert 0 < want.sum() < len(want)
+    assert Tester._valid_mask(np.zeros((0, 5)), [0, 0, 10, 10], W, H).shape == (0,)
+
+
+def _loop_threshold(cscores, cboxes, thresh, num_classes):
+    """lib/inference.py:289-295 as written there"""
+    out = []
+    for j in range(1, num_classes):
+        inds = np.where(cscores[:, j] > thresh)[0]
+        out.append(np.hstack((cboxes[inds, 0:4], cscores[inds, j, np.newaxis])))
+    return out
+
+
+def _loop_aggregate(scale_cls_dets, valid_ranges, num_images, num_classes):
+    """lib/inference.py:170-190 as written there"""
+    from sniper_amd.inference import _valid_range_filter
+    problems = []
+    for i in range(num_images):
+        for j in range(1, num_classes):
+            agg = [np.empty((0, 5), np.float32)]
+            for all_cls_dets, vr in zip(scale_cls_dets, valid_ranges):
+                for c in range(len(all_cls_dets[j][i])):
+                    d = _valid_range_filter(np.asarray(all_cls_dets[j][i][c], np.float32).reshape(-1, 5), vr)
+                    if d.shape[0] > 0:
+                        agg.append(d)
+            problems.append(np.vstack(agg))
+    return problems
+
+
+def test_vectorised_post_processing_equals_the_reference_loops():
+    """Tester.get_detections / aggregate host work (score threshold per class, chip-border pruning, valid-range merge into the
+    per (image, class) NMS problems): the array formulations return exactly what the reference's nested loops return -- same
+    rows, same order, same dtypes -- including empty classes, empty chips and chips without any detection."""
+    from sniper_amd.inference import Tester, aggregate_problems, prune_chip_border, threshold_detections
+    rs = np.random.RandomState(11)
+    NC, R = 9, 60
+    for dtype in (np.float32, np.float64):
+        cscores = rs.rand(R, NC).astype(np.float32) ** 6          # most scores under the threshold
+        cscores[:, 3] = 0                                           # an empty class
+        cboxes = (rs.rand(R, 4) * 300).astype(dtype)
+        got, want = threshold_detections(cscores, cboxes, 0.05, NC), _loop_threshold(cscores, cboxes, 0.05, NC)
+        assert len(got) == len(want) == NC - 1
+        for g, w in zip(got, want):
+            assert g.dtype == w.dtype and g.shape == w.shape and np.array_equal(g, w)
+        assert got[2].shape == (0, 5) and sum(len(g) for g in got) > 0
+    # pruning: per class float64 rows in image coordinates
+    crop = np.array([100.0, 40.0, 420.0, 300.0])
+    per_class = [np.hstack((np.sort(rs.rand(n, 4) * 320, axis=1)[:, [0, 1, 2, 3]], rs.rand(n, 1))).astype(np.float32)
+                 for n in (0, 25, 3, 0, 40, 1, 0, 12)]
+    per_class[1][:5, 0] = 4.0                                       # next to the chip's left border -> pruned
+    got = prune_chip_border(per_class, crop, 640, 480)
+    for a, g in zip(per_class, got):
+        d = np.array(a, dtype=np.float64).reshape(-1, 5)
+        d[:, 0] += crop[0]; d[:, 2] += crop[0]; d[:, 1] += crop[1]; d[:, 3] += crop[1]
+        keep = np.array([Tester._check_valid(r, crop, 640, 480) for r in d], bool) if len(d) else np.zeros(0, bool)
+        assert g.dtype == np.float64 and np.array_equal(g, d[keep].reshape(-1, 5))
+    assert len(got[1]) <= 20
+    # aggregation over 3 scales, 3 images with 1 / 2 / 0..3 chips
+    n_img = 3
+    scales = []
+    for s_i in range(3):
+        chips_per_image = [1, 2, s_i]
+        scales.append([[[np.hstack((np.sort(rs.rand(n, 4) * 400, axis=1), rs.rand(n, 1))).astype(np.float64 if s_i else np.float32)
+                         for n in rs.randint(0, 6, chips_per_image[i])] for i in range(n_img)] for _ in range(NC)])
+    for sc in scales:                                              # a class without detections anywhere
+        sc[4] = [[np.zeros((0, 5), np.float32) for _ in chips] for chips in sc[4]]
+    vr = ((-1, 90), (32, 180), (75, -1))
+    got, want = aggregate_problems(scales, vr, n_img, NC), _loop_aggregate(scales, vr, n_img, NC)
+    assert len(got) == len(want) == n_img * (NC - 1)
+    for g, w in zip(got, want):
+        assert g.dtype == np.float32 and g.shape == w.shape and np.array_equal(g, w)
+    assert sum(len(g) for g in got) > 0 and any(len(g) == 0 for g in got)

@@ -161,3 +161,68 @@ def test_autofocus_pipeline_end_to_end():
     many = w.worker_many([p.copy() for p in probs])
     for p, m in zip(probs, many):
         assert np.array_equal(m, w.worker(p.copy()))
+
+
+def test_inference_forward_graph_replay_equals_eager():
+    """A bound test-time executor runs eagerly once, captures its forward on the second call and replays it from then on
+    (sniper_amd/engine/executor.py): every output of the replayed graph equals the eager forward of a second Module on the same
+    inputs bit for bit, for fresh inputs on every call."""
+    import os
+    import sniper_amd.mx as mx
+    from sniper_amd import config as cfgmod
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 600, 100
+    shapes = [('data', (2, 3, 192, 256)), ('im_info', (2, 3)), ('im_ids', (2,)), ('chip_ids', (2,))]
+
+    def module():
+        net = rn.resnet_mx_101_e2e(n_proposals=400, test_nbatch=2)
+        sym = net.get_symbol_rcnn(cfg, is_train=False)
+        net.infer_shape(dict(shapes))
+        mod = mx.mod.Module(symbol=sym, context=[mx.gpu(0)], data_names=[k for k, _ in shapes], label_names=None)
+        mod.bind(shapes, None, for_training=False)
+        return net, mod
+    net, graphed = module()
+    rs = np.random.RandomState(7)
+    arg = {}
+    for k, s in net.arg_shape_dict.items():          # MSRA weights, damped residual branches: activations stay inside fp16
+        if k in dict(shapes):
+            continue
+        if k.endswith('_gamma'):
+            v = np.full(s, 0.3 if k.endswith('_bn3_gamma') else 1.0, np.float32)
+        elif k.endswith('_weight') and len(s) > 1:
+            v = (rs.standard_normal(s) * np.sqrt(2.0 / float(np.prod(s[1:])))).astype(np.float32)
+        else:
+            v = (rs.standard_normal(s) * 0.01).astype(np.float32)
+        arg[k] = mx.nd.array(v)
+    aux = {k: mx.nd.array(np.full(s, 1600.0 if k == 'bn_data_moving_var' else 1.0, np.float32) if k.endswith('_var')
+                          else np.zeros(s, np.float32)) for k, s in net.aux_shape_dict.items()}
+    graphed.init_params(arg_params=arg, aux_params=aux)
+    old = os.environ.get('SNIPER_HIP_GRAPHS')
+    os.environ['SNIPER_HIP_GRAPHS'] = '0'
+    try:
+        _, eager = module()
+        eager.init_params(arg_params=arg, aux_params=aux)
+    finally:
+        if old is None:
+            del os.environ['SNIPER_HIP_GRAPHS']
+        else:
+            os.environ['SNIPER_HIP_GRAPHS'] = old
+    modes = []
+    for call in range(4):
+        data = [mx.nd.array((rs.standard_normal((2, 3, 192, 256)) * 40).astype(np.float32)),
+                mx.nd.array(np.array([[192, 256, 1.0], [180, 256, 0.9]], np.float32)), mx.nd.array(np.array([call, call + 1], np.float32)),
+                mx.nd.array(np.zeros(2, np.float32))]
+        batch = mx.io.DataBatch(data=data, label=None, pad=0, index=None, provide_data=shapes, provide_label=None)
+        graphed.forward(batch, is_train=False)
+        a = [o.asnumpy() for o in graphed.get_outputs()]
+        eager.forward(batch, is_train=False)
+        b = [o.asnumpy() for o in eager.get_outputs()]
+        exe = next(iter(graphed._exes.values()))
+        modes.append(exe._infer_graph is not None)
+        assert len(a) == len(b) >= 6
+        for name, x, y in zip(graphed.output_names, a, b):
+            assert np.array_equal(x, y), (call, name, float(np.abs(x - y).max()))
+        assert np.isfinite(a[1]).all()
+    assert modes == [False, True, True, True]
+    assert next(iter(eager._exes.values()))._infer_graph is None

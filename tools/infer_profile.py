@@ -1,0 +1,48 @@
+"""Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
+cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
+
+    python tools/infer_profile.py [n_top]
+"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import sniper_amd.mx as mx
+    from sniper_amd import config as cfgmod
+    from sniper_amd.inference import imdb_detection_wrapper
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+
+    class Imdb(object):
+        num_classes, classes, name, result_path = 81, None, 'synthetic', None
+    rs = np.random.RandomState(0)
+    base = [{'image': rs.randint(0, 256, (480, 640, 3)).astype(np.uint8), 'width': 640, 'height': 480, 'flipped': False,
+             'gt_overlaps': np.zeros((1, 81), np.float32)} for _ in range(8)]
+    cfg = cfgmod.res101_e2e_autofocus()
+    cache = {}
+    for p in range(5):
+        roidb = [dict(r) for r in base]
+        torch.cuda.synchronize()
+        pr = cProfile.Profile() if p == 4 else None
+        t0 = time.perf_counter()
+        if pr:
+            pr.enable()
+        imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache)
+        torch.cuda.synchronize()
+        if pr:
+            pr.disable()
+        print('pass %d: %.1f ms' % (p, (time.perf_counter() - t0) * 1e3), flush=True)
+    st = pstats.Stats(pr)
+    st.sort_stats('cumulative').print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
+
+
+if __name__ == '__main__':
+    main()
