@@ -52,7 +52,7 @@ def conv_flops(name, a):
     """Algorithmic FLOPs of one conv-family launch from its C-ABI arguments."""
     if name in ('sn_conv_fwd', 'sn_conv_fwd_stats'):
         N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[5:18]
-    elif name == 'sn_conv_dgrad':
+    elif name in ('sn_conv_dgrad', 'sn_conv_dgrad_bn'):      # (the fused BatchNorm-backward variant has the same leading arguments)
         N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[4:17]
     elif name == 'sn_conv_wgrad':
         N, H, W, Cin, _, Cout, _, KH, KW, s, p, d = a[3:15]
@@ -69,7 +69,7 @@ def conv_flops(name, a):
 class ConvProfiler(object):
     """Wraps sniper_amd.hip.call: brackets every conv-family launch with HIP events recorded on the
     stream the kernel is launched on (torch's current stream)."""
-    NAMES = ('sn_conv_fwd', 'sn_conv_fwd_stats', 'sn_conv_dgrad', 'sn_conv_wgrad', 'sn_conv_stem_fwd')
+    NAMES = ('sn_conv_fwd', 'sn_conv_fwd_stats', 'sn_conv_dgrad', 'sn_conv_dgrad_bn', 'sn_conv_wgrad', 'sn_conv_stem_fwd')
 
     def __init__(self):
         from sniper_amd import hip
@@ -279,8 +279,8 @@ def bench_inference(passes=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=20, help='chips per GPU (BASELINE C2: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--inference', action='store_true', help='(default on rank 0 at N = 1; kept for old command lines)')
@@ -377,7 +377,7 @@ def main():
     n_launch = sum(v[0] for v in per.values())
     roof = {'bound': 'mfma',
             'kernel': 'conv_dma_kernel<DGRAD,BM,BN,...> / conv_igemm_p2_kernel / conv_wgrad_tr_kernel / wgrad_{flat,taps}_dma_kernel '
-                      '(+ conv_igemm_kernel for narrow layers, wgrad_reduce_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_wgrad',
+                      '(+ conv_igemm_kernel for narrow layers, wgrad_reduce_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_dgrad_bn, sn_conv_wgrad',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
             'mode': 'in situ (eager replay of the timed step, weight gradients on the side stream: %s); sum of launch durations as '
                     'rocprofv3 --kernel-trace --stats reports them' % bool(side),

@@ -21,7 +21,7 @@ micro)
   echo "microbench exit $?" >> gpurun_out/microbench.log
   tail -20 gpurun_out/microbench.log ;;
 bench)
-  timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2>&1
+  timeout 1200 python bench.py > gpurun_out/bench.log 2>&1
   echo "bench exit $?" >> gpurun_out/bench.log
   tail -2 gpurun_out/bench.log ;;
 prof)
