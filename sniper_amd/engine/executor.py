@@ -281,6 +281,7 @@ class Executor(object):
                 cons.setdefault((id(n), i), []).append(node)
         heads = set((id(n), i) for n, i in self.sym._heads)
         self.consumers = cons
+        self.head_keys = heads       # graph outputs: read by the caller, not by a node
         var_is_param = set(self.param_names) | set(self.aux_names)
         # static format analysis: 'act' (fp16 channels-last) vs 'f32' (reference order)
         binary = ('_plus', '_minus', '_mul', 'elemwise_add')

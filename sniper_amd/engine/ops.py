@@ -110,9 +110,23 @@ class BatchNormStep(Step):
         self.act = 1 if self.relu else 0      # fused activation code of the BN kernels: 0 none, 1 ReLU, 2 ReLU6
         if not self.is_stem and len(cons) == 1 and _is_relu6(cons[0]):
             self.act = 2
+        # Test-time graphs: a BatchNorm that is the only reader of a convolution's output is a per-channel affine map (+ ReLU) of
+        # it -- the convolution applies it itself (weights scaled by `scale`, bias = `shift`, ReLU in its epilogue) and this
+        # step's output IS the convolution's output tensor: no separate pass over the activation (12 % of the AutoFocus pass).
+        self.folded_into = None
+        prod = None if self.is_stem else self.x.producer
+        if (not ex.for_training and prod is not None and type(prod).__name__ == 'ConvolutionStep' and self.x.fmt == 'act'
+                and self.act in (0, 1) and not prod.is_stem and not prod.depthwise and not prod.out_f32
+                and len(ex.consumers.get((id(prod.node), 0), [])) == 1 and (id(prod.node), 0) not in ex.head_keys
+                and os.environ.get('SNIPER_INFER_FOLD_BN', '1') != '0'):
+            self.folded_into = prod
+            prod.fold_bn = self
         if self.is_stem:
             self.y = self.new_out('f32', alloc=False)
             self.y.stem = (self.x, self.scale, self.shift)
+        elif self.folded_into is not None:
+            self.y = self.new_out('act', alloc=False)
+            self.y.t = self.x.t
         else:
             self.y = self.new_out('act')
         self.y.needs_grad = ex.for_training and (self.x.needs_grad or self.gamma.trainable or self.beta.trainable) \
@@ -148,12 +162,21 @@ class BatchNormStep(Step):
                 hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
                          self.shift, hip.stream())
                 self._global_ready = True
+        if self.folded_into is not None:
+            if not self.global_stats:        # (a test-time executor normalises with the moving statistics whatever the flag says)
+                g = None if self.fix_gamma else self.gamma.master
+                hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
+                         self.shift, hip.stream())
+                self._global_ready = True
+            self.folded_into.refold(self.scale, self.shift)
 
     def _use_batch_stats(self):
         return self.ex.is_train and not self.global_stats
 
     def forward(self):
         ex = self.ex
+        if self.folded_into is not None:
+            return                       # the producing convolution wrote act(scale * conv + shift) into the shared tensor
         g = None if self.fix_gamma else self.gamma.master
         if not self._use_batch_stats():
             if not self._global_ready:
@@ -332,6 +355,18 @@ class _GemmLike(Step):
         if self.out_f32 and self.Ho * self.Wo > 1:
             self.tmp_nhwc32 = ex.empty((self.N, self.Ho, self.Wo, self.O), F32)
 
+    def refold(self, scale, shift):
+        """Test-time fold of the BatchNorm that alone reads this convolution (BatchNormStep.setup): w' = scale[o] * w (from the
+        fp32 master, one rounding to fp16), b' = scale * b + shift, into persistent buffers (a captured forward keeps their
+        addresses)."""
+        w = self.w.master.view(self.O, -1) * scale.view(-1, 1)
+        b = shift if self.b is None else self.b.master * scale + shift
+        if getattr(self, 'wf', None) is None:
+            self.wf, self.bf = w.to(F16).view_as(self.w.w16).contiguous(), b.to(F32).contiguous().clone()
+        else:
+            self.wf.copy_(w.view_as(self.wf))
+            self.bf.copy_(b)
+
     def forward(self):
         ex = self.ex
         x = self.x_tensor()
@@ -462,6 +497,13 @@ class ConvolutionStep(_GemmLike):
             hip.call('sn_conv_fwd_stats', x, self.w.w16, bias, None if res is None else res.t, dst, self.N, self.H, self.W, self.C,
                      self.C, self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0,
                      self.stats_buf, hip.stream())
+            return
+        fold = getattr(self, 'fold_bn', None)
+        if fold is not None:     # test-time: the BatchNorm (+ ReLU) reading this output is part of the epilogue (refold)
+            if getattr(self, 'wf', None) is None:
+                raise RuntimeError('%s: folded BatchNorm weights missing (parameters were never set)' % self.node.name)
+            hip.call('sn_conv_fwd', x, self.wf, self.bf, None, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0,
+                     self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 1 if fold.act == 1 else 0, 0, hip.stream())
             return
         hip.call('sn_conv_fwd', x, self.w.w16, bias, None if res is None else res.t, dst, self.N, self.H, self.W, self.C, self.C,
                  self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0,

@@ -226,3 +226,78 @@ def test_inference_forward_graph_replay_equals_eager():
         assert np.isfinite(a[1]).all()
     assert modes == [False, True, True, True]
     assert next(iter(eager._exes.values()))._infer_graph is None
+
+
+def test_inference_batchnorm_folds_into_the_producing_convolution():
+    """Test-time executors let a convolution apply the BatchNorm (+ ReLU) that alone reads its output (scaled weights, shift as
+    bias, ReLU in the epilogue; sniper_amd/engine/ops.py BatchNormStep.setup / ConvolutionStep.refold).  Same outputs as the
+    unfolded graph (SNIPER_INFER_FOLD_BN=0) within fp16 rounding, for 3x3 / 1x1 / strided convolutions with and without bias,
+    a BatchNorm without ReLU, and a BatchNorm whose input has a second reader (not folded)."""
+    import os
+    import sniper_amd.mx as mx
+    d = mx.sym.Variable('data')
+    c1 = mx.sym.Convolution(data=d, kernel=(3, 3), pad=(1, 1), num_filter=64, no_bias=True, name='c1')
+    b1 = mx.sym.BatchNorm(data=c1, fix_gamma=False, eps=2e-5, use_global_stats=True, name='b1')
+    r1 = mx.sym.Activation(data=b1, act_type='relu', name='r1')
+    c2 = mx.sym.Convolution(data=r1, kernel=(1, 1), num_filter=128, no_bias=False, name='c2')
+    b2 = mx.sym.BatchNorm(data=c2, fix_gamma=False, eps=2e-5, use_global_stats=True, name='b2')          # no ReLU behind it
+    c3 = mx.sym.Convolution(data=b2, kernel=(3, 3), stride=(2, 2), pad=(1, 1), num_filter=64, no_bias=True, name='c3')
+    b3 = mx.sym.BatchNorm(data=c3, fix_gamma=False, eps=2e-5, use_global_stats=True, name='b3')          # c3 has two readers
+    r3 = mx.sym.Activation(data=b3, act_type='relu', name='r3')
+    out = mx.sym.Group([r3, c3])
+    shapes = [('data', (2, 64, 24, 40))]
+    rs = np.random.RandomState(5)
+
+    def run(fold):
+        old = os.environ.get('SNIPER_INFER_FOLD_BN')
+        os.environ['SNIPER_INFER_FOLD_BN'] = '1' if fold else '0'
+        try:
+            mod = mx.mod.Module(symbol=out, context=[mx.gpu(0)], data_names=['data'], label_names=None)
+            mod.bind(shapes, None, for_training=False)
+        finally:
+            if old is None:
+                del os.environ['SNIPER_INFER_FOLD_BN']
+            else:
+                os.environ['SNIPER_INFER_FOLD_BN'] = old
+        return mod
+    folded, plain = run(True), run(False)
+    exe = next(iter(folded._exes.values()))
+    arg, aux = {}, {}
+    for name, p in exe.params.items():
+        shp = p.ref_shape
+        if name.endswith('_gamma'):
+            v = rs.uniform(0.5, 1.5, shp)
+        elif name.endswith('_weight'):
+            v = rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))
+        else:
+            v = rs.standard_normal(shp) * 0.3
+        arg[name] = mx.nd.array(v.astype(np.float32))
+    for name, t in exe.aux.items():
+        aux[name] = mx.nd.array((rs.uniform(0.5, 2.0, tuple(t.shape)) if name.endswith('_var') else rs.standard_normal(tuple(t.shape)) * 0.2
+                                 ).astype(np.float32))
+    for m in (folded, plain):
+        m.init_params(arg_params=arg, aux_params=aux)
+    kinds = {type(s).__name__ + ':' + s.node.name: getattr(s, 'folded_into', None) is not None for s in exe.steps
+             if type(s).__name__ == 'BatchNormStep'}
+    assert kinds == {'BatchNormStep:b1': True, 'BatchNormStep:b2': True, 'BatchNormStep:b3': False}, kinds
+    assert all(getattr(s, 'folded_into', None) is None for s in next(iter(plain._exes.values())).steps)
+    for call in range(3):            # eager, capture, replay
+        x = mx.nd.array(rs.standard_normal(shapes[0][1]).astype(np.float32))
+        batch = mx.io.DataBatch(data=[x], label=None, pad=0, index=None, provide_data=shapes, provide_label=None)
+        folded.forward(batch, is_train=False)
+        a = [o.asnumpy() for o in folded.get_outputs()]
+        plain.forward(batch, is_train=False)
+        b = [o.asnumpy() for o in plain.get_outputs()]
+        for u, v in zip(a, b):
+            assert u.shape == v.shape and np.isfinite(u).all()
+            err = np.abs(u - v).max() / max(np.abs(v).max(), 1e-6)
+            assert err < 4e-3, (call, err)         # two fp16 roundings of a scaled weight vs of the normalised output
+        assert (a[0] >= 0).all() and (a[0] > 0).mean() > 0.2
+    # new parameters after the capture reach the folded buffers (set_params -> params_changed -> refold)
+    arg2 = {k: mx.nd.array(v.asnumpy() * 0.5) if k.endswith('_gamma') else v for k, v in arg.items()}
+    for m in (folded, plain):
+        m.set_params(arg2, aux)
+    folded.forward(batch, is_train=False)
+    plain.forward(batch, is_train=False)
+    u, v = folded.get_outputs()[0].asnumpy(), plain.get_outputs()[0].asnumpy()
+    assert np.abs(u - v).max() / max(np.abs(v).max(), 1e-6) < 4e-3 and not np.allclose(u, a[0])
