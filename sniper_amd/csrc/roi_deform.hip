@@ -421,6 +421,165 @@ __global__ __launch_bounds__(256) void dpsroi_bwd_data_kernel(const half_t *__re
   if (active_c) tile_store(acc, d_data, out_f32, b, y0, x0, H, W, C, c);
 }
 
+// ---- the same tile-owner data gradient on the matrix cores ------------------------------------------------------------
+// Phase B above is D[cell (16)][channel] += sum_e W[cell][e] * dout[row(e)][channel] with W[cy*4+cx][e] = Wy_e[cy] * Wx_e[cx]:
+// a GEMM with M = the tile's 16 cells, N = channels, K = the entries.  As 20 VALU instructions per entry and thread it was
+// instruction-issue bound (0.5 ms at R = 6000: 1.4 M entries x 256 channels).  Here a wave owns 64 channels (4 fragments of
+// 16), phase A writes W TRANSPOSED ([cell][entry], zero padded to whole 32-entry K-steps) as an fp16 pair hi + lo
+// (w = hi + lo to 2^-22: the fp32 output keeps its 1e-3 contract) and one K-step is 8 v_mfma_f32_16x16x32_f16 per wave
+// on gathered dout values (B operand: lane (channel n, k-group) holds its channel's value of 8 consecutive entries).
+// Same windows, same entry order, fixed accumulation order: deterministic.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kMfmaK = 64;     // bins of one RoI (pooled * pooled) this kernel handles
+constexpr int kListCap = 384;  // entries collected before they are multiplied: >= 4 RoIs x 49 bins beyond the flush threshold
+constexpr int kListPitch = kListCap + 8;   // halves per cell row: 16-byte reads of the 16 rows fall on 16 different bank quads
+
+__global__ __launch_bounds__(256, 5) void dpsroi_bwd_data_mfma_kernel(const half_t *__restrict__ dout, const float *__restrict__ rois,
+                                                                      const float *__restrict__ trans, const int4 *__restrict__ win,
+                                                                      void *__restrict__ d_data, int out_f32, int R, int H, int W, int C,
+                                                                      int P, int S, float scale, float trans_std) {
+  __shared__ __attribute__((aligned(16))) half_t w_hi[16][kListPitch];
+  __shared__ __attribute__((aligned(16))) half_t w_lo[16][kListPitch];
+  __shared__ __attribute__((aligned(16))) int e_row[kListCap];
+  __shared__ int roi_list[256];
+  __shared__ int wave_cnt[4];
+  __shared__ int seg_n[4];
+  const int PP = P * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int tiles_x = (W + 3) >> 2;
+  const int x0 = (int)(blockIdx.x % tiles_x) * 4, y0 = (int)(blockIdx.x / tiles_x) * 4;
+  const int b = blockIdx.y, c0 = blockIdx.z * 256 + wave * 64;
+  floatx4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;    // entries in the list (workgroup-uniform)
+  // multiply the collected entries into the accumulators: zero the tail of the last 32-entry K-step (row 0, weight 0), then
+  // every wave runs its 64 channels over the whole list
+  auto flush = [&]() {
+    const int kend = (cnt + 31) & ~31;
+    for (int i = tid; i < (kend - cnt) * 16; i += 256) {
+      const int e = cnt + i / 16, m = i & 15;
+      w_hi[m][e] = (half_t)0;
+      w_lo[m][e] = (half_t)0;
+      if (m == 0) e_row[e] = 0;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < cnt; k0 += 32) {
+      const half8 a_hi = *reinterpret_cast<const half8 *>(&w_hi[fr][k0 + kg * 8]);
+      const half8 a_lo = *reinterpret_cast<const half8 *>(&w_lo[fr][k0 + kg * 8]);
+      const int4 r0 = *reinterpret_cast<const int4 *>(&e_row[k0 + kg * 8]);
+      const int4 r1 = *reinterpret_cast<const int4 *>(&e_row[k0 + kg * 8 + 4]);
+      const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      half8 bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j * 16 + fr;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bv[j][t] = c < C ? dout[(size_t)rows[t] * C + c] : (half_t)0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bv[j], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bv[j], acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();      // the list is free again
+    cnt = 0;
+  };
+  for (int base = 0; base < R; base += 256) {
+    const int rr = base + tid;
+    bool hit = false;
+    if (rr < R) {
+      const int4 w = win[rr];
+      hit = w.w && w.x == b && (w.y & 0xffff) <= x0 + 3 && (w.y >> 16) >= x0 && (w.z & 0xffff) <= y0 + 3 && (w.z >> 16) >= y0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = wave_cnt[k];
+      off += k < wave ? n : 0;
+      total += n;
+    }
+    if (hit) roi_list[off + __popcll(m & lt)] = rr;
+    __syncthreads();
+    for (int g0 = 0; g0 < total; g0 += 4) {
+      if (cnt > kListCap - 4 * kMfmaK) flush();                      // room for four more RoIs?
+      // phase A: this wave's RoI, one lane per bin -> which bins touch the tile, and their separable weights
+      bool act = false;
+      float Wx[4] = {0.f, 0.f, 0.f, 0.f}, Wy[4] = {0.f, 0.f, 0.f, 0.f};
+      float inv = 0.f;
+      int r = 0;
+      const int bin = lane;
+      if (g0 + wave < total && bin < PP) {
+        r = roi_list[g0 + wave];
+        const int ph = bin / P, pw = bin - ph * P;
+        const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+        int nvx = 0, nvy = 0;
+        for (int i = 0; i < S; ++i) {
+          float w = sample_pos(g.wstart, i, g.sub_w), h = sample_pos(g.hstart, i, g.sub_h);
+          if (!(w < -0.5f || w > (float)W - 0.5f)) {
+            ++nvx;
+            tent4(fminf(fmaxf(w, 0.f), (float)W - 1.f), x0, Wx);
+          }
+          if (!(h < -0.5f || h > (float)H - 0.5f)) {
+            ++nvy;
+            tent4(fminf(fmaxf(h, 0.f), (float)H - 1.f), y0, Wy);
+          }
+        }
+        const float sx = Wx[0] + Wx[1] + Wx[2] + Wx[3], sy = Wy[0] + Wy[1] + Wy[2] + Wy[3];
+        act = nvx * nvy > 0 && sx > 0.f && sy > 0.f;
+        inv = act ? 1.f / (float)(nvx * nvy) : 0.f;
+      }
+      const unsigned long long am = __ballot(act);
+      if (lane == 0) seg_n[wave] = __popcll(am);
+      __syncthreads();
+      int eoff = cnt, added = 0;      // entries of the four RoIs are appended in wave order
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int n = seg_n[k];
+        eoff += k < wave ? n : 0;
+        added += n;
+      }
+      if (act) {
+        const int pos = eoff + __popcll(am & lt);
+        e_row[pos] = r * PP + bin;
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < 4; ++cx) {
+            const float w = Wy[cy] * (Wx[cx] * inv);
+            const half_t hi = (half_t)w;
+            w_hi[cy * 4 + cx][pos] = hi;
+            w_lo[cy * 4 + cx][pos] = (half_t)(w - (float)hi);
+          }
+      }
+      cnt += added;
+      __syncthreads();      // seg_n is rewritten by the next round (and the list is read by a flush)
+    }
+  }
+  flush();
+  // D[m = 4 kg + r][n = fr]: tile row cy = kg, column cx = r, channel c0 + 16 j + fr
+  const int y = y0 + kg;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j * 16 + fr;
+    if (c >= C || y >= H) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = x0 + r;
+      if (x >= W) continue;
+      const size_t o = (((size_t)b * H + y) * W + x) * C + c;
+      if (out_f32) ((float *)d_data)[o] = acc[j][r];
+      else ((half_t *)d_data)[o] = (half_t)acc[j][r];
+    }
+  }
+}
+
 // d_trans (R,2,P,P): one thread per (r, ph, pw, 8-channel chunk), segmented shuffle reduction over the C/8 lanes
 // that share a bin, one plain store per (r,ph,pw,xy).  Same window factorisation as the forward:
 //   d out / d tx = roi_w * trans_std / count * sum_y sum_x Wy(y) DWx(x) data[y][x],  DWx = +1 / -1 on a sample's upper / lower cell
@@ -513,8 +672,13 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
   SN_CHECK_LAUNCH();
   const int tiles = sn_div_up(W, 4) * sn_div_up(H, 4);
   const size_t smem = sizeof(float) * 4 * pooled * pooled * kEntStride + sizeof(int) * (256 + 8);
-  hipLaunchKernelGGL(dpsroi_bwd_data_kernel, dim3(tiles, B, sn_div_up(C, 256)), dim3(256), smem, s, (const half_t *)dout, rois,
-                     trans, (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+  static const bool valu_only = getenv("SNIPER_DPSROI_BWD_VALU") != nullptr;
+  if (pooled * pooled <= kMfmaK && !valu_only)      // entries x channels on the matrix cores
+    hipLaunchKernelGGL(dpsroi_bwd_data_mfma_kernel, dim3(tiles, B, sn_div_up(C, 256)), dim3(256), 0, s, (const half_t *)dout, rois,
+                       trans, (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+  else
+    hipLaunchKernelGGL(dpsroi_bwd_data_kernel, dim3(tiles, B, sn_div_up(C, 256)), dim3(256), smem, s, (const half_t *)dout, rois,
+                       trans, (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
   SN_CHECK_LAUNCH();
   if (trans) {
     const int cpr = C / 8;
@@ -968,6 +1132,151 @@ __global__ __launch_bounds__(256) void deform_col2im_data_kernel(const half_t *_
   if (active_c) tile_store(acc, d_data, out_f32, n, y0, x0, H, W, C, c);
 }
 
+// The same tile-owner gather on the matrix cores (see dpsroi_bwd_data_mfma_kernel): D[cell][channel] += sum_e W[cell][e] *
+// dcol[row(e)][channel], W = Wy (x) Wx of a sample that touches the tile, as an fp16 hi + lo pair; a wave owns 64 channels of
+// the deformable group, the workgroup's waves share one entry list (candidate order = the scalar kernel's order).
+template <typename TO>
+__global__ __launch_bounds__(256) void deform_col2im_data_mfma_kernel(const half_t *__restrict__ dcol, const TO *__restrict__ offset,
+                                                                      void *__restrict__ d_data, int out_f32, int H, int W, int C,
+                                                                      int Ho, int Wo, int KH, int KW, int stride, int pad, int dil,
+                                                                      int DG, int off_ps, int slabs,
+                                                                      const unsigned *__restrict__ dmax_bits) {
+  __shared__ __attribute__((aligned(16))) half_t w_hi[16][kListPitch];
+  __shared__ __attribute__((aligned(16))) half_t w_lo[16][kListPitch];
+  __shared__ __attribute__((aligned(16))) int e_row[kListCap];
+  __shared__ int seg_n[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6, nthr = blockDim.x;
+  const int fr = lane & 15, kg = lane >> 4;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int T = KH * KW, cg = C / DG;
+  const int tiles_x = (W + 3) >> 2;
+  const int x0 = (int)(blockIdx.x % tiles_x) * 4, y0 = (int)(blockIdx.x / tiles_x) * 4;
+  const int n = blockIdx.y, g = blockIdx.z / slabs, slab = blockIdx.z - g * slabs;
+  const int cl0 = slab * nthr + wave * 64;     // first channel (inside the group) of this wave's 64
+  int oy_lo = 0, oy_hi = Ho - 1, ox_lo = 0, ox_hi = Wo - 1;
+  if (dmax_bits) {
+    const float D = __uint_as_float(*dmax_bits);
+    if (D < 1.0e6f) {
+      const int Di = (int)ceilf(D) + 1, span = (KH > KW ? KH : KW) - 1;
+      auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };   // floor(a / b), b > 0
+      oy_lo = max(0, -fdiv(-(y0 - Di + pad - span * dil), stride));
+      oy_hi = min(Ho - 1, fdiv(y0 + 3 + Di + pad, stride));
+      ox_lo = max(0, -fdiv(-(x0 - Di + pad - span * dil), stride));
+      ox_hi = min(Wo - 1, fdiv(x0 + 3 + Di + pad, stride));
+    }
+  }
+  const int wh = max(oy_hi - oy_lo + 1, 0), ww = max(ox_hi - ox_lo + 1, 0);
+  const int cand = wh * ww * T, cand_full = Ho * Wo * T;
+  floatx4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  auto flush = [&]() {
+    const int kend = (cnt + 31) & ~31;
+    for (int i = tid; i < (kend - cnt) * 16; i += nthr) {
+      const int e = cnt + i / 16, m = i & 15;
+      w_hi[m][e] = (half_t)0;
+      w_lo[m][e] = (half_t)0;
+      if (m == 0) e_row[e] = 0;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < cnt; k0 += 32) {
+      const half8 a_hi = *reinterpret_cast<const half8 *>(&w_hi[fr][k0 + kg * 8]);
+      const half8 a_lo = *reinterpret_cast<const half8 *>(&w_lo[fr][k0 + kg * 8]);
+      const int4 r0 = *reinterpret_cast<const int4 *>(&e_row[k0 + kg * 8]);
+      const int4 r1 = *reinterpret_cast<const int4 *>(&e_row[k0 + kg * 8 + 4]);
+      const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      half8 bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cl = cl0 + j * 16 + fr;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bv[j][t] = cl < cg ? dcol[(size_t)rows[t] * C + g * cg + cl] : (half_t)0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bv[j], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bv[j], acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cnt = 0;
+  };
+  for (int base = 0; base < cand; base += nthr) {
+    if (cnt > kListCap - nthr) flush();
+    const int widx = base + tid;
+    int idx = 0;
+    bool hit = false;
+    float Wx[4] = {0.f, 0.f, 0.f, 0.f}, Wy[4] = {0.f, 0.f, 0.f, 0.f};
+    if (widx < cand) {
+      const int wl = widx / T, tap = widx - wl * T;
+      const int oy = oy_lo + wl / ww, ox = ox_lo + wl % ww;
+      const int ml = oy * Wo + ox;
+      idx = ml * T + tap;
+      const int kh = tap / KW, kw = tap - kh * KW;
+      const TO *op = offset + ((size_t)n * Ho * Wo + ml) * off_ps + g * 2 * T + 2 * tap;
+      const float py = (float)(oy * stride - pad + kh * dil) + (float)op[0];
+      const float px = (float)(ox * stride - pad + kw * dil) + (float)op[1];
+      const DeformSample s = deform_sample(py, px, H, W);
+      if (s.ok && s.x1 >= x0 && s.x0 <= x0 + 3 && s.y1 >= y0 && s.y0 <= y0 + 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          Wx[k] = (s.x0 - x0 == k ? 1.f - s.lx : 0.f) + (s.x1 - x0 == k ? s.lx : 0.f);
+          Wy[k] = (s.y0 - y0 == k ? 1.f - s.ly : 0.f) + (s.y1 - y0 == k ? s.ly : 0.f);
+        }
+        if (s.x0 == s.x1) {  // clamped at the border: deform_sample put weight 1 on the single cell
+#pragma unroll
+          for (int k = 0; k < 4; ++k) Wx[k] = (s.x0 - x0 == k ? 1.f : 0.f);
+        }
+        if (s.y0 == s.y1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) Wy[k] = (s.y0 - y0 == k ? 1.f : 0.f);
+        }
+        hit = true;
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) seg_n[wave] = __popcll(m);
+    __syncthreads();
+    int eoff = cnt, added = 0;
+    for (int k = 0; k < nwave; ++k) {
+      const int nn = seg_n[k];
+      eoff += k < wave ? nn : 0;
+      added += nn;
+    }
+    if (hit) {
+      const int pos = eoff + __popcll(m & lt);
+      e_row[pos] = n * cand_full + idx;   // row (m, tap) of dcol
+#pragma unroll
+      for (int cy = 0; cy < 4; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) {
+          const float w = Wy[cy] * Wx[cx];
+          const half_t hi = (half_t)w;
+          w_hi[cy * 4 + cx][pos] = hi;
+          w_lo[cy * 4 + cx][pos] = (half_t)(w - (float)hi);
+        }
+    }
+    cnt += added;
+    __syncthreads();
+  }
+  flush();
+  const int y = y0 + kg;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cl = cl0 + j * 16 + fr;
+    if (cl >= cg || y >= H) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = x0 + r;
+      if (x >= W) continue;
+      const size_t o = (((size_t)n * H + y) * W + x) * C + g * cg + cl;
+      if (out_f32) ((float *)d_data)[o] = acc[j][r];
+      else ((half_t *)d_data)[o] = (half_t)acc[j][r];
+    }
+  }
+}
+
 SN_EXPORT int sn_deform_im2col(const void *data, const void *offset, void *col, int N, int H, int W, int C, int KH, int KW,
                                int stride, int pad, int dil, int deformable_groups, int offset_pix_stride, int offset_dtype,
                                sn_stream_t stream) {
@@ -1043,7 +1352,17 @@ SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *o
                            offset_pix_stride, dmax);
       SN_CHECK_LAUNCH();
     }
-    if (offset_dtype == 0)
+    static const bool valu_only = getenv("SNIPER_DEFORM_BWD_VALU") != nullptr;
+    if (!valu_only) {      // entries x channels on the matrix cores
+      if (offset_dtype == 0)
+        hipLaunchKernelGGL((deform_col2im_data_mfma_kernel<half_t>), grid, dim3(bt), 0, s, (const half_t *)dcol,
+                           (const half_t *)offset, d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups,
+                           offset_pix_stride, slabs, (const unsigned *)dmax);
+      else
+        hipLaunchKernelGGL((deform_col2im_data_mfma_kernel<float>), grid, dim3(bt), 0, s, (const half_t *)dcol,
+                           (const float *)offset, d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups,
+                           offset_pix_stride, slabs, (const unsigned *)dmax);
+    } else if (offset_dtype == 0)
       hipLaunchKernelGGL((deform_col2im_data_kernel<half_t>), grid, dim3(bt), 0, s, (const half_t *)dcol, (const half_t *)offset,
                          d_data, d_data_f32, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, slabs,
                          (const unsigned *)dmax);
