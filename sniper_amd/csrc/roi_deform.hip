@@ -635,6 +635,110 @@ __global__ __launch_bounds__(256) void dpsroi_bwd_trans_kernel(const half_t *__r
   }
 }
 
+// d_trans with the bin geometry computed ONCE per (RoI, bin) -- the kernel above recomputes roi_geom, the sample lists and
+// 2 x (cells x S) tent sums / tent derivatives in each of a bin's C/8 threads (0.42 ms at R = 6000, VALU-bound like the old
+// forward).  One workgroup per RoI: the first P*P threads put every bin's window, weights and derivative weights into LDS, then
+// the threads walk the (bin, 8-channel chunk) items (the chunks of a bin are consecutive lanes) and reduce over the chunks with
+// the same shuffles.  Same cell order, same products: the sums are those of dpsroi_bwd_trans_kernel.
+struct BinWinD {
+  float wx[kWinMax], wy[kWinMax], dwx[kWinMax], dwy[kWinMax];
+  int x_lo, nx, y_lo, ny, slow;
+  float kx, ky;     // trans_std / count * roi_w, ... * roi_h
+};
+__global__ __launch_bounds__(256) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
+                                                                   const float *__restrict__ rois, const float *__restrict__ trans,
+                                                                   float *__restrict__ d_trans, int R, int H, int W, int C, int P,
+                                                                   int S, float scale, float trans_std) {
+  __shared__ BinWinD win[kBinsMax];
+  __shared__ int s_b;
+  const int r = blockIdx.x, cpr = C >> 3, nb = P * P;   // host: cpr is a power of two <= 64
+  if (threadIdx.x < nb) {
+    const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
+    const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+    const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+    BinWinD &b = win[threadIdx.x];
+    const int count = ax.n * ay.n;
+    const float k = count ? trans_std / (float)count : 0.f;
+    b.kx = k * g.roi_w;
+    b.ky = k * g.roi_h;
+    b.x_lo = ax.lo; b.nx = count ? ax.hi - ax.lo + 1 : 0;
+    b.y_lo = ay.lo; b.ny = count ? ay.hi - ay.lo + 1 : 0;
+    b.slow = (b.nx > kWinMax || b.ny > kWinMax) ? 1 : 0;
+    if (!b.slow) {
+#pragma unroll
+      for (int q = 0; q < kWinMax; ++q) {
+        b.wx[q] = q < b.nx ? tent_sum(ax, ax.lo + q) : 0.f;
+        b.dwx[q] = q < b.nx ? tent_dsum(ax, ax.lo + q) : 0.f;
+        b.wy[q] = q < b.ny ? tent_sum(ay, ay.lo + q) : 0.f;
+        b.dwy[q] = q < b.ny ? tent_dsum(ay, ay.lo + q) : 0.f;
+      }
+    }
+    if (threadIdx.x == 0) s_b = g.b;
+  }
+  __syncthreads();
+  const half_t *img0 = data + (size_t)s_b * H * W * C;
+  const half_t *grow = dout + (size_t)r * nb * C;
+  const int items = nb * cpr, rounds = (items + 255) / 256;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int it = rd * 256 + threadIdx.x;
+    const bool active = it < items;
+    const int itc = active ? it : items - 1;
+    const int bin = itc / cpr, ch = (itc - bin * cpr) * 8;
+    const BinWinD &b = win[bin];
+    float gtx = 0.f, gty = 0.f;
+    if (active && b.nx > 0) {
+      const half8 go = *reinterpret_cast<const half8 *>(grow + (size_t)itc * 8);
+      const half_t *img = img0 + ch;
+      if (!b.slow) {
+        for (int qy = 0; qy < b.ny; ++qy) {
+          const float wy = b.wy[qy], dwy = b.dwy[qy];
+          if (wy == 0.f && dwy == 0.f) continue;
+          const half_t *row = img + ((size_t)(b.y_lo + qy) * W + b.x_lo) * C;
+          for (int qx = 0; qx < b.nx; ++qx) {
+            const float kx = wy * b.dwx[qx], ky = dwy * b.wx[qx];
+            if (kx == 0.f && ky == 0.f) continue;
+            const half8 u = *reinterpret_cast<const half8 *>(row + (size_t)qx * C);
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
+            gtx += kx * dot;
+            gty += ky * dot;
+          }
+        }
+      } else {             // oversized window: weights on the fly, as dpsroi_bwd_trans_kernel
+        const int ph = bin / P, pw = bin - ph * P;
+        const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+        const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+        for (int y = ay.lo; y <= ay.hi; ++y) {
+          const float wy = tent_sum(ay, y), dwy = tent_dsum(ay, y);
+          if (wy == 0.f && dwy == 0.f) continue;
+          for (int x = ax.lo; x <= ax.hi; ++x) {
+            const float kx = wy * tent_dsum(ax, x), ky = dwy * tent_sum(ax, x);
+            if (kx == 0.f && ky == 0.f) continue;
+            const half8 u = *reinterpret_cast<const half8 *>(img + ((size_t)y * W + x) * C);
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
+            gtx += kx * dot;
+            gty += ky * dot;
+          }
+        }
+      }
+      gtx *= b.kx;
+      gty *= b.ky;
+    }
+    for (int off = cpr >> 1; off > 0; off >>= 1) {
+      gtx += __shfl_xor(gtx, off, 64);
+      gty += __shfl_xor(gty, off, 64);
+    }
+    if (active && (threadIdx.x & (cpr - 1)) == 0) {
+      const int ph = bin / P, pw = bin - ph * P;
+      d_trans[(((size_t)r * 2 + 0) * P + ph) * P + pw] = gtx;
+      d_trans[(((size_t)r * 2 + 1) * P + ph) * P + pw] = gty;
+    }
+  }
+}
+
 static long blocks_for(long total) {
   long b = (total + 255) / 256;
   return b < 1 ? 1 : (b > 16384 ? 16384 : b);
@@ -685,8 +789,13 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
     SN_REQUIRE(C % 8 == 0 && cpr <= 64 && (cpr & (cpr - 1)) == 0,
                "sn_dpsroi_pool_bwd: with trans, C/8 must be a power of two <= 64 (C=%d)", C);
     const long total = (long)R * pooled * pooled * cpr;
-    hipLaunchKernelGGL(dpsroi_bwd_trans_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t *)dout,
-                       (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+    static const bool v1 = getenv("SNIPER_DPSROI_V1") != nullptr;
+    if (pooled * pooled <= kBinsMax && !v1)
+      hipLaunchKernelGGL(dpsroi_bwd_trans_roi_kernel, dim3((unsigned)R), dim3(256), 0, s, (const half_t *)dout, (const half_t *)data,
+                         rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+    else
+      hipLaunchKernelGGL(dpsroi_bwd_trans_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t *)dout,
+                         (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
     SN_CHECK_LAUNCH();
   }
   return SN_OK;
@@ -1308,7 +1417,16 @@ __global__ __launch_bounds__(256) void deform_absmax_kernel(const TO *__restrict
     m = (v > m || v != v) ? (v != v ? INFINITY : v) : m;      // NaN -> +inf: the window opens completely
   }
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  // one integer atomic per workgroup, and only when it can raise the value: 4096 same-address atomics (one per wave of 1024
+  // workgroups) serialised to 51 us for a 3 MB read
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const unsigned bits = __float_as_uint(b);
+    if (bits > *reinterpret_cast<volatile unsigned *>(out)) atomicMax(out, bits);
+  }
 }
 
 SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *offset, void *d_data, int d_data_f32,
@@ -1343,7 +1461,7 @@ SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *o
       const long rows = (long)N * Ho * Wo;
       const int cols = 2 * KH * KW * deformable_groups;
       const long want = (rows * cols + 255) / 256;
-      const unsigned blocks = (unsigned)(want > 1024 ? 1024 : (want < 1 ? 1 : want));
+      const unsigned blocks = (unsigned)(want > 256 ? 256 : (want < 1 ? 1 : want));
       if (offset_dtype == 0)
         hipLaunchKernelGGL((deform_absmax_kernel<half_t>), dim3(blocks), dim3(256), 0, s, (const half_t *)offset, rows, cols,
                            offset_pix_stride, dmax);
