@@ -961,8 +961,18 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dy
 __global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float *__restrict__ part, int nblk, int C, float *__restrict__ db) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
+  // the row blocks are added in block order (fixed bits), but their loads are independent: eight in flight instead of a chain
+  // of nblk dependent L2 round trips (13.5 us for 96 blocks)
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += part[(size_t)k * C + c];
+  int k = 0;
+  for (; k + 8 <= nblk; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * C + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < nblk; ++k) s += part[(size_t)k * C + c];
   db[c] += s;
 }
 
