@@ -25,9 +25,11 @@ Extra objects on the JSON line:
                   step_tflops            conv FLOPs of a step / the timed ms_per_step (end to end, everything else included).
                 peak = 2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).  traffic = HBM bytes per conv launch from rocprofv3 --pmc
                 passes, reported only when they were collected on THIS build of the convolution sources (else null).
-  cpu_baseline  the reference's CPU iterator path (chip extraction + box assignment + RPN anchor labelling; oracle/
-                restatement of lib/data_utils/data_workers.py) timed on this node's host cores on a bounded sample, chips/s,
-                kind "port"; it times the DATA PATH only and is a reported baseline, never a speed-up claim.  `c1` inside it:
+  cpu_baseline  the reference's CPU iterator path (chip extraction + box assignment + RPN anchor labelling) timed on this
+                node's host cores on a bounded sample, chips/s: kind "reference" = the reference's own
+                lib/data_utils/data_workers.py (lib2to3 artefact) over its compiled chips / bbox modules (oracle/_ref), kind
+                "port" = the oracle/ restatement where that artefact is missing; it times the DATA PATH only and is a reported
+                baseline, never a speed-up claim.  `c1` inside it:
                 BASELINE configs[0] -- MobileNetV2 Faster-RCNN, 2 x 512 x 512 chips, one training step (forward + backward)
                 through the reference-semantics CPU operators of oracle/graph_cpu.py.
   inference     BASELINE configs[4] (AutoFocus inference, `inf images/sec`); --no-inference skips it.
@@ -155,26 +157,36 @@ def pmc_traffic():
 
 
 def cpu_baseline(seconds_target=15.0):
-    """The reference's CPU data path (oracle restatement), Pool(P) over images like MNIteratorE2E does."""
+    """The reference's CPU data path, Pool(P) over images like MNIteratorE2E does.  kind "reference": the reference's OWN
+    lib/data_utils/data_workers.py (chip_worker.chip_extractor / box_assigner, anchor_worker.worker) over its compiled chips /
+    bbox modules -- the lib2to3 artefact and the modules oracle/build.py made from the reference sources (oracle/_ref, present on
+    the GPU box); kind "port": oracle/data_path.py, the restatement pinned against them, where the artefact is missing."""
     import multiprocessing as mp
     from oracle import build as obuild
-    obuild.build_restatement()
+    from oracle import ref_py
+    use_ref = ref_py.available() and os.environ.get('SNIPER_CPU_BASELINE', 'reference') != 'port'
+    if not use_ref:
+        obuild.build_restatement()
+    fn = _cpu_image_chips_ref if use_ref else _cpu_image_chips
     P = min(os.cpu_count() or 1, 64)   # TRAIN.NUM_PROCESS = 64 in the reference config
     with mp.get_context('fork').Pool(P) as pool:
-        pool.map(_cpu_image_chips, range(P), chunksize=1)          # warm the workers (imports, anchor tables)
+        pool.map(fn, range(P), chunksize=1)          # warm the workers (imports, anchor tables)
         # bounded sample: a pilot batch sizes the timed batch to about `seconds_target` of wall time
         t0 = time.time()
-        pool.map(_cpu_image_chips, range(8 * P), chunksize=4)
+        pool.map(fn, range(8 * P), chunksize=4)
         pilot = max(time.time() - t0, 1e-3)
         n_img = int(min(max(8 * P * seconds_target / pilot, 8 * P), 4096 * P))
         t0 = time.time()
-        chips = pool.map(_cpu_image_chips, range(10 ** 6, 10 ** 6 + n_img), chunksize=4)
+        chips = pool.map(fn, range(10 ** 6, 10 ** 6 + n_img), chunksize=4)
         dt = time.time() - t0
     n_chips = int(sum(chips))
-    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'port', 'scope': 'data path only (a3-a6 of SURVEY section 8): '
-            'a reported baseline, not comparable with the training-step throughput above',
-            'sample': '%d synthetic images -> %d chips: chip_extractor + box_assigner + anchor_worker (oracle/data_path.py, '
-                      'restating lib/data_utils/data_workers.py) under multiprocessing.Pool(%d), %.1f s' % (n_img, n_chips, P, dt)}
+    what = ('the reference\'s own chip_worker.chip_extractor + box_assigner + anchor_worker.worker (lib/data_utils/data_workers.py '
+            'translated by lib2to3, over its compiled chips.pyx / cchips.cpp / bbox.pyx; oracle/_ref)' if use_ref else
+            'chip_extractor + box_assigner + anchor_worker (oracle/data_path.py, restating lib/data_utils/data_workers.py)')
+    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'reference' if use_ref else 'port',
+            'scope': 'data path only (a3-a6 of SURVEY section 8): a reported baseline, not comparable with the training-step '
+                     'throughput above',
+            'sample': '%d synthetic images -> %d chips: %s under multiprocessing.Pool(%d), %.1f s' % (n_img, n_chips, what, P, dt)}
 
 
 def cpu_c1_step():
@@ -241,6 +253,35 @@ def _cpu_image_chips(i):
     for ci, crop in enumerate(crops):
         at([512, 512, crop[1]], crop[0].copy(), crop[1], props[ci], gtids, r['boxes'][gtids].copy(), r['boxes'].copy(),
            r['max_classes'][gtids].reshape(-1, 1))
+    return len(crops)
+
+
+def _cpu_image_chips_ref(i):
+    """one image through the reference's own workers (oracle/ref_py.py loads them; per-process cache on the function)"""
+    from oracle import ref_py
+    from sniper_amd import config as cfgmod
+    from sniper_amd.synthetic import make_roidb
+    st = getattr(_cpu_image_chips_ref, 'st', None)
+    if st is None:
+        ns = ref_py.load()
+        cfg = cfgmod.res101_e2e()
+        np.random.seed(0)
+        cw = ns.data_workers.chip_worker(cfg, 512)
+        cw.chip_stride = 56
+        cw.chip_generator = ns.chip_generator.chip_generator(chip_stride=56, use_cpp=True)
+        aw = ns.data_workers.anchor_worker(cfg, 512)
+        st = _cpu_image_chips_ref.st = (cw, aw)
+    cw, aw = st
+    r = make_roidb(1, seed=100000 + i, n_proposals=0)[0]
+    np.random.seed(i)
+    ref_py.srand(i)
+    crops = cw.chip_extractor(r)
+    r['crops'] = crops
+    props = cw.box_assigner(r)[0]
+    gtids = np.where(r['max_overlaps'] == 1)[0]
+    for ci, crop in enumerate(crops):
+        aw.worker([[512, 512, crop[1]], crop[0].copy(), crop[1], props[ci], gtids, r['boxes'][gtids].copy(), r['boxes'].copy(),
+                   r['max_classes'][gtids].reshape(-1, 1)])
     return len(crops)
 
 

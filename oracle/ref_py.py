@@ -7,8 +7,10 @@ the two documented integer-division fixes, and import them over tiny stubs for `
 pass-through), ``cv2`` and ``nms``.  The native pieces come from ``oracle/_ref`` (built by
 ``oracle/build.py`` from the reference sources where they lie).
 
-Only usable where ``/root/reference`` exists (the build container); it produces the golden vectors
-in ``tests/golden`` (``tests/golden/make_golden.py``) and pins the numpy/C restatements.
+Where ``/root/reference`` exists (the build container) it produces the golden vectors in ``tests/golden``
+(``tests/golden/make_golden.py``) and pins the numpy/C restatements.  Where it does not (the GPU box), the same modules load from
+the translated artefact ``oracle/_ref/py3`` and the compiled modules in ``oracle/_ref`` -- bench.py's ``cpu_baseline`` times the
+reference's own workers that way (kind "reference").
 """
 import ctypes
 import importlib
@@ -27,8 +29,22 @@ REF = build.REF
 _STATE = {}
 
 
+ARTEFACT_LIB = os.path.join(build.REF_OUT, "py3", "lib")      # lib2to3 output of build.build_reference_py3 (travels to the GPU box)
+
+
 def available():
-    return build.have_reference()
+    """The reference's Python can be run here: from its checkout, or from the translated artefact + the compiled modules that
+    oracle/build.py left under oracle/_ref/ (the GPU box has no checkout)."""
+    return build.have_reference() or artefact_available()
+
+
+def artefact_available():
+    try:
+        names = os.listdir(build.REF_OUT)
+    except OSError:
+        return False
+    return (os.path.isfile(os.path.join(ARTEFACT_LIB, "data_utils", "data_workers.py")) and any(f.startswith("chips.") for f in names)
+            and any(f.startswith("bbox.") for f in names))
 
 
 def _stub_modules():
@@ -77,35 +93,38 @@ def load():
     if "ns" in _STATE:
         return _STATE["ns"]
     if not available():
-        raise RuntimeError("reference checkout not present at %s" % REF)
-    build.build_reference()
+        raise RuntimeError("neither the reference checkout (%s) nor its translated artefact (%s) is present" % (REF, ARTEFACT_LIB))
     # py2-era numpy aliases used by the reference (bbox.pyx:14, data_workers.py)
     if not hasattr(np, "float"):
         np.float = float
     if not hasattr(np, "int"):
         np.int = int
-    tmp = tempfile.mkdtemp(prefix="sniper_ref_py3_")
-    _STATE["tmp"] = tmp
-    lib3 = os.path.join(tmp, "lib3")
-    os.makedirs(lib3)
-    for sub in ("bbox", "chips", "data_utils"):
-        os.makedirs(os.path.join(lib3, sub))
-        src = os.path.join(REF, "lib", sub)
-        for f in os.listdir(src):
-            if f.endswith(".py"):
-                shutil.copy(os.path.join(src, f), os.path.join(lib3, sub, f))
-    subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", lib3], stdout=subprocess.DEVNULL,
-                          stderr=subprocess.DEVNULL)
+    if build.have_reference():
+        build.build_reference()
+        tmp = tempfile.mkdtemp(prefix="sniper_ref_py3_")
+        _STATE["tmp"] = tmp
+        lib3 = os.path.join(tmp, "lib3")
+        os.makedirs(lib3)
+        for sub in ("bbox", "chips", "data_utils"):
+            os.makedirs(os.path.join(lib3, sub))
+            src = os.path.join(REF, "lib", sub)
+            for f in os.listdir(src):
+                if f.endswith(".py"):
+                    shutil.copy(os.path.join(src, f), os.path.join(lib3, sub, f))
+        subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", lib3], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
 
-    def _sed(path, old, new):
-        with open(path) as fh:
-            s = fh.read()
-        assert old in s, (path, old)
-        with open(path, "w") as fh:
-            fh.write(s.replace(old, new))
+        def _sed(path, old, new):
+            with open(path) as fh:
+                s = fh.read()
+            assert old in s, (path, old)
+            with open(path, "w") as fh:
+                fh.write(s.replace(old, new))
 
-    dw = os.path.join(lib3, "data_utils", "data_workers.py")
-    _sed(dw, "chip_size / cfg.network.RPN_FEAT_STRIDE", "chip_size // cfg.network.RPN_FEAT_STRIDE")
+        dw = os.path.join(lib3, "data_utils", "data_workers.py")
+        _sed(dw, "chip_size / cfg.network.RPN_FEAT_STRIDE", "chip_size // cfg.network.RPN_FEAT_STRIDE")
+    else:
+        lib3 = ARTEFACT_LIB          # the same translation (+ the same division fix), made where the checkout exists
     # py2-only pickling shim (copy_reg / im_func) is dead weight for single-process use
     for name, mod in _stub_modules().items():
         sys.modules.setdefault(name, mod)
