@@ -63,6 +63,30 @@ def test_test_graph_lowers():
     ex = Executor(sym, shapes, False, [], device=torch.device('cpu'))
     assert any(type(s).__name__ == 'MultiProposalStep' for s in ex.steps)
     assert ex.n_trainable == 0
+    # test-time BatchNorm folding: bn2 / bn3 of every bottleneck read a convolution nobody else reads -> folded into it; bn1 reads
+    # the residual sum (also the next shortcut's input), bn0 the packed stem convolution, bn_data the image: not folded
+    bns = [s for s in ex.steps if type(s).__name__ == 'BatchNormStep']
+    folded = sorted(s.node.name for s in bns if s.folded_into is not None)
+    # (the three stage-4 bn3 layers read a DeformableConvolution: sampling + GEMM, no epilogue to fold into)
+    assert len(folded) == 33 * 2 - 3 and all(n.endswith(('_bn2', '_bn3')) for n in folded), folded[:5]
+    assert not any(n.startswith('stage4') and n.endswith('_bn3') for n in folded)
+    assert all(s.folded_into.fold_bn is s and s.y.t is s.x.t for s in bns if s.folded_into is not None)
+    assert not any(type(s).__name__ == 'DeformableConvolutionStep' and getattr(s, 'fold_bn', None) is not None for s in ex.steps)
+
+
+def test_batchnorm_folding_is_test_time_only(monkeypatch):
+    cfg = cfgmod.res101_e2e(batch_images=2)
+    net = ours.resnet_mx_101_e2e(momentum=0.995)
+    sym = net.get_symbol_rcnn(cfg)
+    shapes = dict(data=(2, 3, 512, 512), valid_ranges=(2, 2), im_info=(2, 3), label=(2, 21 * 32 * 32),
+                  bbox_target=(2, 84, 32, 32), bbox_weight=(2, 84, 32, 32), gt_boxes=(2, 100, 5))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    assert not any(getattr(s, 'folded_into', None) is not None for s in ex.steps)
+    monkeypatch.setenv('SNIPER_INFER_FOLD_BN', '0')
+    net = ours.resnet_mx_101_e2e(test_nbatch=2)
+    sym = net.get_symbol_rcnn(cfg, is_train=False)
+    ex = Executor(sym, dict(data=(2, 3, 512, 512), im_info=(2, 3), im_ids=(2,), chip_ids=(2,)), False, [], device=torch.device('cpu'))
+    assert not any(getattr(s, 'folded_into', None) is not None for s in ex.steps)
 
 
 def test_mobilenetv2_lowering_plan():
