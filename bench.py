@@ -328,6 +328,8 @@ def main():
     ap.add_argument('--no-inference', action='store_true', help='skip BASELINE config C5 (inf images/sec)')
     args = ap.parse_args()
 
+    # the host driver only supports dmabuf IPC: without this RCCL's peer mapping fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
