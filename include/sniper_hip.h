@@ -146,7 +146,7 @@ int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *res
                 int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
                 int relu, int out_f32, sn_stream_t stream);
 /* Kernel-selection override for sn_conv_fwd / sn_conv_dgrad (tuning hook, tools/conv_tune.py; no reference counterpart):
- * -1 = built-in per-layer table (default), 0 = register-staged kernels only, 1..9 = that LDS-DMA tile configuration for every
+ * -1 = built-in per-layer table (default), 0 = register-staged kernels only, 1..17 = that LDS-DMA tile configuration for every
  * layer that qualifies (see conv_dma.hip).  Results are identical up to fp32 summation order inside a tile's K loop
  * (the K order itself does not change).  Process-wide; set it while no launch is in flight. */
 int sn_conv_tune(int cfg);
