@@ -78,13 +78,30 @@ def _valid_range_filter(cls_dets, valid_range):
     return cls_dets[ok, :]
 
 
+def _stack_rows(per_class, dtype):
+    """(rows of every class stacked, rows per class) for a list of (n, 5) arrays / empty lists, as `dtype`."""
+    lens = np.fromiter((len(a) for a in per_class), np.int64, len(per_class))
+    if lens.sum() == 0:
+        return np.zeros((0, 5), dtype), lens
+    try:
+        big = np.concatenate(per_class)            # one pass when every entry already is an (n, 5) array
+        if big.ndim != 2 or big.shape[1] != 5:
+            raise ValueError
+        big = big.astype(dtype, copy=big.dtype == dtype)      # always a fresh array: callers write into it
+    except ValueError:                               # ragged input (the reference leaves [] for "no detections")
+        big = np.concatenate([np.asarray(a, dtype).reshape(-1, 5) for a in per_class])
+    return big, lens
+
+
 def threshold_detections(cscores, cboxes, cls_thresh, num_classes):
     """Tester.get_detections' score threshold for every class of one chip (lib/inference.py:289-295): list over classes
     1..num_classes-1 of `hstack(cboxes[inds, 0:4], cscores[inds, j, None])`, inds = where(cscores[:, j] > cls_thresh) -- one mask,
     one gather and one split instead of a where / hstack pair per class."""
     mask = (cscores[:, 1:num_classes] > cls_thresh).T            # (classes, RoIs): nonzero() walks a class's RoIs in order
     cls_idx, roi_idx = np.nonzero(mask)
-    dets = np.hstack((cboxes[roi_idx, 0:4], cscores[roi_idx, cls_idx + 1, np.newaxis]))
+    dets = np.empty((len(roi_idx), 5), np.result_type(cboxes.dtype, cscores.dtype))
+    dets[:, 0:4] = cboxes[roi_idx, 0:4]
+    dets[:, 4] = cscores[roi_idx, cls_idx + 1]
     return np.split(dets, np.cumsum(mask.sum(1))[:-1])
 
 
@@ -93,9 +110,7 @@ def prune_chip_border(per_class, crop, im_width, im_height):
     and drop those within 10 px of a chip border that is not an image border (`check_valid`, :236-259).  All classes in one
     float64 array, one mask; returns the list over classes of (n, 5) float64 arrays."""
     nc = len(per_class)
-    arrs = [np.asarray(a, np.float64).reshape(-1, 5) for a in per_class]
-    lens = np.fromiter((a.shape[0] for a in arrs), np.int64, nc)
-    big = np.concatenate(arrs)                  # a copy: the inputs keep their chip coordinates
+    big, lens = _stack_rows(per_class, np.float64)          # a copy: the inputs keep their chip coordinates
     big[:, 0] += crop[0]; big[:, 2] += crop[0]
     big[:, 1] += crop[1]; big[:, 3] += crop[1]
     ok = Tester._valid_mask(big, crop, im_width, im_height)
@@ -107,37 +122,37 @@ def prune_chip_border(per_class, crop, im_width, im_height):
 def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes):
     """The per (image, class) NMS problems of Tester.aggregate (lib/inference.py:170-190): for image i and class j the rows of
     every scale's every chip that pass that scale's valid range, in (scale, chip, row) order.  Built per image with a handful
-    of array operations (one concatenation, one area mask, one stable sort by class) instead of classes x scales x chips
-    Python iterations; returns the problems in (image, class) order, float32 (n, 5)."""
+    of array operations instead of classes x scales x chips Python iterations: every (scale, chip) part is stacked class-major
+    and masked once, and since each part already is class-major the regrouping by class is a block permutation computed from the
+    per (part, class) counts -- no sort.  Returns the problems in (image, class) order, float32 (n, 5)."""
     nc = num_classes - 1
     problems = []
     for i in range(num_images):
-        parts, cls_ids, oks = [], [], []
+        parts, counts = [], []
         for all_cls_dets, vr in zip(scale_cls_dets, valid_ranges):
             for c in range(len(all_cls_dets[1][i])):
-                arrs = [np.asarray(all_cls_dets[j][i][c], np.float32).reshape(-1, 5) for j in range(1, num_classes)]
-                lens = np.fromiter((a.shape[0] for a in arrs), np.int64, nc)
-                if lens.sum() == 0:
+                big, lens = _stack_rows([all_cls_dets[j][i][c] for j in range(1, num_classes)], np.float32)
+                if len(big) == 0:
                     continue
-                big = np.concatenate(arrs)
                 areas = (big[:, 3] - big[:, 1]) * (big[:, 2] - big[:, 0])      # float32 products, as _valid_range_filter
                 ok = np.ones(len(big), bool)
                 if vr[0] > 0:
                     ok &= areas > vr[0] * vr[0]
                 if vr[1] > 0:
                     ok &= areas <= vr[1] * vr[1]
-                parts.append(big)
-                cls_ids.append(np.repeat(np.arange(nc), lens))
-                oks.append(ok)
+                parts.append(big[ok])
+                counts.append(np.bincount(np.repeat(np.arange(nc), lens)[ok], minlength=nc))
         if not parts:
             problems.extend(np.empty((0, 5), np.float32) for _ in range(nc))
             continue
-        big, cid, ok = np.concatenate(parts), np.concatenate(cls_ids), np.concatenate(oks)
-        big, cid = big[ok], cid[ok]
-        order = np.argsort(cid, kind='stable')          # rows of a class stay in (scale, chip, row) order
-        big = big[order]
-        cuts = np.cumsum(np.bincount(cid, minlength=nc))[:-1]
-        problems.extend(np.split(big, cuts))
+        big = np.concatenate(parts)                  # rows ordered (part, class, row)
+        cnt = np.stack(counts)                       # (parts, classes)
+        src = np.cumsum(cnt.ravel()) - cnt.ravel()   # first row of block (part, class) in `big`
+        length = cnt.T.ravel()                       # blocks in destination order: class-major, parts (scale, chip) inside
+        start = src.reshape(cnt.shape).T.ravel()
+        total = int(length.sum())
+        order = np.repeat(start - (np.cumsum(length) - length), length) + np.arange(total)
+        problems.extend(np.split(big[order], np.cumsum(cnt.sum(0))[:-1]))
     return problems
 
 
