@@ -87,7 +87,7 @@ def _stack_rows(per_class, dtype):
         big = np.concatenate(per_class)            # one pass when every entry already is an (n, 5) array
         if big.ndim != 2 or big.shape[1] != 5:
             raise ValueError
-        big = big.astype(dtype, copy=big.dtype == dtype)      # always a fresh array: callers write into it
+        big = big.astype(dtype, copy=False)          # (concatenate already returned a fresh array: callers may write into it)
     except ValueError:                               # ragged input (the reference leaves [] for "no detections")
         big = np.concatenate([np.asarray(a, dtype).reshape(-1, 5) for a in per_class])
     return big, lens
