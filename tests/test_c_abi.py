@@ -78,3 +78,25 @@ def test_every_python_source_compiles():
         except SyntaxError as e:
             bad.append('%s: %s' % (f, e))
     assert len(files) > 40 and not bad, bad
+
+
+def test_conv_tile_plan_divides_the_baseline_shapes_over_the_cus():
+    """Host-side selection only (no launch): at BASELINE C2 (20 chips) the pipelined convolution takes 160-row tiles, so that
+    20 480 stage-3 pixels are 128 row tiles (256 / 512 / 1024 workgroups for 256 / 512 / 1024 channels on 256 CUs) and 81 920
+    stage-2 pixels 512 -- DESIGN.md section 8.4 (a silent change of this table costs 5 % of the step).  The row-tile count is
+    what sn_conv_fwd_stats_blocks / sn_conv_dgrad_bn_blocks report (the statistics partials are per row tile)."""
+    from sniper_amd import hip
+
+    def fwd(N, H, W, Cin, Cout, K, stride=1, pad=0, res=0):
+        return hip.query('sn_conv_fwd_stats_blocks', N, H, W, Cin, Cin, Cout, Cout, res, K, K, stride, pad, 1)
+
+    def dgrad(N, H, W, Cin, Cout, K, pad=0):
+        return hip.query('sn_conv_dgrad_bn_blocks', N, H, W, Cin, Cin, Cout, Cout, 0, K, K, 1, pad, 1)
+    assert fwd(20, 32, 32, 1024, 256, 1) == 128            # stage-3 conv1
+    assert fwd(20, 32, 32, 256, 256, 3, pad=1) == 128      # stage-3 conv2
+    assert fwd(20, 32, 32, 256, 1024, 1, res=1024) == 128  # stage-3 conv3 + residual
+    assert fwd(20, 64, 64, 128, 128, 3, pad=1) == 512      # stage-2 conv2
+    assert fwd(20, 32, 32, 1024, 512, 1) == 128            # stage-4 conv1
+    assert dgrad(20, 32, 32, 256, 256, 3, pad=1) == 128    # data gradient of stage-3 conv2, BatchNorm reduction fused
+    assert fwd(20, 128, 128, 64, 256, 1) == 5120           # a single K-step: 64-row tiles (all epilogue)
+    assert fwd(20, 128, 128, 64, 64, 1) == 0               # <= 64 output channels: register-staged kernel, no fused statistics
