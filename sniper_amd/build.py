@@ -27,7 +27,9 @@ EXTRA = {
     "mask.hip": ["-ffp-contract=off"],
 }
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-        "-munsafe-fp-atomics"]
+        "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"]
+# the compiler's per-kernel resource remarks (VGPRs, scratch, occupancy, LDS) are kept beside the object: tests/test_kernel_resources.py
+# reads them -- an accumulator tile that silently moved to scratch memory shows up there and nowhere else
 
 
 def _hipcc():
@@ -35,6 +37,12 @@ def _hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+def _is_remark_context(line):
+    """the source excerpt clang prints under a remark: `  NN | code` and the caret line"""
+    t = line.lstrip()
+    return t.startswith("|") or (t[:1].isdigit() and "|" in t[:12])
 
 
 def sources():
@@ -74,8 +82,12 @@ def build(force=False, verbose=True):
             if r.returncode != 0:
                 failed = True
                 sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
-            elif verbose and r.stdout.strip():
-                print(r.stdout)
+            else:
+                with open(cmd[-1][:-2] + ".remarks", "w") as fh:
+                    fh.write(r.stdout)
+                rest = "\n".join(ln for ln in r.stdout.splitlines() if "remark:" not in ln and not _is_remark_context(ln))
+                if verbose and rest.strip():
+                    print(rest)
     if failed:
         raise RuntimeError("hipcc failed")
     if jobs or not os.path.exists(LIB):

@@ -1,0 +1,48 @@
+"""CPU: register budgets of the hot kernels, from the compiler's own resource remarks (kept by the build beside each object).
+Found the hard way in round 2: an epilogue loop nest too big to unroll fully makes hipcc index the MFMA accumulators dynamically,
+and the whole accumulator tile moves to scratch memory (528 bytes per lane) -- correct results, a fraction of the speed, nothing in
+any parity test notices.  This test does."""
+import os
+import re
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, 'sniper_amd', 'lib', 'obj')
+
+
+def _resources(unit):
+    """{mangled kernel name: {resource: value}} from the remarks sniper_amd/build.py keeps beside the object file"""
+    path = os.path.join(OBJ, unit + '.remarks')
+    if not os.path.isfile(path):
+        pytest.skip('%s not built here (python -m sniper_amd.build writes it)' % path)
+    out, name = {}, None
+    with open(path) as fh:
+        for ln in fh:
+            m = re.search(r'Function Name: (\S+)', ln)
+            if m:
+                name = m.group(1)
+                out[name] = {}
+                continue
+            m = re.search(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)', ln)
+            if m and name:
+                out[name][m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def test_hot_kernels_keep_their_accumulators_in_registers():
+    conv, roi = _resources('conv_dma'), _resources('roi_deform')
+    dma = {k: v for k, v in conv.items() if 'conv_dma_kernel' in k}
+    assert len(dma) == 2 * 17, sorted(dma)                       # forward + data gradient of every configuration
+    for name, res in dma.items():
+        big = 'Li256ELi256E' in name     # the 256 x 256 tile: 8 waves at the 256-VGPR cap, a few epilogue values spill
+        assert res['ScratchSize'] <= (32 if big else 0) and res['VGPRs Spill'] <= (32 if big else 0), (name, res)
+        assert res['VGPRs'] <= 256, (name, res)
+    for frag in ('dpsroi_bwd_data_mfma_kernel', 'deform_col2im_data_mfma_kernel', 'dpsroi_bwd_trans_roi_kernel', 'dpsroi_fwd_roi_kernel'):
+        hits = {k: v for k, v in roi.items() if frag in k}
+        assert hits, frag
+        for name, res in hits.items():
+            assert res['ScratchSize'] == 0 and res['VGPRs Spill'] == 0, (name, res)
+    # the matrix-core gathers are launched five workgroups deep per CU (1280 tile workgroups on 256 CUs): <= 96 VGPRs
+    for name, res in roi.items():
+        if 'dpsroi_bwd_data_mfma_kernel' in name:
+            assert res['VGPRs'] <= 96 and res['Occupancy'] >= 5, res
