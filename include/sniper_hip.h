@@ -195,6 +195,22 @@ size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_str
                                      int stride, int pad, int dil);
 int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride, int Cout,
                   int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws, size_t ws_bytes, sn_stream_t stream);
+/* Several layers' weight gradients in ONE launch (same result as n calls of sn_conv_wgrad): a layer alone has too few output tiles
+ * for 256 CUs and needs split-K partial slabs; a table of layers fills the chip with whole-K jobs.  descs: n entries of sn_wgrad_desc in host
+ * memory, read during the call); scratch from sn_conv_wgrad_batch_workspace_bytes on the same table.  Replaces the weight-gradient
+ * half of the fork's Convolution / FullyConnected backward (symbols/faster/resnet_mx_101_e2e.py:43-66,147-155,288-303). */
+typedef struct sn_wgrad_desc {
+  const void *dy, *x;
+  float *dw;
+  int N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil;
+} sn_wgrad_desc;
+size_t sn_conv_wgrad_batch_workspace_bytes(const sn_wgrad_desc *descs, int n);
+int sn_conv_wgrad_batch(const sn_wgrad_desc *descs, int n, void *ws, size_t ws_bytes, sn_stream_t stream);
+/* A/B and tuning hook: impl 1 = wave-specialised batched kernel (default), 0 = the round-1/2 kernels; job_steps = longest job in
+ * 64-pixel K-steps (0 = built-in).  Set before the workspace query of the launches it affects. */
+int sn_conv_wgrad_impl(int impl, int job_steps);
+/* diagnostics (tools/wgrad_batch_bench.py --trace): per-job phase cycles [jobs][8] x uint64 into buf; NULL = off */
+int sn_conv_wgrad_trace(void *buf);
 /* bias gradient: db[c] += sum_rows dy[r][c].  Row blocks leave partial sums in `ws` (sn_bias_grad_workspace_bytes) and are added in
  * block order -- deterministic, no atomics; without scratch one block per 64 channels walks all rows. */
 size_t sn_bias_grad_workspace_bytes(long rows, int C);

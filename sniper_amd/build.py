@@ -27,7 +27,7 @@ EXTRA = {
     "mask.hip": ["-ffp-contract=off"],
 }
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-        "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"]
+        "-Rpass-analysis=kernel-resource-usage"]
 # the compiler's per-kernel resource remarks (VGPRs, scratch, occupancy, LDS) are kept beside the object: tests/test_kernel_resources.py
 # reads them -- an accumulator tile that silently moved to scratch memory shows up there and nowhere else
 

@@ -747,9 +747,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int MI = 4, NI = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int co0 = blockIdx.x * 128 + (wave >> 1) * 64, ci0 = blockIdx.y * 128 + (wave & 1) * 64;
+  int bx, by, bz;
+  if (!wgrad_block(p, bx, by, bz)) return;
+  const int co0 = bx * 128 + (wave >> 1) * 64, ci0 = by * 128 + (wave & 1) * 64;
   const int taps = p.KH * p.KW;
-  const int tap = blockIdx.z % taps, split = blockIdx.z / taps;
+  const int tap = bz % taps, split = bz / taps;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   if (co0 >= p.Cout || ci0 >= p.Cin) return;  // wave-uniform
   const int cpr = (p.Wo + 31) / 32;  // 32-pixel chunks per (img, oy) row
@@ -852,9 +854,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 128;
+  int bx, by, bz;
+  if (!wgrad_block(p, bx, by, bz)) return;
+  const int co0 = bx * 128, ci0 = by * 128;
   const int taps = p.KH * p.KW;
-  const int tap = blockIdx.z % taps, split = blockIdx.z / taps;
+  const int tap = bz % taps, split = bz / taps;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int cpr = (p.Wo + 31) / 32;  // 32-pixel units per (img, oy) row
   const int nunits = p.N * p.Ho * cpr;
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradParams
   // phase stamps of thread 0 (shader clock): [0] entry, [1] first tile in LDS, [2] contraction done, [3] stores drained
   auto stamp = [&](int k) {
     if (p.trace && tid == 0)
-      p.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memtime();
+      p.trace[((size_t)(bz * p.gy + by) * p.gx + bx) * 8 + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
 
@@ -1068,6 +1072,7 @@ struct WgradPlan {
 // 0 = that kernel off (register-staged kernel instead).  Process-wide.
 static int g_wgrad_flat = env_int("SNIPER_WGRAD_FLAT", -1), g_wgrad_taps = env_int("SNIPER_WGRAD_TAPS", -1);
 static int g_wgrad_wgs = env_int("SNIPER_WGRAD_WGS", 0);   // K-split target (workgroups per launch); 0 = built-in
+int g_wgrad_xcd = env_int("SNIPER_WGRAD_XCD", 1);          // 0 = dispatch-order block mapping (A/B against the XCD-aware one)
 SN_EXPORT int sn_conv_wgrad_tune(int flat_stages, int taps_stages, int target_workgroups) {
   SN_REQUIRE(target_workgroups >= 0 && target_workgroups <= 4096, "sn_conv_wgrad_tune: bad workgroup target");
   g_wgrad_wgs = target_workgroups;
@@ -1124,17 +1129,17 @@ static WgradPlan wgrad_plan(const void *dy, const void *x, int N, int H, int W, 
 
 // Scratch for the split-K partials of sn_conv_wgrad (0 when the layer needs no split).  Without it (or with too little)
 // the layer runs unsplit -- slower, same result modulo summation order; there is no atomic accumulation anywhere.
-SN_EXPORT size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH,
-                                               int KW, int stride, int pad, int dil) {
+static size_t wgrad_legacy_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH,
+                                           int KW, int stride, int pad, int dil) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const WgradPlan q = wgrad_plan(nullptr, nullptr, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil);
   if (q.splits <= 1) return 0;
   return sn_align(sizeof(float) * (size_t)q.splits * Cout * q.taps * Cin);
 }
 
-SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride,
-                            int Cout, int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws,
-                            size_t ws_bytes, sn_stream_t stream) {
+static int wgrad_legacy(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride,
+                        int Cout, int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws,
+                        size_t ws_bytes, hipStream_t s) {
   SN_REQUIRE(dy && x && dw, "sn_conv_wgrad: null pointer");
   WgradParams p;
   p.dy = (const half_t *)dy; p.x = (const half_t *)x; p.dw = dw;
@@ -1155,7 +1160,6 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
     else { q.splits = 1; q.units_per_split = q.nunits + (q.nunits & 1); }   // no scratch: one owner per element, no split
   }
   p.units_per_split = q.units_per_split;
-  hipStream_t s = sn_stream(stream);
   static const bool trace_armed = getenv("SNIPER_CONV_TRACE") != nullptr;
   if (trace_armed) {
     const char *e = getenv("SNIPER_CONV_TRACE_PTR");
@@ -1164,7 +1168,7 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
   if (q.kind) {
     if (int rc = wgrad_dma_launch(p, q.kind, q.stages, q.splits, s)) return rc;
   } else {
-    const dim3 grid(q.gx, q.gy, q.taps * q.splits);
+    const dim3 grid(wgrad_grid(p, q.gx, q.gy, q.taps * q.splits, g_wgrad_xcd != 0));
     if (q.vec_ok) hipLaunchKernelGGL(conv_wgrad_tr_kernel, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
     SN_CHECK_LAUNCH();
@@ -1177,6 +1181,116 @@ SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int
     SN_CHECK_LAUNCH();
   }
   return SN_OK;
+}
+
+// ---- entry points: one layer, or a table of layers in one launch (conv_wgrad_ps.hip) ----
+static int g_wgrad_impl = env_int("SNIPER_WGRAD_IMPL", 1);   // 1 = wave-specialised batched kernel, 0 = the round-1/2 kernels (A/B)
+SN_EXPORT int sn_conv_wgrad_impl(int impl, int job_steps) {
+  SN_REQUIRE((impl == 0 || impl == 1) && job_steps >= 0, "sn_conv_wgrad_impl: impl in {0, 1}, job_steps >= 0");
+  g_wgrad_impl = impl;
+  wgrad_ps_set_job_steps(job_steps);
+  return SN_OK;
+}
+
+// diagnostics: phase timeline of the batched kernel's jobs into buf ([jobs][8] x uint64, see conv_wgrad_ps.hip); NULL = off
+SN_EXPORT int sn_conv_wgrad_trace(void *buf) {
+  wgrad_ps_set_trace(static_cast<unsigned long long *>(buf));
+  return SN_OK;
+}
+
+static bool wgrad_desc_params(const sn_wgrad_desc &d, WgradParams &p) {
+  p.dy = (const half_t *)d.dy; p.x = (const half_t *)d.x; p.dw = d.dw;
+  p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.dy_ps = d.dy_pix_stride; p.x_ps = d.x_pix_stride;
+  p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad; p.dil = d.dil;
+  if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 || d.KW <= 0 || d.stride <= 0 || d.dil <= 0) return false;
+  p.Ho = (d.H + 2 * d.pad - d.dil * (d.KH - 1) - 1) / d.stride + 1;
+  p.Wo = (d.W + 2 * d.pad - d.dil * (d.KW - 1) - 1) / d.stride + 1;
+  p.slab = nullptr; p.slab_stride = 0; p.units_per_split = 0;
+  return p.Ho > 0 && p.Wo > 0;
+}
+
+// launch == false: only the scratch size.  Scratch layout: the split-K slabs of every chunk of <= 24 batched problems, then the
+// scratch of each problem that runs on the round-1/2 kernels (operands not 16-byte addressable, or the A/B switch).
+static int wgrad_batch_run(const sn_wgrad_desc *descs, int n, void *ws, size_t ws_bytes, hipStream_t s, bool launch, size_t *need) {
+  size_t off = 0;
+  WgradParams chunk[kWgradMaxProblems];
+  int nc = 0;
+  auto flush = [&]() -> int {
+    if (!nc) return SN_OK;
+    WgradBatch tab;
+    char *base = ws ? static_cast<char *>(ws) + off : nullptr;
+    size_t bytes = wgrad_ps_plan(chunk, nc, tab, base);
+    if (launch) {
+      // too little scratch (or none): the chunk runs unsplit -- slower, same result modulo summation order, never atomics
+      if (bytes && !(ws && off + bytes <= ws_bytes && ((uintptr_t)base % 16) == 0)) bytes = wgrad_ps_plan(chunk, nc, tab, nullptr, false);
+      if (int rc = wgrad_ps_launch(tab, s)) return rc;
+    }
+    off += bytes;
+    nc = 0;
+    return SN_OK;
+  };
+  // chunks: <= 24 problems (the table is a kernel argument), cut where the job count fills whole rounds of the 256 CUs -- a chunk
+  // of 528 equal jobs runs as long as one of 768; one of 492 runs like 512
+  long jobs = 0;
+  auto fill = [](long j) { return j <= 0 ? 0.0 : (double)j / (256.0 * (double)((j + 255) / 256)); };
+  for (int i = 0; i < n; ++i) {
+    const sn_wgrad_desc &d = descs[i];
+    WgradParams p;
+    SN_REQUIRE(wgrad_desc_params(d, p), "sn_conv_wgrad_batch: bad dims in problem %d", i);
+    if (launch) SN_REQUIRE(d.dy && d.x && d.dw, "sn_conv_wgrad_batch: null pointer in problem %d", i);
+    if (g_wgrad_impl == 1 && wgrad_ps_ok(p)) {
+      const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+      const long steps = flat ? sn_div_up(sn_div_up(p.N * p.H * p.W, 32), 2) : sn_div_up(p.N * p.Ho * sn_div_up(p.Wo, 32), 2);
+      const long j = (long)sn_div_up(p.Cout, 128) * sn_div_up(p.Cin, 128) * p.KH * p.KW * ((steps + 399) / 400);
+      if (nc && jobs >= 200 && fill(jobs) >= 0.93 && fill(jobs + j) < fill(jobs) - 0.02) {
+        if (int rc = flush()) return rc;
+        jobs = 0;
+      }
+      chunk[nc++] = p;
+      jobs += j;
+      if (nc == kWgradMaxProblems) {
+        if (int rc = flush()) return rc;
+        jobs = 0;
+      }
+    } else {
+      const size_t bytes = wgrad_legacy_workspace_bytes(d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad, d.dil);
+      if (launch) {
+        char *base = ws ? static_cast<char *>(ws) + off : nullptr;
+        const size_t have = ws && off + bytes <= ws_bytes ? bytes : 0;
+        if (int rc = wgrad_legacy(d.dy, d.x, d.dw, d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad,
+                                  d.dil, have ? base : nullptr, have, s))
+          return rc;
+      }
+      off += bytes;
+    }
+  }
+  if (int rc = flush()) return rc;
+  if (need) *need = off;
+  return SN_OK;
+}
+
+SN_EXPORT size_t sn_conv_wgrad_batch_workspace_bytes(const sn_wgrad_desc *descs, int n) {
+  size_t need = 0;
+  if (!descs || n <= 0 || wgrad_batch_run(descs, n, nullptr, 0, nullptr, false, &need)) return 0;
+  return need;
+}
+
+SN_EXPORT int sn_conv_wgrad_batch(const sn_wgrad_desc *descs, int n, void *ws, size_t ws_bytes, sn_stream_t stream) {
+  SN_REQUIRE(descs && n > 0, "sn_conv_wgrad_batch: empty table");
+  return wgrad_batch_run(descs, n, ws, ws_bytes, sn_stream(stream), true, nullptr);
+}
+
+SN_EXPORT size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH,
+                                               int KW, int stride, int pad, int dil) {
+  const sn_wgrad_desc d = {nullptr, nullptr, nullptr, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil};
+  return sn_conv_wgrad_batch_workspace_bytes(&d, 1);
+}
+
+SN_EXPORT int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride,
+                            int Cout, int dy_pix_stride, int KH, int KW, int stride, int pad, int dil, void *ws,
+                            size_t ws_bytes, sn_stream_t stream) {
+  const sn_wgrad_desc d = {dy, x, dw, N, H, W, Cin, x_pix_stride, Cout, dy_pix_stride, KH, KW, stride, pad, dil};
+  return sn_conv_wgrad_batch(&d, 1, ws, ws_bytes, stream);
 }
 
 // Weight gradient of the stem convolution on the packed input of sn_pack_stem_input (MobileNetV2's first 3x3/2 conv
@@ -1217,7 +1331,7 @@ SN_EXPORT int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int 
     else { splits = 1; p.units_per_split = N * Ho * sn_div_up(Wo, 32); }   // no scratch: unsplit, one owner per element
   }
   hipStream_t s = sn_stream(stream);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, KH * splits), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_grid(p, gx, gy, KH * splits)), dim3(256), 0, s, p);
   SN_CHECK_LAUNCH();
   if (p.slab) {
     long blocks = (long)((n / 4 + 255) / 256);

@@ -50,7 +50,51 @@ struct WgradParams {
   unsigned long long *trace = nullptr;   // phase timeline (tools/conv_trace.py --wgrad; SNIPER_CONV_TRACE), normally null
   float *slab;          // split-K partials [split][Cout][taps][Cin] (plain stores, reduced by wgrad_reduce_kernel) or null
   size_t slab_stride;   // elements per split
+  // logical grid (tile columns, tile rows, taps x splits).  The launch is one-dimensional and XCD-aware: hardware block b runs
+  // on XCD b % 8, and every XCD is handed a CONTIGUOUS range of the split-major item list, so the tiles that share one
+  // K-split's dY / X panels fetch them through ONE L2 (wgrad_block() below)
+  int gx, gy, gz, per_xcd;
 };
+
+// logical block index of a weight-gradient workgroup; false = surplus block of the rounded-up launch
+__device__ __forceinline__ bool wgrad_block(const WgradParams &p, int &bx, int &by, int &bz) {
+  const int b = blockIdx.x;
+  const int item = p.per_xcd ? (b & 7) * p.per_xcd + (b >> 3) : b;   // per_xcd = 0: dispatch order (A/B runs)
+  const int tiles = p.gx * p.gy;
+  if (item >= tiles * p.gz) return false;
+  bz = item / tiles;
+  const int r = item - bz * tiles;
+  by = r / p.gx;
+  bx = r - by * p.gx;
+  return true;
+}
+static inline unsigned wgrad_grid(WgradParams &p, int gx, int gy, int gz, bool xcd_aware = true) {
+  p.gx = gx; p.gy = gy; p.gz = gz;
+  p.per_xcd = xcd_aware ? (gx * gy * gz + 7) / 8 : 0;
+  return xcd_aware ? 8u * (unsigned)p.per_xcd : (unsigned)(gx * gy * gz);
+}
+
+// ---- wave-specialised, batched weight gradient (conv_wgrad_ps.hip) ----
+struct WgradProblem {
+  const half_t *dy, *x;
+  float *dw, *slab;          // slab: split-K partials [split][Cout][taps][Cin] of this problem, or null (unsplit: dw += tile)
+  size_t slab_stride;        // Cout * taps * Cin
+  int N, H, W, Ho, Wo, Cin, Cout, dy_ps, x_ps, KH, KW, stride, pad, dil;   // a flat problem (1x1 / s1 / p0, FC) is one row of N*H*W pixels
+  int gx, gy, taps, splits, units_per_split, cpr, nunits, item0;            // jobs [split][tap][ci tile][co tile] start at item0
+};
+constexpr int kWgradMaxProblems = 24;     // 24 x 128 B + header < the 4 KB kernel-argument segment
+struct WgradBatch {
+  int n, total_items, per_xcd, reserved;
+  int xcd_start[9];            // XCD x runs jobs [xcd_start[x], xcd_start[x + 1]): contiguous, about equal K-steps each
+  int reserved2;
+  unsigned long long *trace;   // phase timeline of every job (diagnostics), normally null
+  WgradProblem p[kWgradMaxProblems];
+};
+bool wgrad_ps_ok(const WgradParams &p);                                           // operands 16-byte addressable, < 1 GB each
+size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bool allow_split = true);   // -> scratch bytes of the split problems
+int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s);
+void wgrad_ps_set_job_steps(int steps);
+void wgrad_ps_set_trace(unsigned long long *buf);
 
 // LDS-DMA weight-gradient kernels.  kind 1: "flat" contraction over one long row of pixels (1x1 / stride 1 / pad 0
 // convolutions, FullyConnected, the deformable convolution's column GEMM), 128 (co) x 128 (ci) tile per workgroup,

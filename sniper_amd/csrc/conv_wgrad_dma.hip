@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256, MINW) void wgrad_flat_dma_kernel(const WgradPa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 128, split = blockIdx.z;
+  int bx, by, split;
+  if (!wgrad_block(p, bx, by, split)) return;
+  const int co0 = bx * 128, ci0 = by * 128;
   const long px_begin = (long)split * p.units_per_split * 32;
   long px_end = px_begin + (long)p.units_per_split * 32;
   if (px_end > p.W) px_end = p.W;
@@ -182,7 +184,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_dma_kernel(const WgradParam
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64, split = blockIdx.z;
+  int bx, by, split;
+  if (!wgrad_block(p, bx, by, split)) return;
+  const int co0 = bx * 64, ci0 = by * 64;
   const int cpr = (p.Wo + 31) / 32;
   const int nunits = p.N * p.Ho * cpr;
   const int u_begin = split * p.units_per_split, u_end = min(nunits, u_begin + p.units_per_split);
@@ -312,13 +316,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_dma_kernel(const WgradParam
 }
 
 // kind 1 / 2 as in conv_common.h; stages: 2..4 (flat: 2 or 3; taps: 3 or 4)
-int wgrad_dma_launch(const WgradParams &p, int kind, int stages, int splits, hipStream_t s) {
+extern int g_wgrad_xcd;
+int wgrad_dma_launch(const WgradParams &p_in, int kind, int stages, int splits, hipStream_t s) {
+  WgradParams p = p_in;
   if (kind == 1) {
-    const dim3 grid(sn_div_up(p.Cout, 128), sn_div_up(p.Cin, 128), splits);
+    const dim3 grid(wgrad_grid(p, sn_div_up(p.Cout, 128), sn_div_up(p.Cin, 128), splits, g_wgrad_xcd != 0));
     if (stages == 3) hipLaunchKernelGGL((wgrad_flat_dma_kernel<3, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_flat_dma_kernel<2, 2>), grid, dim3(256), 0, s, p);
   } else {
-    const dim3 grid(sn_div_up(p.Cout, 64), sn_div_up(p.Cin, 64), splits);
+    const dim3 grid(wgrad_grid(p, sn_div_up(p.Cout, 64), sn_div_up(p.Cin, 64), splits, g_wgrad_xcd != 0));
     if (stages == 4) hipLaunchKernelGGL((wgrad_taps_dma_kernel<4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_taps_dma_kernel<3>), grid, dim3(256), 0, s, p);
   }

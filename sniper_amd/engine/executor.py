@@ -159,6 +159,14 @@ class Executor(object):
         self.use_side_stream = for_training and os.environ.get('SNIPER_WGRAD_STREAM', '0') == '1' and self.device.type == 'cuda'
         self._keepalive = []
         self._side_reads = set()     # storages the side stream may still be reading (see grad_slot)
+        # Weight gradients are DEFERRED and launched as tables of layers (sn_conv_wgrad_batch): one stage-3 layer has 16-36
+        # output tiles, so alone it needs a 7-16-way K split with fp32 partial slabs; a few dozen layers per launch fill the
+        # 256 CUs with whole-K jobs (csrc/conv_wgrad_ps.hip).  A queued layer keeps its dY / X tensors alive; a dY that another
+        # Val would accumulate into IN PLACE before the flush (the residual trunk's shared gradient) is protected by
+        # grad_slot (out-of-place accumulation).  SNIPER_WGRAD_DEFER=0: launch per layer, at the layer's backward.
+        self.defer_wgrads = for_training and os.environ.get('SNIPER_WGRAD_DEFER', '1') != '0' and not self.use_side_stream
+        self._pending_wgrads = []    # [(dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil)]
+        self._pending_reads = set()  # storages queued weight gradients still have to read
         self._graph_fb = self._graph_up = None
         self._eager_fb = self._eager_up = 0
 
@@ -216,13 +224,15 @@ class Executor(object):
 
     # ---- gradient plumbing -------------------------------------------------------------------
     def grad_slot(self, v):
-        """-> (tensor in v's own format, accumulate?).  First writer overwrites, later ones add (in place).
+        """-> (dst, src): the tensor (v's own format) the caller writes v's gradient contribution into, and the tensor it adds
+        to it (None for the first writer; normally dst itself -- later writers add in place).
         A gradient tensor can be shared: a residual add hands the SAME tensor to both operands (add_grad), so the tensor
-        about to be accumulated into may be the dY a convolution's weight-gradient kernels are still reading on the side
-        stream.  If it was handed to the side stream, the main stream waits for the side stream first."""
+        about to be accumulated into may be the dY of a convolution whose weight gradient has not run yet: queued for a
+        batched launch (then the sum goes to a fresh tensor, src = the old one, which the queue keeps alive), or running on the
+        side stream (then the main stream waits for the side stream first)."""
         if v.grad is None:
             v.grad = self.empty(v.t.shape, v.t.dtype)
-            return v.grad, False
+            return v.grad, None
         # copy on write: the tensor is also the (not yet consumed) gradient of the residual add's other operand.  In ResNet /
         # MobileNetV2 that operand's producer has run its backward and dropped the tensor by now (no copy); any other
         # graph order gets a private copy instead of a silently corrupted dY.
@@ -237,7 +247,30 @@ class Executor(object):
             ev.record(self.side_stream)
             torch.cuda.current_stream().wait_event(ev)
             self._side_reads.clear()
-        return v.grad, True
+        if self._pending_reads and v.grad.untyped_storage().data_ptr() in self._pending_reads:
+            src = v.grad
+            v.grad = self.empty(src.shape, src.dtype)
+            return v.grad, src
+        return v.grad, v.grad
+
+    def queue_wgrad(self, *problem):
+        """problem = the arguments of sn_conv_wgrad up to `dil` (tensors dy, x, dw first)."""
+        self._pending_wgrads.append(problem)
+        for t in problem[:2]:
+            self._pending_reads.add(t.untyped_storage().data_ptr())
+        if len(self._pending_wgrads) >= 160:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        if not self._pending_wgrads:
+            return
+        tab = hip.wgrad_table(self._pending_wgrads)
+        n = len(self._pending_wgrads)
+        need = hip.query('sn_conv_wgrad_batch_workspace_bytes', tab, n)
+        ws = self.ws.get(need) if need else None
+        hip.call('sn_conv_wgrad_batch', tab, n, ws, need, hip.stream())
+        self._pending_wgrads = []
+        self._pending_reads.clear()
 
     def add_grad(self, v, g, g_fmt):
         """Accumulate gradient tensor g (format g_fmt: 'act' NHWC fp16 or 'f32' reference order) into v."""
@@ -651,6 +684,7 @@ class Executor(object):
         steps = self.steps if segment is None else (self.steps[k:] if segment == 'a' else self.steps[:k])
         for s in reversed(steps):
             s.backward()
+        self.flush_wgrads()                       # the optimizer / all-reduce of this segment read the gradient arena next
         if segment in (None, 'b'):
             for v in self.vals.values():
                 v.grad = None

@@ -155,19 +155,16 @@ class BatchNormStep(Step):
         # gamma/beta keeps its folded scale/shift
         if not (only_trainable and self.global_stats and not self.gamma.trainable and not self.beta.trainable):
             self._global_ready = False
-            if self.global_stats:
+            if self.global_stats or not self.ex.for_training:
                 # fold the moving statistics NOW (persistent buffers): a forward pass that is a hipGraph replay never comes
-                # back to Python, so a lazy recompute after set_params / a checkpoint load would keep the stale scale / shift
+                # back to Python, so a lazy recompute after set_params / a checkpoint load would keep the stale scale / shift.
+                # A test-time executor normalises EVERY layer with the moving statistics, whatever use_global_stats says
+                # (MobileNetV2's BatchNorm after the depthwise convolutions is neither global-stats nor folded).
                 g = None if self.fix_gamma else self.gamma.master
                 hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
                          self.shift, hip.stream())
                 self._global_ready = True
         if self.folded_into is not None:
-            if not self.global_stats:        # (a test-time executor normalises with the moving statistics whatever the flag says)
-                g = None if self.fix_gamma else self.gamma.master
-                hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
-                         self.shift, hip.stream())
-                self._global_ready = True
             self.folded_into.refold(self.scale, self.shift)
 
     def _use_batch_stats(self):
@@ -214,18 +211,18 @@ class BatchNormStep(Step):
         n, h, w, c = self.x.nhwc()
         M = n * h * w
         x = ex.as_act(self.x)
-        dx, acc = (None, False)
+        dx, acc = (None, None)
         if self.x.needs_grad:
-            dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty(x.shape, F16), False)
+            dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty(x.shape, F16), None)
         dg = self.gamma.grad if self.gamma.trainable else None
         db = self.beta.grad if self.beta.trainable else None
         if self.bwd_partials is not None:       # sum g, sum g*(x-mean) came out of the consumer's data-gradient epilogue
             part, nblk = self.bwd_partials
             self.bwd_partials = None
-            hip.call('sn_bn_backward_blocks', part, nblk, self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale,
+            hip.call('sn_bn_backward_blocks', part, nblk, self.y.grad, x, acc, dx, M, c, c, c, c, c, self.scale,
                      self.shift, self.save_mean, self.save_invstd, self.act, self.bws, dg, db, hip.stream())
         else:
-            hip.call('sn_bn_backward', self.y.grad, x, dx if acc else None, dx, M, c, c, c, c, c, self.scale, self.shift,
+            hip.call('sn_bn_backward', self.y.grad, x, acc, dx, M, c, c, c, c, c, self.scale, self.shift,
                      self.save_mean, self.save_invstd, self.act, self.bws, dg, db, hip.stream())
         if self.x.needs_grad and self.x.fmt != 'act':
             ex.add_grad(self.x, dx, 'act')
@@ -261,7 +258,7 @@ class ActivationStep(Step):
         n, h, w, c = self.x.nhwc()
         if self.x.fmt == 'act':
             dx, acc = self.ex.grad_slot(self.x)
-            hip.call('sn_ew_f16', self.y.grad, dx if acc else None, self.y.t, dx, n * h * w, c, c, c, c, c, 2, hip.stream())
+            hip.call('sn_ew_f16', self.y.grad, acc, self.y.t, dx, n * h * w, c, c, c, c, c, 2, hip.stream())
         else:
             tmp = self.ex.empty(self.y.t.shape, F16)
             hip.call('sn_ew_f16', self.y.grad, None, self.y.t, tmp, n * h * w, c, c, c, c, c, 2, hip.stream())
@@ -310,7 +307,7 @@ class ClipStep(Step):
         x = self.ex.as_act(self.x)
         if self.x.fmt == 'act':
             dx, acc = self.ex.grad_slot(self.x)
-            hip.call('sn_clip_f16', self.y.grad, x, dx if acc else None, dx, n * h * w, c, c, c, c, c, self.lo, self.hi, 1,
+            hip.call('sn_clip_f16', self.y.grad, x, acc, dx, n * h * w, c, c, c, c, c, self.lo, self.hi, 1,
                      hip.stream())
         else:
             tmp = self.ex.empty(self.y.t.shape, F16)
@@ -323,7 +320,11 @@ class ClipStep(Step):
 # Convolution / FullyConnected on the implicit-GEMM MFMA kernels
 # ---------------------------------------------------------------------------------------------
 def _wgrad(ex, dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil):
-    """sn_conv_wgrad with the executor's shared split-K scratch (deterministic, atomic-free reduction)."""
+    """sn_conv_wgrad with the executor's shared split-K scratch (deterministic, atomic-free reduction) -- or, by default, queued
+    for the executor's next batched launch (Executor.flush_wgrads)."""
+    if ex.defer_wgrads:
+        ex.queue_wgrad(dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil)
+        return
     need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil)
     ws = ex.ws.get(need) if need else None
     hip.call('sn_conv_wgrad', dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil, ws, need, hip.stream())
@@ -411,7 +412,7 @@ class _GemmLike(Step):
         if self.x.needs_grad:
             if self.x.fmt == 'act':
                 dx, acc = ex.grad_slot(self.x)
-                self.launch_dgrad(dy, Op, dx if acc else None, dx)
+                self.launch_dgrad(dy, Op, acc, dx)
             else:
                 dx = ex.empty(self.x_shape_nhwc(), F16)
                 self.launch_dgrad(dy, Op, None, dx)
@@ -1137,8 +1138,8 @@ class DeconvolutionStep(Step):
             ex.on_side(lambda: _wgrad(ex, dtmp, x, self.w.grad, self.N, self.H, self.W, self.C, self.C, O4, O4, 1, 1, 1, 0, 1),
                        keep=(dtmp, x))
         if self.x.needs_grad:
-            dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty((self.N, self.H, self.W, self.C), F16), False)
-            hip.call('sn_conv_dgrad', dtmp, self.w.wT16, dx if acc else None, dx, self.N, self.H, self.W, self.C, self.C, O4, O4, self.C,
+            dx, acc = ex.grad_slot(self.x) if self.x.fmt == 'act' else (ex.empty((self.N, self.H, self.W, self.C), F16), None)
+            hip.call('sn_conv_dgrad', dtmp, self.w.wT16, acc, dx, self.N, self.H, self.W, self.C, self.C, O4, O4, self.C,
                      1, 1, 1, 0, 1, 0, hip.stream())
             if self.x.fmt != 'act':
                 ex.add_grad(self.x, dx, 'act')
@@ -1166,7 +1167,9 @@ class PickStep(Step):
             return
         n, h, w, c = self.x.nhwc()
         dx, acc = self.ex.grad_slot(self.x)
-        hip.call('sn_pick_bwd', self.y.grad, self.ex.as_f32(self.idx), dx, n, h * w, c, 1 if acc else 0, hip.stream())
+        if acc is not None and acc is not dx:        # the scatter adds in place: bring the earlier contributions over first
+            hip.call('sn_copy2d', acc, dx, 1, acc.numel(), acc.numel(), acc.numel(), 0, 0, hip.stream())
+        hip.call('sn_pick_bwd', self.y.grad, self.ex.as_f32(self.idx), dx, n, h * w, c, 1 if acc is not None else 0, hip.stream())
         self.y.grad = None
 
 

@@ -45,6 +45,21 @@ def query(name, *args):
     return lib().raw(name)(*[_conv(a) for a in args])
 
 
+class WgradDesc(ctypes.Structure):
+    """sn_wgrad_desc (include/sniper_hip.h): one layer of a batched weight-gradient launch."""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int) for k in ("N", "H", "W", "Cin", "x_pix_stride", "Cout", "dy_pix_stride", "KH", "KW", "stride", "pad", "dil")]
+
+
+def wgrad_table(problems):
+    """[(dy, x, dw, N, H, W, Cin, x_ps, Cout, dy_ps, KH, KW, stride, pad, dil)] -> ctypes array of sn_wgrad_desc (tensors or None)."""
+    arr = (WgradDesc * len(problems))()
+    for d, pr in zip(arr, problems):
+        d.dy, d.x, d.dw = [t.data_ptr() if isinstance(t, torch.Tensor) else None for t in pr[:3]]
+        (d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad, d.dil) = [int(v) for v in pr[3:]]
+    return arr
+
+
 def dev(x, dtype=None, device=None):
     """numpy / tensor -> contiguous device tensor."""
     device = device or require_gpu()

@@ -301,3 +301,60 @@ def test_inference_batchnorm_folds_into_the_producing_convolution():
     plain.forward(batch, is_train=False)
     u, v = folded.get_outputs()[0].asnumpy(), plain.get_outputs()[0].asnumpy()
     assert np.abs(u - v).max() / max(np.abs(v).max(), 1e-6) < 4e-3 and not np.allclose(u, a[0])
+
+
+def test_set_params_after_capture_reaches_unfolded_batch_statistics_layers():
+    """a test-time executor normalises use_global_stats=False layers with the moving statistics too; when such a
+    layer is NOT folded into its producer (here: its input has a second reader), its scale / shift used to be recomputed
+    lazily in forward() -- which a hipGraph replay never reaches.  New parameters after the capture must change the replayed
+    output exactly as they change an eager executor's."""
+    import os
+    import sniper_amd.mx as mx
+    d = mx.sym.Variable('data')
+    c1 = mx.sym.Convolution(data=d, kernel=(1, 1), num_filter=64, no_bias=True, name='c1')
+    b1 = mx.sym.BatchNorm(data=c1, fix_gamma=False, eps=2e-5, use_global_stats=False, name='b1')     # c1 has two readers: not folded
+    r1 = mx.sym.Activation(data=b1, act_type='relu', name='r1')
+    out = mx.sym.Group([r1, c1])
+    shapes = [('data', (2, 64, 16, 24))]
+    rs = np.random.RandomState(11)
+
+    def module(graphs):
+        old = os.environ.get('SNIPER_HIP_GRAPHS')
+        os.environ['SNIPER_HIP_GRAPHS'] = '1' if graphs else '0'
+        try:
+            mod = mx.mod.Module(symbol=out, context=[mx.gpu(0)], data_names=['data'], label_names=None)
+            mod.bind(shapes, None, for_training=False)
+        finally:
+            if old is None:
+                del os.environ['SNIPER_HIP_GRAPHS']
+            else:
+                os.environ['SNIPER_HIP_GRAPHS'] = old
+        return mod
+    graphed, eager = module(True), module(False)
+    exe = next(iter(graphed._exes.values()))
+    assert all(getattr(s, 'folded_into', None) is None for s in exe.steps)
+    arg = {'c1_weight': mx.nd.array((rs.standard_normal((64, 64, 1, 1)) * 0.2).astype(np.float32)),
+           'b1_gamma': mx.nd.array(rs.uniform(0.5, 1.5, (64,)).astype(np.float32)),
+           'b1_beta': mx.nd.array((rs.standard_normal((64,)) * 0.3).astype(np.float32))}
+    aux = {'b1_moving_mean': mx.nd.array((rs.standard_normal((64,)) * 0.2).astype(np.float32)),
+           'b1_moving_var': mx.nd.array(rs.uniform(0.5, 2.0, (64,)).astype(np.float32))}
+    for m in (graphed, eager):
+        m.init_params(arg_params=arg, aux_params=aux)
+    x = mx.nd.array(rs.standard_normal(shapes[0][1]).astype(np.float32))
+    batch = mx.io.DataBatch(data=[x], label=None, pad=0, index=None, provide_data=shapes, provide_label=None)
+    for call in range(3):            # eager, capture, replay
+        graphed.forward(batch, is_train=False)
+        eager.forward(batch, is_train=False)
+    before = graphed.get_outputs()[0].asnumpy().copy()
+    assert exe._infer_graph is not None
+    assert np.array_equal(before, eager.get_outputs()[0].asnumpy())
+    arg2 = dict(arg, b1_gamma=mx.nd.array(arg['b1_gamma'].asnumpy() * 0.25), b1_beta=mx.nd.array(arg['b1_beta'].asnumpy() + 0.5))
+    aux2 = dict(aux, b1_moving_mean=mx.nd.array(aux['b1_moving_mean'].asnumpy() - 0.3))
+    for m in (graphed, eager):
+        m.set_params(arg2, aux2)
+    graphed.forward(batch, is_train=False)
+    eager.forward(batch, is_train=False)
+    after, want = graphed.get_outputs()[0].asnumpy(), eager.get_outputs()[0].asnumpy()
+    assert exe._infer_graph is not None          # still the replayed graph
+    assert np.array_equal(after, want)
+    assert not np.allclose(after, before)

@@ -73,7 +73,11 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (see tools/conv_tune.py)')
+    ap.add_argument('--modes', default='', help='e.g. "-1/-1/0,0/0/256" (flat stages / taps stages / workgroup target)')
     a = ap.parse_args()
+    global MODES
+    if a.modes:
+        MODES = [tuple(int(v) for v in m.split('/')) for m in a.modes.split(',')]
     d = torch.device('cuda', 0)
     B = a.batch
     g = torch.Generator(device=d)
