@@ -58,6 +58,15 @@ def conv_flops(name, a):
         N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[4:17]
     elif name == 'sn_conv_wgrad':
         N, H, W, Cin, _, Cout, _, KH, KW, s, p, d = a[3:15]
+    elif name == 'sn_conv_wgrad_batch':          # a table of layers (sniper_amd.hip.wgrad_table), one launch per <= 24 of them
+        tab, n = a[0], a[1]
+        tot = 0.0
+        for i in range(n):
+            d = tab[i]
+            Ho = (d.H + 2 * d.pad - d.dil * (d.KH - 1) - 1) // d.stride + 1
+            Wo = (d.W + 2 * d.pad - d.dil * (d.KW - 1) - 1) // d.stride + 1
+            tot += 2.0 * d.N * Ho * Wo * d.Cout * d.Cin * d.KH * d.KW
+        return tot
     elif name == 'sn_conv_stem_fwd':
         N, Hp, Wp, Ho, Wo, Cout, _, KH, KWP, s = a[4:14]
         return 2.0 * N * Ho * Wo * Cout * KH * 7 * 3   # real 7x7x3 taps (the padded ones are zeros)
@@ -71,7 +80,7 @@ def conv_flops(name, a):
 class ConvProfiler(object):
     """Wraps sniper_amd.hip.call: brackets every conv-family launch with HIP events recorded on the
     stream the kernel is launched on (torch's current stream)."""
-    NAMES = ('sn_conv_fwd', 'sn_conv_fwd_stats', 'sn_conv_dgrad', 'sn_conv_dgrad_bn', 'sn_conv_wgrad', 'sn_conv_stem_fwd')
+    NAMES = ('sn_conv_fwd', 'sn_conv_fwd_stats', 'sn_conv_dgrad', 'sn_conv_dgrad_bn', 'sn_conv_wgrad', 'sn_conv_wgrad_batch', 'sn_conv_stem_fwd')
 
     def __init__(self):
         from sniper_amd import hip
@@ -151,6 +160,7 @@ def pmc_traffic():
             d = json.load(fh)
         if d.get('conv_sources_hash') != conv_sources_hash():
             return None
+        pmc_traffic.detail = {k: d.get(k) for k in ('hbm_bytes_per_step', 'kernel_launches_per_step', 'launches', 'steps')}
         return d.get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         return None
@@ -419,15 +429,16 @@ def main():
     isolated = iso_fl / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
     n_launch = sum(v[0] for v in per.values())
     roof = {'bound': 'mfma',
-            'kernel': 'conv_dma_kernel<DGRAD,BM,BN,...> / conv_igemm_p2_kernel / conv_wgrad_tr_kernel / wgrad_{flat,taps}_dma_kernel '
-                      '(+ conv_igemm_kernel for narrow layers, wgrad_reduce_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_dgrad_bn, sn_conv_wgrad',
+            'kernel': 'conv_dma_kernel<DGRAD,BM,BN,...> / conv_igemm_p2_kernel / wgrad_ps_kernel (+ conv_igemm_kernel for narrow layers, '
+                      'wgrad_reduce2_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_dgrad_bn, sn_conv_wgrad_batch',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
             'mode': 'in situ (eager replay of the timed step, weight gradients on the side stream: %s); sum of launch durations as '
                     'rocprofv3 --kernel-trace --stats reports them' % bool(side),
             'achieved_isolated': round(isolated, 2), 'frac_isolated': round(isolated / MFMA_PEAK_TFLOPS, 4),
             'step_tflops': round(tot_fl / 2 / (ms_per_step * 1e-3) / 1e12, 2), 'event_bracket_overhead_us': round(profile.overhead_us, 2),
-            'traffic': pmc_traffic(),
-            'launches_per_step': n_launch // 2,
+            'traffic': pmc_traffic(),         # HBM bytes per KERNEL launch of the family (incl. the slab-reduce kernels)
+            'traffic_detail': getattr(pmc_traffic, 'detail', None),
+            'entry_calls_per_step': n_launch // 2,   # C-ABI calls bracketed with events (one batched weight-gradient call = up to 24 layers)
             'avg_launch_ms': round(tot_ms / max(1, n_launch), 4),
             'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
             'conv_ms_per_step_isolated': round(iso_ms / 2, 3),

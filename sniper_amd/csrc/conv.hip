@@ -522,6 +522,11 @@ static int conv_dma_choice_balanced(int M, int Nout, int nk, bool dgrad) {
   if (M < 8192) return (Nout >= 1024 && nk >= 128) ? 4 : 6;   // FullyConnected over 6000 RoIs
   static const int bal = env_int("SNIPER_CONV_BAL", 14), bal_d = env_int("SNIPER_CONV_BAL_D", 16);
   if (nk <= 1) return 6;                              // stage 1: a single K-step, all epilogue
+  // round 3: long contractions with about one 160 x 128 tile per CU take the producer / consumer specialised kernel (cfg 18):
+  // its K loop is ~1.3x faster (profiles/r03_conv_tune_ps.txt: stage-3 3x3 38 -> 30 us, 1x1 1024 -> 256 24 -> 21 us), but it is one
+  // 8-wave workgroup per CU, so short contractions with 4 tiles per CU -- all fill and epilogue -- lose (32 -> 47 us)
+  static const int ps = env_int("SNIPER_CONV_PS", 18), ps_nk = env_int("SNIPER_CONV_PS_NK", 16);
+  if (ps > 0 && nk >= ps_nk && (long)sn_div_up(M, 160) * sn_div_up(Nout, 128) <= 320) return ps;
   return dgrad ? bal_d : bal;
 }
 

@@ -35,7 +35,7 @@ struct ConvParams {
 
 // LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: 1..kConvDmaConfigs, see conv_dma_config().
 struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };
-constexpr int kConvDmaConfigs = 17;
+constexpr int kConvDmaConfigs = 20;
 ConvDmaConfig conv_dma_config(int cfg);
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
 

@@ -49,21 +49,29 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW>
-__global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const ConvParams p, int mtiles, int ntiles) {
-  constexpr int NW = WMW * WNW, T = 64 * NW, BK = 64;
+// PS ("producer / consumer specialised", round 3): the workgroup has WMW x WNW CONSUMER waves (one per SIMD for 2 x 2) that only read
+// fragments and multiply, plus four PRODUCER waves (the second wave of each SIMD) that only compute gather addresses and issue the
+// LDS-DMA pieces, S - 1 stages ahead.  A wave's instruction stream is in order, so in the unspecialised kernel a K-step costs
+// DMA issue (~70 cycles per piece) PLUS the MFMAs (tools/probes/dma_rate_probe.hip); with the two jobs in different waves a step
+// costs the longer of the two (the same split made the weight gradient's K loop 2x faster: conv_wgrad_ps.hip).  The consumers keep
+// the two 32-channel halves of a K-step in two register sets; the step's barrier sits between the two MFMA blocks and every set is
+// re-read for the next half right behind the block that used it, so no step begins with barrier -> ds_read -> wait.
+template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false>
+__global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dma_kernel(const ConvParams p, int mtiles, int ntiles) {
+  constexpr int NW = WMW * WNW, T = 64 * (NW + (PS ? 4 : 0)), BK = 64;
+  constexpr int NL = PS ? 4 : NW;                       // waves that stage the tiles
   constexpr int WTM = BM / WMW, WTN = BN / WNW;   // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int PA = BM / 8, PB = BN / 8;               // 8-row DMA groups (1 KB pieces) of the two operand tiles
-  constexpr int AGW = (PA + NW - 1) / NW, BGW = (PB + NW - 1) / NW;   // ... per wave
-  constexpr int L = AGW + BGW;                          // DMA instructions per wave per stage
+  constexpr int AGW = (PA + NL - 1) / NL, BGW = (PB + NL - 1) / NL;   // ... per staging wave
+  constexpr int L = AGW + BGW;                          // DMA instructions per staging wave per stage
   constexpr int STAGE = (BM + BN) * BK;                 // half_t elements per stage
   constexpr bool kPingPong = NW == 8 && S >= 3;         // see the K loop
   // Every wave issues exactly L pieces per stage (the counted s_waitcnt needs one number): where the groups do not divide
   // over the waves, a wave without a group of its own in the last round fetches its previous group once more (same
   // bytes to the same LDS address).
   static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile / wave shape");
-  static_assert(PA >= NW * (AGW - 1) + 1 && PB >= NW * (BGW - 1) + 1 && (AGW == 1 ? PA >= NW : true) && (BGW == 1 ? PB >= NW : true),
+  static_assert(PA >= NL * (AGW - 1) + 1 && PB >= NL * (BGW - 1) + 1 && (AGW == 1 ? PA >= NL : true) && (BGW == 1 ? PB >= NL : true),
                 "a wave's repeated piece must exist");
   static_assert((S - 1) * L < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE];
@@ -78,7 +86,10 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   stamp(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WNW, wn = wave % WNW;
+  const bool producer = PS && wave >= NW;
+  const int lw = PS ? (producer ? wave - NW : 0) : wave;   // index among the staging waves
+  const int cw = producer ? 0 : wave;                      // index among the multiplying waves
+  const int wm = cw / WNW, wn = cw % WNW;
   const int m0 = mt * BM, n0 = nt * BN;
   const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;   // row inside an 8-row group, global 16-byte chunk
 
@@ -88,9 +99,9 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   const int HoWo = p.Ho * p.Wo;
   int a_grp[AGW], b_grp[BGW];          // wave-uniform group index of this wave's i-th piece
 #pragma unroll
-  for (int i = 0; i < AGW; ++i) a_grp[i] = (wave + NW * i < PA) ? wave + NW * i : wave + NW * (i - 1);
+  for (int i = 0; i < AGW; ++i) a_grp[i] = (lw + NL * i < PA) ? lw + NL * i : lw + NL * (i - 1);
 #pragma unroll
-  for (int i = 0; i < BGW; ++i) b_grp[i] = (wave + NW * i < PB) ? wave + NW * i : wave + NW * (i - 1);
+  for (int i = 0; i < BGW; ++i) b_grp[i] = (lw + NL * i < PB) ? lw + NL * i : lw + NL * (i - 1);
 #pragma unroll
   for (int i = 0; i < AGW; ++i) {
     const int m = m0 + 8 * a_grp[i] + lrow;
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
   const bool pre_res = kPre && p.res != nullptr && vec8;
   // the BatchNorm input a fused backward reduction reads (sn_conv_dgrad_bn) takes the same slot when there is no residual
   const bool pre_bnx = kPre && p.res == nullptr && p.bn_x != nullptr && p.stats != nullptr && vec8 && p.bn_x_ps % 8 == 0;
-  if constexpr (kPre) if (pre_res || pre_bnx) {
+  if constexpr (kPre) if ((pre_res || pre_bnx) && !producer) {
     const half_t *src = pre_res ? p.res : p.bn_x;
     const int src_ps = pre_res ? p.res_ps : p.bn_x_ps;
 #pragma unroll
@@ -217,38 +228,116 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
     }
   }
 
-  // ---- pipeline: stages t+1 .. t+S-1 in flight under compute(t); one barrier per K-step
+  if constexpr (PS) {
+    if (producer) {
+      // ---- producer: stage t must have landed before barrier t; behind it the consumers are done with stage t - 1, whose buffer
+      // takes stage t + S - 1
 #pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) issue(s);
-  int cur = 0, nxt = S - 1;   // buffer of stage t / of stage t+S-1
-  int t = 0;
-  for (; t + S - 1 < nk; ++t) {
-    wait_vmcnt<(S - 2) * L>();          // stage t has landed (this wave's part); S-2 younger stages stay in flight
-    __builtin_amdgcn_s_barrier();       // ... everybody's part has, and everybody is done reading buffer `nxt` (stage t-1)
-    if (t == 0) stamp(1);
-    // A wave's instruction stream is in order: while it issues its DMA pieces (tools/probes/dma_rate_probe.hip: ~70 cycles each
-    // under load) it issues no MFMA, and the barrier puts every wave of the workgroup in the same phase.  With two waves
-    // per SIMD (8-wave workgroups: waves w and w + 4 share a SIMD) the upper half therefore multiplies FIRST and fetches
-    // afterwards: one half's MFMAs run under the other half's DMA issue.  Buffer `nxt` is free for the whole K-step.
-    if (kPingPong && wave >= NW / 2) {
-      compute(cur);
-      issue(nxt);
+      for (int s = 0; s < S - 1; ++s)
+        if (s < nk) issue(s);
+      int nxt = S - 1;
+      for (int t = 0; t < nk; ++t) {
+        const int young = min(S - 2, nk - 1 - t);
+        if (S > 3 && young >= 2) wait_vmcnt<(S > 3 ? 2 : 0) * L>();
+        else if (S > 2 && young == 1) wait_vmcnt<(S > 2 ? 1 : 0) * L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + S - 1 < nk) issue(nxt);
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+      }
     } else {
-      issue(nxt);
-      compute(cur);
+      // ---- consumer: register set 0 = channels 0-31 of the K-step, set 1 = channels 32-63
+      half8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+      auto read = [&](int buf, int ks, half8 (&fa)[MI], half8 (&fb)[NI]) {
+        const half_t *const base = lds + buf * STAGE;
+        const int co = (sw ^ (ks * 4)) * 8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const half8 *>(base + a_rd + i * 16 * BK + co);
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) fb[jn] = *reinterpret_cast<const half8 *>(base + b_rd + jn * 16 * BK + co);
+      };
+      auto mma = [&](const half8 (&fa)[MI], const half8 (&fb)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);
+      };
+      // MI * NI MFMAs and MI + NI fragment reads per half step: one read behind every second MFMA (a ds_read_b128 occupies the
+      // LDS for 4 cycles per wave; the matrix pipe takes 16 per MFMA), pinned -- left alone hipcc sinks every read behind the
+      // last MFMA that uses its destination
+      auto interleave = [&]() {
+#pragma unroll
+        for (int k = 0; k < MI + NI; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // two MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 2 * (MI + NI) > 0 ? MI * NI - 2 * (MI + NI) : 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto step_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of the stage behind this barrier has returned
+        __builtin_amdgcn_s_barrier();
+      };
+      if (nk > 0) {
+        step_barrier();
+        stamp(1);
+        read(0, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int cur = 0, nxt = 1;
+      for (int t = 0; t + 1 < nk; ++t) {
+        mma(fa0, fb0);
+        read(cur, 1, fa1, fb1);
+        interleave();
+        step_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        read(nxt, 0, fa0, fb0);
+        interleave();
+        cur = nxt;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+      }
+      if (nk > 0) {
+        mma(fa0, fb0);
+        read(cur, 1, fa1, fb1);
+        interleave();
+        mma(fa1, fb1);
+      }
     }
-    cur = cur + 1 == S ? 0 : cur + 1;
-    nxt = nxt + 1 == S ? 0 : nxt + 1;
-  }
-  for (; t < nk; ++t) {                 // drain: nothing left to issue; nk-1-t younger stages are still in flight
-    const int young = nk - 1 - t;
-    if (S > 3 && young >= 2) wait_vmcnt<(S > 3 ? 2 : 0) * L>();
-    else if (S > 2 && young == 1) wait_vmcnt<(S > 2 ? 1 : 0) * L>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    compute(cur);
-    cur = cur + 1 == S ? 0 : cur + 1;
+  } else {
+    // ---- pipeline: stages t+1 .. t+S-1 in flight under compute(t); one barrier per K-step
+  #pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+      if (s < nk) issue(s);
+    int cur = 0, nxt = S - 1;   // buffer of stage t / of stage t+S-1
+    int t = 0;
+    for (; t + S - 1 < nk; ++t) {
+      wait_vmcnt<(S - 2) * L>();          // stage t has landed (this wave's part); S-2 younger stages stay in flight
+      __builtin_amdgcn_s_barrier();       // ... everybody's part has, and everybody is done reading buffer `nxt` (stage t-1)
+      if (t == 0) stamp(1);
+      // A wave's instruction stream is in order: while it issues its DMA pieces (tools/probes/dma_rate_probe.hip: ~70 cycles each
+      // under load) it issues no MFMA, and the barrier puts every wave of the workgroup in the same phase.  With two waves
+      // per SIMD (8-wave workgroups: waves w and w + 4 share a SIMD) the upper half therefore multiplies FIRST and fetches
+      // afterwards: one half's MFMAs run under the other half's DMA issue.  Buffer `nxt` is free for the whole K-step.
+      if (kPingPong && wave >= NW / 2) {
+        compute(cur);
+        issue(nxt);
+      } else {
+        issue(nxt);
+        compute(cur);
+      }
+      cur = cur + 1 == S ? 0 : cur + 1;
+      nxt = nxt + 1 == S ? 0 : nxt + 1;
+    }
+    for (; t < nk; ++t) {                 // drain: nothing left to issue; nk-1-t younger stages are still in flight
+      const int young = nk - 1 - t;
+      if (S > 3 && young >= 2) wait_vmcnt<(S > 3 ? 2 : 0) * L>();
+      else if (S > 2 && young == 1) wait_vmcnt<(S > 2 ? 1 : 0) * L>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      compute(cur);
+      cur = cur + 1 == S ? 0 : cur + 1;
+    }
   }
 
   stamp(2);
@@ -418,9 +507,11 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
       }
     }
   };
-  if (vec8) epilogue(std::integral_constant<int, 0>{});
-  else if (vec4) epilogue(std::integral_constant<int, 1>{});
-  else epilogue(std::integral_constant<int, 2>{});
+  if (!producer) {
+    if (vec8) epilogue(std::integral_constant<int, 0>{});
+    else if (vec4) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 2>{});
+  }
   if (p.trace) {
     wait_vmcnt<0>();
     stamp(3);
@@ -437,7 +528,7 @@ __global__ __launch_bounds__(64 * WMW *WNW, MINW) void conv_dma_kernel(const Con
       }
     float *red = reinterpret_cast<float *>(lds);   // [wm][2][BN]
     __syncthreads();
-    if (fr == 0) {
+    if (fr == 0 && !producer) {
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -485,15 +576,19 @@ static const ConvDmaConfig kCfg[kConvDmaConfigs + 1] = {
     {160, 128, 512, 3, 3 * 288 * 128},   // 15: 8 waves (2 x 4), wave tile 80 x 32: twice the waves issuing the tile's DMA pieces
     {160, 128, 512, 2, 2 * 288 * 128},   // 16: the same, 2 workgroups / CU
     {80, 128, 256, 2, 2 * 208 * 128},    // 17: 52 KB, 3 workgroups / CU, wave tile 80 x 32 (1 x 4 waves)
+    // producer / consumer specialised (round 3): 4 multiplying waves (2 x 2) + 4 staging waves, one workgroup per CU
+    {160, 128, 512, 4, 4 * 288 * 128},   // 18: 144 KB, wave tile 80 x 64
+    {128, 128, 512, 4, 4 * 256 * 128},   // 19: 128 KB, wave tile 64 x 64
+    {192, 128, 512, 3, 3 * 320 * 128},   // 20: 120 KB, wave tile 96 x 64  (256 x 128, wave tile 128 x 64, spills: 256 VGPRs + scratch)
 };
 
 ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConfigs) ? kCfg[cfg] : kCfg[0]; }
 
-template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW>
+template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false>
 static void launch_one(const ConvParams &p, hipStream_t s) {
   const int mtiles = sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
   const dim3 grid(sn_div_up(mtiles, 8) * 8 * ntiles);
-  hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW>), grid, dim3(64 * WMW * WNW), 0, s, p, mtiles, ntiles);
+  hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, p, mtiles, ntiles);
 }
 
 template <bool DGRAD>
@@ -516,6 +611,9 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
     case 15: launch_one<DGRAD, 160, 128, 2, 4, 3, 1>(p, s); break;
     case 16: launch_one<DGRAD, 160, 128, 2, 4, 2, 2>(p, s); break;
     case 17: launch_one<DGRAD, 80, 128, 1, 4, 2, 3>(p, s); break;
+    case 18: launch_one<DGRAD, 160, 128, 2, 2, 4, 1, true>(p, s); break;
+    case 19: launch_one<DGRAD, 128, 128, 2, 2, 4, 1, true>(p, s); break;
+    case 20: launch_one<DGRAD, 192, 128, 2, 2, 3, 1, true>(p, s); break;
     default: SN_REQUIRE(false, "conv_dma_launch: unknown configuration %d", cfg);
   }
   SN_CHECK_LAUNCH();

@@ -28,10 +28,51 @@ def f16r(x):
     return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
 
 
+def error_quantiles(got, want):
+    """Elementwise error of got against want, two denominators: |want| of the element itself -- over the elements of at least
+    1e-3 of the tensor's largest magnitude (`rel_elementwise`; below that a relative error is rounding noise over nothing) and
+    over the SIGNIFICANT elements, at least 5 % of the largest magnitude (`rel_significant`: an fp16-stored tensor carries an
+    absolute error of ~1e-4 of its scale in every element, so the relative error of an element grows as the element shrinks;
+    for the elements that matter it must stay under the tolerance) -- and the tensor's largest magnitude (`err_over_max`, the
+    max-norm the tolerances of assert_close are stated in)."""
+    got = np.asarray(got, np.float64).ravel()
+    want = np.asarray(want, np.float64).ravel()
+    err = np.abs(got - want)
+    top = max(float(np.abs(want).max()), 1e-30)
+    big = np.abs(want) >= 1e-3 * top
+    rel = err[big] / np.abs(want[big]) if big.any() else np.zeros(1)
+    sig = np.abs(want) >= 5e-2 * top
+    rel_sig = err[sig] / np.abs(want[sig]) if sig.any() else np.zeros(1)
+    qs = (0.5, 0.9, 0.99, 0.999, 1.0)
+    return {'n': int(want.size), 'max_abs_want': top,
+            'rel_elementwise': {('p%g' % (100 * q)): float(np.quantile(rel, q)) for q in qs},
+            'rel_significant': {('p%g' % (100 * q)): float(np.quantile(rel_sig, q)) for q in qs},
+            'err_over_max': {('p%g' % (100 * q)): float(np.quantile(err, q) / top) for q in qs},
+            'rel_l2': float(np.sqrt((err ** 2).sum() / max((want ** 2).sum(), 1e-300)))}
+
+
+def _log_quantiles(what, got, want):
+    """one JSON line per comparison into gpurun_out/parity_quantiles.jsonl (merged back from the GPU box; summarised into
+    profiles/ by tools/parity_report.py) -- the measured distribution behind every `<= 1e-2` claim"""
+    import json
+    import os
+    try:
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(root, exist_ok=True)
+        rec = {'what': str(what), 'test': os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]}
+        rec.update(error_quantiles(got, want))
+        with open(os.path.join(root, 'parity_quantiles.jsonl'), 'a') as fh:
+            fh.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+
+
 def assert_close(got, want, rtol, atol, what=''):
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (what, got.shape, want.shape)
+    if got.size >= 64:
+        _log_quantiles(what, got, want)
     err = np.abs(got - want)
     tol = atol + rtol * np.abs(want)
     bad = err > tol

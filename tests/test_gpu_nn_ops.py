@@ -132,7 +132,7 @@ def test_conv_dgrad_wgrad(case):
 DMA_CASES = [CONV_CASES[i] for i in (0, 2, 3, 8, 9, 11, 12)]
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 18)))
+@pytest.mark.parametrize('cfg', list(range(1, 21)))
 def test_conv_dma_configurations(cfg, conv_tuning):
     """conv_dma_kernel (csrc/conv_dma.hip): each (tile, waves, ring depth) configuration forced on layers with padding taps,
     stride 2, dilation, ragged M / Cout tiles, bias + residual + ReLU and the scalar epilogue, against torch-CPU fp32."""
@@ -397,12 +397,13 @@ def test_sgd_and_weight_transpose():
     assert torch.equal(wp[..., :O], wt) and float(wp[..., O:].abs().sum()) == 0
 
 
-CONV_DMA_BM = {1: 128, 2: 128, 3: 256, 4: 128, 5: 64, 6: 64, 7: 256, 8: 128, 9: 128}
+CONV_DMA_BM = {1: 128, 2: 128, 3: 256, 4: 128, 5: 64, 6: 64, 7: 256, 8: 128, 9: 128, 18: 160, 19: 128, 20: 192}
 
 
 @pytest.mark.parametrize('N,H,C,O,K,bm,res', [(3, 17, 64, 192, 1, '64', False), (2, 24, 128, 256, 3, '128', True), (5, 9, 64, 128, 3, '64', True),
                                               (4, 32, 256, 320, 1, '128', False), (2, 24, 128, 256, 3, 'dma3', True), (3, 17, 64, 192, 1, 'dma6', False),
-                                              (4, 32, 256, 320, 1, 'dma4', False), (5, 9, 64, 128, 3, 'dma8', True), (2, 24, 128, 256, 3, 'dma7', True)])
+                                              (4, 32, 256, 320, 1, 'dma4', False), (5, 9, 64, 128, 3, 'dma8', True), (2, 24, 128, 256, 3, 'dma7', True),
+                                              (2, 24, 128, 256, 3, 'dma18', True), (4, 32, 256, 320, 1, 'dma19', False), (3, 17, 64, 192, 1, 'dma20', False)])
 def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch, conv_tuning):
     """sn_conv_fwd_stats: same output as sn_conv_fwd, and the per-row-tile partials sum to the statistics of the STORED
     fp16 tensor (what sn_bn_stats would read back); register-staged kernel at both tile heights and LDS-DMA configurations
@@ -456,7 +457,8 @@ def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch, conv_tunin
 
 
 @pytest.mark.parametrize('N,H,C,O,K,bm,act', [(3, 17, 128, 192, 1, '64', 1), (2, 24, 128, 256, 3, '128', 1), (4, 12, 192, 64, 3, '64', 0),
-                                              (2, 16, 320, 128, 1, '128', 2), (2, 24, 128, 256, 3, 'dma1', 1), (3, 17, 128, 192, 1, 'dma5', 1)])
+                                              (2, 16, 320, 128, 1, '128', 2), (2, 24, 128, 256, 3, 'dma1', 1), (3, 17, 128, 192, 1, 'dma5', 1),
+                                              (2, 24, 128, 256, 3, 'dma18', 1), (3, 17, 128, 192, 1, 'dma19', 2)])
 def test_conv_dgrad_bn_epilogue(N, H, C, O, K, bm, act, monkeypatch, conv_tuning):
     """sn_conv_dgrad_bn: same dx as sn_conv_dgrad, and partials that make sn_bn_backward_blocks reproduce sn_bn_backward
     (dx of the BatchNorm below, dgamma, dbeta) -- ReLU / none / ReLU6 masks, both tile heights, ragged tiles."""

@@ -12,7 +12,7 @@ import os
 import sys
 
 FAMILY = ('conv_dma_kernel', 'conv_igemm_p2_kernel', 'conv_igemm_kernel', 'conv_wgrad_tr_kernel', 'conv_wgrad_kernel', 'wgrad_flat_dma_kernel',
-          'wgrad_taps_dma_kernel', 'wgrad_reduce_kernel')
+          'wgrad_taps_dma_kernel', 'wgrad_reduce_kernel', 'wgrad_ps_kernel', 'wgrad_reduce2_kernel')
 
 
 def collect(d, counter):
@@ -38,6 +38,7 @@ def collect(d, counter):
 
 def main():
     fdir, wdir = sys.argv[1], sys.argv[2]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10      # steps the profiled command ran: warmup 1 + 2 timed + 1 idle-device + 2 x 3 eager
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                              'profiles', 'pmc_traffic.json')
     fetch, write = collect(fdir, 'FETCH_SIZE'), collect(wdir, 'WRITE_SIZE')
@@ -53,7 +54,8 @@ def main():
         tot_n += n
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import conv_sources_hash
-    res = {'hbm_bytes_per_launch': round(tot_b / max(tot_n, 1)), 'launches': tot_n, 'conv_sources_hash': conv_sources_hash(), 'by_kernel': per,
+    res = {'hbm_bytes_per_launch': round(tot_b / max(tot_n, 1)), 'launches': tot_n, 'steps': steps,
+           'hbm_bytes_per_step': round(tot_b / steps), 'kernel_launches_per_step': round(tot_n / steps, 1), 'conv_sources_hash': conv_sources_hash(), 'by_kernel': per,
            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 2 '
                      '--warmup 1 --no-cpu-baseline`; KiB -> bytes, FETCH_SIZE x2 (gfx950 correction)'}
     with open(out, 'w') as fh:
