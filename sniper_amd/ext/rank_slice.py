@@ -1,0 +1,108 @@
+"""Data parallel, one process per GPU, with the reference's GLOBAL-batch iterator: every rank assembles only ITS slice.
+
+`main_train.py` sizes the batch as `len(context) * BATCH_IMAGES` (main_train.py:52-53) and hands `MNIteratorE2E` that global
+size; MXNet's executor group then splits each batch over the GPUs of the one process.  With one process per GPU every rank runs
+the same script, so every rank's iterator would crop, resize and anchor-label all W * B chips of a batch and the Module would keep
+1 / W of them.  `patch_iterator_class` wraps `get_batch` of the iterator class: rank r assembles the chips
+[cur_i + r * B, cur_i + (r + 1) * B) of every global batch and the cursor advances by the global batch, so the ranks' slices are
+disjoint, together they are exactly the batch the unsliced iterator would have built, and `len(iter)`, the epoch length and the
+learning-rate schedule stay those of the global batch.  (All ranks must hold the same chip database: `Module._sync_epoch` seeds
+numpy from rank 0 and resets the iterator at every epoch.)  `install_import_hook` applies the wrapper to the reference's own class
+the moment `iterators.MNIteratorE2E` is imported -- the file itself is untouched."""
+import importlib.abc
+import importlib.util
+import os
+import sys
+
+
+def world_rank():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+
+
+def enabled():
+    return world_rank()[0] > 1 and os.environ.get('SNIPER_RANK_SLICE', '1') != '0'
+
+
+def patch_iterator_class(cls):
+    """Wrap cls.get_batch (MNIteratorE2E contract: cur_i, size, batch_size, _get_batch() -> batch).  Idempotent."""
+    if getattr(cls, '_rank_slice_wrapped', False):
+        return cls
+    orig = cls.get_batch
+
+    def get_batch(self):
+        world, rank = world_rank()
+        if not enabled() or getattr(self, 'rank_slice', True) is False:
+            return orig(self)
+        if self.cur_i >= self.size:
+            return False
+        gb = self.batch_size
+        if gb % world:
+            raise ValueError('global batch %d is not divisible by %d ranks' % (gb, world))
+        lb, base = gb // world, self.cur_i
+        self.cur_i, self.batch_size = base + rank * lb, lb
+        try:
+            self.batch = self._get_batch()
+        finally:
+            self.batch_size, self.cur_i = gb, base + gb
+        self.rank_sliced = True            # Module.fit reads this: the batches are rank-local already
+        return True
+    cls.get_batch = get_batch
+    cls._rank_slice_wrapped = True
+    return cls
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    """Post-import patch of the reference's iterator module (any package prefix: `iterators.MNIteratorE2E`, `lib.iterators...`)."""
+    NAMES = ('MNIteratorE2E',)
+
+    def __init__(self):
+        self._busy = False
+
+    def find_spec(self, name, path, target=None):
+        if self._busy or name.rsplit('.', 1)[-1] not in self.NAMES or name.startswith('sniper_amd.'):
+            return None
+        self._busy = True
+        try:
+            spec = importlib.util.find_spec(name)
+        except (ImportError, ValueError):
+            spec = None
+        finally:
+            self._busy = False
+        if spec is None or spec.loader is None:
+            return None
+        inner = spec.loader
+
+        class Loader(importlib.abc.Loader):
+            def create_module(self, sp):
+                return inner.create_module(sp) if hasattr(inner, 'create_module') else None
+
+            def exec_module(self, module):
+                inner.exec_module(module)
+                cls = getattr(module, name.rsplit('.', 1)[-1], None)
+                if isinstance(cls, type) and hasattr(cls, 'get_batch') and hasattr(cls, '_get_batch'):
+                    patch_iterator_class(cls)
+        spec.loader = Loader()
+        return spec
+
+
+def install_import_hook():
+    if not any(isinstance(f, _Finder) for f in sys.meta_path):
+        sys.meta_path.insert(0, _Finder())
+    for name, mod in list(sys.modules.items()):            # already imported: patch in place
+        if name.rsplit('.', 1)[-1] in _Finder.NAMES and not name.startswith('sniper_amd.'):
+            cls = getattr(mod, name.rsplit('.', 1)[-1], None)
+            if isinstance(cls, type) and hasattr(cls, '_get_batch'):
+                patch_iterator_class(cls)
+
+
+def is_rank_sliced(it):
+    """True when `it` (or the iterator a PrefetchingIter wraps) assembles rank-local batches."""
+    seen = [it] + list(getattr(it, 'iters', []) or []) + [getattr(it, 'iter', None)]
+    for x in seen:
+        if x is None:
+            continue
+        if getattr(x, 'rank_sliced', False):
+            return True
+        if enabled() and getattr(type(x), '_rank_slice_wrapped', False) and getattr(x, 'rank_slice', True) is not False:
+            return True
+    return False

@@ -205,3 +205,8 @@ class MNIteratorE2E(mx.io.DataIter):
                                 provide_data=self.provide_data, provide_label=self.provide_label)
         batch.worker_data = worker_data   # the anchor-labelling inputs (bench.py re-runs the labelling per step)
         return batch
+
+
+# data parallel, one process per GPU: rank r assembles chips [cur_i + r B, cur_i + (r + 1) B) of every global batch
+from ..ext.rank_slice import patch_iterator_class as _patch  # noqa: E402
+_patch(MNIteratorE2E)

@@ -200,6 +200,15 @@ class Module(object):
         self.optimizer_initialized = True
 
     # ---- compute
+    def _adopt_iterator(self, train_data):
+        """An iterator whose class sniper_amd.ext.rank_slice wrapped assembles only this rank's slice of every global batch:
+        its batches (and provide_data) are rank-local -- nothing to slice, nothing to divide -- but the ranks must still walk
+        the SAME chip database (_sync_epoch)."""
+        from ..ext import rank_slice
+        if self.world > 1 and rank_slice.is_rank_sliced(train_data):
+            self.slice_inputs = False
+            self._global_iter = True
+
     def _slice(self, a):
         if self.world > 1 and self.slice_inputs:
             n = a.shape[0] // self.world
@@ -305,7 +314,7 @@ class Module(object):
         ranks must build the SAME one, or rank r's slice r belongs to a different batch and the per-step all-reduces pair
         different steps: rank 0's seed is broadcast, numpy is re-seeded, the iterator reset, and the epoch length checked."""
         d = _dist()
-        if d is None or d.get_world_size() == 1 or not self.slice_inputs:
+        if d is None or d.get_world_size() == 1 or not (self.slice_inputs or getattr(self, '_global_iter', False)):
             return False
         dev = getattr(self, '_device', None) or torch.device('cpu')
         t = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -329,6 +338,7 @@ class Module(object):
             eval_batch_end_callback=None, initializer=None, arg_params=None, aux_params=None, allow_missing=False,
             force_rebind=False, force_init=False, begin_epoch=0, num_epoch=None, validation_metric=None, monitor=None):
         assert num_epoch is not None, 'please specify number of epochs'
+        self._adopt_iterator(train_data)
         self.bind(data_shapes=train_data.provide_data, label_shapes=train_data.provide_label, for_training=True,
                   force_rebind=force_rebind)
         self.init_params(initializer=initializer, arg_params=arg_params, aux_params=aux_params, allow_missing=allow_missing,

@@ -13,8 +13,9 @@ What the harness supplies (and nothing else):
   * ``dataset``         -> empty module, and ``load_proposal_roidb`` returns a synthetic COCO-shaped roidb whose images
     are PNG files written to a scratch directory (there is no COCO here; lib/dataset is out of scope, SURVEY section 2);
   * a random-init "pretrained" checkpoint written through the shim (there is no ImageNet file here);
-  * ``multiprocessing.Pool`` -> ``multiprocessing.dummy.Pool``: the reference forks 64 worker PROCESSES that would each
-    call the GPU-backed extension modules; threads keep the run inside one HIP context.
+  * nothing for ``multiprocessing.Pool``: ``sniper_amd.ext.install()`` itself makes ``from multiprocessing import Pool`` hand
+    the reference a thread-backed pool (sniper_amd/ext/pool.py) -- its 64 forked worker PROCESSES would each have called the
+    GPU-backed extension modules from a copy of this process's HIP context.
 
 Checks (written to the JSON the pytest wrapper asserts on): the epoch ran to the end over the reference iterator, the
 reference's metrics are finite, parameters moved, the reference's checkpoint callbacks wrote loadable files, and the
@@ -43,10 +44,6 @@ def _install_environment(work):
     import yaml
     _load = yaml.load
     yaml.load = lambda stream, Loader=None: _load(stream, Loader=Loader or yaml.FullLoader)
-
-    import multiprocessing
-    import multiprocessing.dummy
-    multiprocessing.Pool = multiprocessing.dummy.Pool
 
     sys.path.insert(0, ROOT)
     import sniper_amd.mx as mx

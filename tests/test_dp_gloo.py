@@ -75,8 +75,60 @@ def _worker(rank, world_size, port, out):
         ok_len = False
     except RuntimeError:
         ok_len = True
+    # rank-sliced global-batch iterator (sniper_amd/ext/rank_slice.py): an iterator with MNIteratorE2E's batch contract
+    # (cur_i / size / batch_size / _get_batch, lib/iterators/MNIteratorE2E.py:105-117) prepares B chips per step on each rank, not
+    # W * B; the ranks' slices are disjoint and together the global batch of the unwrapped iterator, the cursor still walks
+    # global batches, and Module.fit's adoption makes the Module bind the per-rank shape without slicing again
+    from sniper_amd.ext import rank_slice
+
+    class RefLikeIter(object):
+        def __init__(self, n, batch_size):
+            self.size, self.batch_size, self.cur_i = n, batch_size, 0
+            self.inds = np.random.permutation(n)
+            self.prepared = []                     # chips this process cropped / labelled, per step
+
+        def reset(self):
+            self.cur_i = 0
+            self.inds = np.random.permutation(self.size)
+
+        def __len__(self):
+            return self.size
+
+        def get_batch(self):
+            if self.cur_i >= self.size:
+                return False
+            self.batch = self._get_batch()
+            self.cur_i += self.batch_size
+            return True
+
+        def _get_batch(self):
+            ids = [int(self.inds[i % self.size]) for i in range(self.cur_i, self.cur_i + self.batch_size)]
+            self.prepared.append(ids)
+            return np.asarray(ids)
+
+        @property
+        def provide_data(self):
+            return [('x', (len(self.batch), 3, 4, 4))]
+    rank_slice.patch_iterator_class(RefLikeIter)
+    B = 4
+    it2 = RefLikeIter(6 * world_size * B, world_size * B)
+    m2 = mx.mod.Module(mx.sym.Variable('x'), data_names=['x'], label_names=None)
+    m2._device = torch.device('cpu')
+    m2._adopt_iterator(it2)
+    assert m2._sync_epoch(it2, 0)                  # same permutation on every rank
+    steps, mine_all = 0, []
+    while it2.get_batch():
+        steps += 1
+        mine_all.append(torch.from_numpy(it2.batch.copy()))
+    ok_rs = steps == 6 and all(len(p) == B for p in it2.prepared) and it2.cur_i == it2.size and it2.batch_size == world_size * B
+    ok_rs = ok_rs and m2.slice_inputs is False and m2._local(it2.provide_data[0][1]) == (B, 3, 4, 4)
+    got = [torch.zeros(6 * B, dtype=torch.int64) for _ in range(world_size)]
+    dist.all_gather(got, torch.cat(mine_all))
+    per_step = torch.stack([g.view(6, B) for g in got], 1).reshape(6, world_size * B)       # rank-major inside a global batch
+    ok_rs = ok_rs and bool(torch.equal(per_step.reshape(-1), torch.from_numpy(it2.inds.astype(np.int64))))
     dist.barrier()
-    out[rank] = int(ok_sum) + 2 * int(ok_slice) + 4 * int(ok_time) + 8 * int(ok_local) + 16 * int(ok_sync) + 32 * int(ok_len)
+    out[rank] = int(ok_sum) + 2 * int(ok_slice) + 4 * int(ok_time) + 8 * int(ok_local) + 16 * int(ok_sync) + 32 * int(ok_len) + \
+        64 * int(ok_rs)
     dist.destroy_process_group()
 
 
@@ -90,10 +142,36 @@ def test_two_rank_gradient_exchange_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0, 'rank exited with %s' % p.exitcode
-    assert dict(out) == {0: 63, 1: 63}, dict(out)
+    assert dict(out) == {0: 127, 1: 127}, dict(out)
 
 
 def test_single_process_is_a_no_op():
     from sniper_amd import parallel
     g = torch.ones(10)
     assert parallel.allreduce_gradients(g, None) == 0 and torch.equal(g, torch.ones(10))
+
+
+def test_ext_install_hands_out_a_thread_backed_pool(monkeypatch):
+    """sniper_amd.ext.pool: `from multiprocessing import Pool` after install() is the thread-backed pool with Pool's interface (the
+    reference's forked workers would call GPU-backed extension modules from a copy of the parent's HIP context); the work items
+    run in THIS process, map() keeps order, initializer / initargs are honoured."""
+    import multiprocessing
+    import threading
+    from sniper_amd.ext import pool
+    monkeypatch.setattr(multiprocessing, 'Pool', multiprocessing.Pool)       # restore after the test
+    pool.install()
+    from multiprocessing import Pool
+    assert Pool is pool.Pool
+    seen = []
+    p = Pool(4, initializer=seen.append, initargs=('init',))
+    pid = os.getpid()
+    import time
+    res = p.map(lambda i: (time.sleep(0.02), i * i, os.getpid(), threading.current_thread().name)[1:], range(32))
+    r2 = p.map_async(lambda i: i + 1, range(5)).get(10)
+    p.close()
+    p.join()
+    assert [r[0] for r in res] == [i * i for i in range(32)] and r2 == [1, 2, 3, 4, 5]
+    assert all(r[1] == pid for r in res) and len(set(r[2] for r in res)) > 1
+    assert seen == ['init'] * 4
+    pool.install()                                                            # idempotent
+    assert multiprocessing.Pool is pool.Pool
