@@ -295,12 +295,37 @@ def _cpu_image_chips_ref(i):
     return len(crops)
 
 
-def bench_inference(passes=4):
+def focus_map_blobs(scale_i, image, chip, net_map, frac=0.10):
+    """Synthetic FocusPixel map of the network map's shape (2, h, w): ~`frac` of the pixels positive, in 2-4 round blobs
+    (what a trained AutoFocus branch marks -- regions that contain small objects; a random-init branch marks nearly
+    everything, so every image would stay one full-size chip at every scale and FocusChip generation, chip batching and area-sorted
+    padding would never run).  Deterministic in (scale, image, chip)."""
+    _, h, w = net_map.shape
+    rs = np.random.RandomState(1000003 * scale_i + 1009 * image + chip)
+    k = int(rs.randint(2, 5))
+    r = np.sqrt(frac * h * w / (k * np.pi))
+    yy, xx = np.mgrid[0:h, 0:w]
+    pos = np.zeros((h, w), bool)
+    for b in range(k):       # one blob per stratum of the longer side (objects of a scene are spread out, not stacked), jittered
+        u, v = (b + 0.5 + rs.uniform(-0.2, 0.2)) / k, rs.uniform(0.2, 0.8)
+        cx, cy = (u * w, v * h) if w >= h else (v * w, u * h)
+        pos |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+    out = np.empty((2, h, w), np.float32)
+    out[1] = np.where(pos, 0.9, 0.02)
+    out[0] = 1.0 - out[1]
+    return out
+
+
+def bench_inference(passes=5):
     """BASELINE config C5: ResNet-101 AutoFocus inference, 3-scale coarse-to-fine FocusChip pyramid
-    ((480,512) -> (800,1280) -> (1400,2000), batches of 8 / 8 / 2), 8 synthetic 640x480 images, random-init weights.
-    One pass = GPU image preparation + forward + box decoding + FocusChips + multi-scale soft-NMS aggregation.
+    ((480,512) -> (800,1280) -> (1400,2000), batches of 8 / 8 / 2), 8 synthetic 640x480 images, random-init weights, the
+    FocusPixel maps that drive the chip generation injected (focus_map_blobs: ~10 % positive pixels in blobs).
+    One pass = GPU image preparation + forward + box decoding + FocusChips + multi-scale soft-NMS aggregation; the host
+    post-processing of a batch runs under the next batch's forward (Tester.get_detections).
     Throughput of the last pass (bound executors cached per batch shape and replaying their captured forward, like a resident
-    service: pass 1 binds, pass 2 captures, passes 3.. replay)."""
+    service: pass 1 binds, pass 2 captures, passes 3.. replay).  cpu_baseline: the reference's aggregation of the SAME per-scale
+    detections on the host -- its loops + its compiled cpu_soft_nms under Pool(32) (oracle/inference_ref.py)."""
+    import multiprocessing as mp
     import sniper_amd.mx as mx
     from sniper_amd import config as cfgmod
     from sniper_amd.inference import imdb_detection_wrapper
@@ -312,19 +337,48 @@ def bench_inference(passes=4):
     base = [{'image': rs.randint(0, 256, (480, 640, 3)).astype(np.uint8), 'width': 640, 'height': 480, 'flipped': False,
              'gt_overlaps': np.zeros((1, 81), np.float32)} for _ in range(8)]
     cfg = cfgmod.res101_e2e_autofocus()
-    cache, dt, n_chips = {}, None, None
+    cache, dt, chips_by_scale, dets = {}, None, None, None
     for _ in range(passes):
         roidb = [dict(r) for r in base]
+        counts = []
+
+        def fmap(scale_i, image, chip, net_map):
+            return focus_map_blobs(scale_i, image, chip, net_map)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache)
+        _, dets = imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache,
+                                         focus_map_fn=fmap, return_scale_dets=True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        n_chips = [int(np.asarray(r['inference_crops']).reshape(-1, 4).shape[0]) for r in roidb]
-    return {'metric': 'inf images/sec', 'value': round(len(base) / dt, 2), 'unit': 'images/s', 'seconds_per_pass': round(dt, 3),
-            'images': len(base), 'config': 'ResNet-101 AutoFocus inference, 3-scale FocusChip pyramid, batch 8 images (BASELINE '
-            'configs[4]); synthetic 640x480 images, random-init weights (FocusPixel maps of an untrained net select most of '
-            'every image: finest-scale chips per image %s)' % n_chips}
+        # chips per image at every scale: scale 0 is the whole image; the per-scale detection lists record how many chips ran
+        chips_by_scale = [[len(d[1][i]) for i in range(len(base))] for d in dets]
+    out = {'metric': 'inf images/sec', 'value': round(len(base) / dt, 2), 'unit': 'images/s', 'seconds_per_pass': round(dt, 3),
+           'images': len(base), 'chips_per_image_by_scale': chips_by_scale,
+           'workload': 'ResNet-101 AutoFocus inference, 3-scale FocusChip pyramid (480,512) -> (800,1280) -> (1400,2000), batches of '
+                       '8 / 8 / 2 chips (BASELINE configs[4]); 8 synthetic 640x480 images, random-init weights; FocusPixel maps '
+                       'injected: ~10 % positive pixels in 2-4 blobs per chip (SURVEY 8(d)) -> FocusChips per image at the finer '
+                       'scales as listed; host post-processing of batch b overlapped with the forward of batch b + 1'}
+    try:
+        from oracle import inference_ref
+        P = min(os.cpu_count() or 1, 32)             # Pool(32): lib/inference.py:159
+        with mp.get_context('fork').Pool(P) as pool:
+            inference_ref.aggregate(dets, cfg.TEST.VALID_RANGES, len(base), 81, cfg.TEST.NMS_SIGMA, pool)      # warm the workers
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 or time.perf_counter() - t0 < 3.0:
+                inference_ref.aggregate(dets, cfg.TEST.VALID_RANGES, len(base), 81, cfg.TEST.NMS_SIGMA, pool)
+                reps += 1
+            cdt = (time.perf_counter() - t0) / reps
+        n_boxes = int(sum(len(d[j][i][c]) for d in dets for j in range(1, 81) for i in range(len(base)) for c in range(len(d[j][i]))))
+        out['cpu_baseline'] = {
+            'value': round(len(base) / cdt, 2), 'unit': 'images/s', 'cores': P, 'node_cores': os.cpu_count(), 'kind': inference_ref.kind(),
+            'scope': 'post-processing leg only (multi-scale aggregation + soft-NMS of the %d (image, class) problems, %d candidate '
+                     'boxes); the forward passes have no CPU counterpart here (no MXNet)' % (len(base) * 80, n_boxes),
+            'sample': 'the reference\'s Tester.aggregate loops (lib/inference.py:166-201) + its compiled cpu_soft_nms '
+                      '(lib/nms/cpu_nms.pyx) under multiprocessing.Pool(%d) on this pass\'s per-scale detections, %d repetitions, '
+                      '%.3f s each' % (P, reps, cdt)}
+    except Exception as e:      # noqa: BLE001 -- a baseline is a report
+        out['cpu_baseline'] = {'value': None, 'sample': 'failed: %r' % (e,)}
+    return out
 
 
 def main():
@@ -410,10 +464,7 @@ def main():
     # extra steps: a step contains the gradient all-reduce, and a collective entered by rank 0 alone would never return.
     saved = (ex.use_graphs, ex._graph_fb, ex._graph_up)
     ex.use_graphs, ex._graph_fb, ex._graph_up = False, None, None
-    side = ex.use_side_stream
-
-    def profile(side_stream):
-        ex.use_side_stream = side_stream
+    def profile():
         step(0)                                     # settle (allocations of the eager path)
         with ConvProfiler() as prof:
             for i in range(2):
@@ -421,10 +472,9 @@ def main():
             res = prof.summary()
             profile.overhead_us = prof.overhead_ms * 1e3
             return res
-    tot_ms, tot_fl, per = profile(side)             # in situ: the stream assignment of the timed region
-    iso_ms, iso_fl, iso_per = profile(False)        # one stream: a launch's duration is its own
+    tot_ms, tot_fl, per = profile()                 # in situ: the kernels and the stream of the timed region, launched eagerly
+    iso_ms, iso_fl, iso_per = tot_ms, tot_fl, per   # (one stream since round 3: a launch's duration is its own)
     ex.use_graphs, ex._graph_fb, ex._graph_up = saved
-    ex.use_side_stream = side
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     isolated = iso_fl / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
     n_launch = sum(v[0] for v in per.values())
@@ -432,8 +482,8 @@ def main():
             'kernel': 'conv_dma_kernel<DGRAD,BM,BN,...> / conv_igemm_p2_kernel / wgrad_ps_kernel (+ conv_igemm_kernel for narrow layers, '
                       'wgrad_reduce2_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_dgrad_bn, sn_conv_wgrad_batch',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
-            'mode': 'in situ (eager replay of the timed step, weight gradients on the side stream: %s); sum of launch durations as '
-                    'rocprofv3 --kernel-trace --stats reports them' % bool(side),
+            'mode': 'in situ (eager replay of the timed step on its one stream); sum of launch durations as rocprofv3 --kernel-trace '
+                    '--stats reports them',
             'achieved_isolated': round(isolated, 2), 'frac_isolated': round(isolated / MFMA_PEAK_TFLOPS, 4),
             'step_tflops': round(tot_fl / 2 / (ms_per_step * 1e-3) / 1e12, 2), 'event_bracket_overhead_us': round(profile.overhead_us, 2),
             'traffic': pmc_traffic(),         # HBM bytes per KERNEL launch of the family (incl. the slab-reduce kernels)

@@ -146,8 +146,8 @@ int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *res
                 int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
                 int relu, int out_f32, sn_stream_t stream);
 /* Kernel-selection override for sn_conv_fwd / sn_conv_dgrad (tuning hook, tools/conv_tune.py; no reference counterpart):
- * -1 = built-in per-layer table (default), 0 = register-staged kernels only, 1..17 = that LDS-DMA tile configuration for every
- * layer that qualifies (see conv_dma.hip).  Results are identical up to fp32 summation order inside a tile's K loop
+ * -1 = built-in per-layer table (default), 0 = the register-staged kernel only, 4 / 5 / 6 / 7 / 14 / 16 / 18 = that LDS-DMA tile
+ * configuration for every layer that qualifies (see conv_dma.hip; other numbers are rejected).  Results are identical up to fp32 summation order inside a tile's K loop
  * (the K order itself does not change).  Process-wide; set it while no launch is in flight. */
 int sn_conv_tune(int cfg);
 
@@ -186,11 +186,6 @@ int sn_conv_dgrad_bn(const void *dy, const void *wt, const void *accumulate, voi
 /* Weight gradient, accumulated (+=) into dw fp32 [Cout][KH*KW][Cin].  Layers whose weight tensor is small relative to
  * the pixel count are split over K; with ws = sn_conv_wgrad_workspace_bytes(...) bytes of scratch the partials are
  * reduced without atomics (deterministic); ws may be NULL (atomic accumulation). */
-/* Kernel-selection override for sn_conv_wgrad (tuning hook, tools/wgrad_tune.py): LDS-DMA stages of the flat (1x1 / FC)
- * kernel {-1 built-in, 0 off, 2, 3} and of the all-taps 3x3 kernel {-1, 0, 3, 4}; target_workgroups = the workgroup count
- * the K-split aims at (0 = built-in; fewer workgroups = fewer, larger split-K partial slabs).  Must be set before the workspace query
- * of the launches it affects (the K-split count depends on it). */
-int sn_conv_wgrad_tune(int flat_stages, int taps_stages, int target_workgroups);
 size_t sn_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int x_pix_stride, int Cout, int dy_pix_stride, int KH, int KW,
                                      int stride, int pad, int dil);
 int sn_conv_wgrad(const void *dy, const void *x, float *dw, int N, int H, int W, int Cin, int x_pix_stride, int Cout,
@@ -206,7 +201,8 @@ typedef struct sn_wgrad_desc {
 } sn_wgrad_desc;
 size_t sn_conv_wgrad_batch_workspace_bytes(const sn_wgrad_desc *descs, int n);
 int sn_conv_wgrad_batch(const sn_wgrad_desc *descs, int n, void *ws, size_t ws_bytes, sn_stream_t stream);
-/* A/B and tuning hook: impl 1 = wave-specialised batched kernel (default), 0 = the round-1/2 kernels; job_steps = longest job in
+/* A/B and tuning hook: impl 1 = wave-specialised batched kernel (default), 0 = the gather kernel every layer can run on (the
+ * fallback for operands that are not 16-byte addressable); job_steps = longest job in
  * 64-pixel K-steps (0 = built-in).  Set before the workspace query of the launches it affects. */
 int sn_conv_wgrad_impl(int impl, int job_steps);
 /* diagnostics (tools/wgrad_batch_bench.py --trace): per-job phase cycles [jobs][8] x uint64 into buf; NULL = off */

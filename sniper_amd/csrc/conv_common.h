@@ -33,13 +33,13 @@ struct ConvParams {
 };
 
 
-// LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: 1..kConvDmaConfigs, see conv_dma_config().
+// LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: see conv_dma_config().
 struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };
-constexpr int kConvDmaConfigs = 20;
+constexpr int kConvDmaConfigs = 18;    // highest configuration number (the table has holes: conv_dma_config(c).bm == 0)
 ConvDmaConfig conv_dma_config(int cfg);
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
 
-// ---- weight gradient (conv.hip: gather / register-staged kernels; conv_wgrad_dma.hip: LDS-DMA kernels)
+// ---- weight gradient (conv.hip: gather kernel for unaligned operands and the packed stem; conv_wgrad_ps.hip: everything else)
 struct WgradParams {
   const half_t *dy;  // (N, Ho, Wo, Cout) pixel stride dy_ps
   const half_t *x;   // (N, H, W, Cin)    pixel stride x_ps
@@ -47,7 +47,6 @@ struct WgradParams {
   int N, H, W, Ho, Wo, Cin, Cout, dy_ps, x_ps;
   int KH, KW, stride, pad, dil;
   int units_per_split;  // 32-pixel K chunks handled per blockIdx.z split
-  unsigned long long *trace = nullptr;   // phase timeline (tools/conv_trace.py --wgrad; SNIPER_CONV_TRACE), normally null
   float *slab;          // split-K partials [split][Cout][taps][Cin] (plain stores, reduced by wgrad_reduce_kernel) or null
   size_t slab_stride;   // elements per split
   // logical grid (tile columns, tile rows, taps x splits).  The launch is one-dimensional and XCD-aware: hardware block b runs
@@ -59,7 +58,7 @@ struct WgradParams {
 // logical block index of a weight-gradient workgroup; false = surplus block of the rounded-up launch
 __device__ __forceinline__ bool wgrad_block(const WgradParams &p, int &bx, int &by, int &bz) {
   const int b = blockIdx.x;
-  const int item = p.per_xcd ? (b & 7) * p.per_xcd + (b >> 3) : b;   // per_xcd = 0: dispatch order (A/B runs)
+  const int item = (b & 7) * p.per_xcd + (b >> 3);
   const int tiles = p.gx * p.gy;
   if (item >= tiles * p.gz) return false;
   bz = item / tiles;
@@ -68,10 +67,10 @@ __device__ __forceinline__ bool wgrad_block(const WgradParams &p, int &bx, int &
   bx = r - by * p.gx;
   return true;
 }
-static inline unsigned wgrad_grid(WgradParams &p, int gx, int gy, int gz, bool xcd_aware = true) {
+static inline unsigned wgrad_grid(WgradParams &p, int gx, int gy, int gz) {
   p.gx = gx; p.gy = gy; p.gz = gz;
-  p.per_xcd = xcd_aware ? (gx * gy * gz + 7) / 8 : 0;
-  return xcd_aware ? 8u * (unsigned)p.per_xcd : (unsigned)(gx * gy * gz);
+  p.per_xcd = (gx * gy * gz + 7) / 8;
+  return 8u * (unsigned)p.per_xcd;
 }
 
 // ---- wave-specialised, batched weight gradient (conv_wgrad_ps.hip) ----
@@ -96,9 +95,4 @@ int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s);
 void wgrad_ps_set_job_steps(int steps);
 void wgrad_ps_set_trace(unsigned long long *buf);
 
-// LDS-DMA weight-gradient kernels.  kind 1: "flat" contraction over one long row of pixels (1x1 / stride 1 / pad 0
-// convolutions, FullyConnected, the deformable convolution's column GEMM), 128 (co) x 128 (ci) tile per workgroup,
-// grid (Cout/128, Cin/128, splits).  kind 2: KxK stride-1 convolution with ALL taps in one workgroup, 64 (co) x 64 (ci) x
-// taps tile, grid (Cout/64, Cin/64, splits).  p.units_per_split / p.slab as for conv_wgrad_tr_kernel; with p.slab == nullptr
-// (one split) the tile is added to p.dw with plain read-modify-write stores.
-int wgrad_dma_launch(const WgradParams &p, int kind, int stages, int splits, hipStream_t s);
+

@@ -19,7 +19,7 @@
 //     round 1's attempt a no-gain.
 //
 // The tile shape is a template parameter set (BM x BN outputs, WMW x WNW waves, S stages); conv_plan() in conv.hip picks
-// one per layer from the measured table (tools/conv_tune.py).
+// one per layer from the measured table (tools/conv_tune.py).  Seven configurations are instantiated (kCfg below).
 #include "conv_common.h"
 #include <type_traits>
 
@@ -553,33 +553,24 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   stamp(4);
 }
 
-// cfg -> tile shape.  LDS = stages * (bm + bn) * 128 B.
+// cfg -> tile shape.  LDS = stages * (bm + bn) * 128 B.  The numbers are those of round 2's seventeen-entry table (profiles/r02_conv_tune*.txt
+// name them); the entries no selection rule and no whole-step A/B ever chose were removed in round 3 (bm = 0: no such configuration).
 static const ConvDmaConfig kCfg[kConvDmaConfigs + 1] = {
     {0, 0, 0, 0, 0},
-    {128, 128, 256, 2, 2 * 256 * 128},   // 1: 64 KB, 2 workgroups / CU
-    {128, 128, 256, 3, 3 * 256 * 128},   // 2: 96 KB
-    {256, 128, 512, 3, 3 * 384 * 128},   // 3: 144 KB, 8 waves, wave tile 64 x 64
-    {128, 256, 512, 3, 3 * 384 * 128},   // 4
-    {64, 128, 256, 3, 3 * 192 * 128},    // 5: 72 KB, 2 / CU, wave tile 32 x 64
-    {64, 128, 256, 2, 2 * 192 * 128},    // 6: 48 KB, 3 / CU
-    {256, 256, 512, 2, 2 * 512 * 128},   // 7: 128 KB, wave tile 64 x 128
-    {128, 128, 512, 3, 3 * 256 * 128},   // 8: 96 KB, 8 waves, wave tile 32 x 64
-    {128, 128, 256, 4, 4 * 256 * 128},   // 9: 128 KB
+    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
+    {128, 256, 512, 3, 3 * 384 * 128},   // 4: 144 KB, 8 waves: FullyConnected over 6000 RoIs with >= 1024 outputs
+    {64, 128, 256, 3, 3 * 192 * 128},    // 5: 72 KB, 2 / CU, wave tile 32 x 64: narrow heads, long contractions
+    {64, 128, 256, 2, 2 * 192 * 128},    // 6: 48 KB, 3 / CU: narrow heads, FC, single-K-step layers
+    {256, 256, 512, 2, 2 * 512 * 128},   // 7: 128 KB, wave tile 64 x 128: >= 3.75 tiles of 256 x 256 per CU
+    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
     // 160-row tiles: 20 480 pixels (20 chips x 32 x 32) = 128 row tiles, i.e. 256 / 512 / 1024 workgroups for 256 / 512 / 1024
-    // output channels -- whole multiples of the 256 CUs.  One workgroup per CU (LDS), so no CU carries two tiles while
-    // another carries one (tools/conv_trace.py: the K-step rate of a CU is shared by its resident workgroups)
-    {160, 128, 256, 3, 3 * 288 * 128},   // 10: 108 KB, wave tile 80 x 64
-    {160, 128, 256, 4, 4 * 288 * 128},   // 11: 144 KB
-    {192, 128, 256, 3, 3 * 320 * 128},   // 12: 120 KB, wave tile 96 x 64: 6000 RoI rows = 32 row tiles
-    {160, 256, 256, 3, 3 * 416 * 128},   // 13: 156 KB, wave tile 80 x 128
-    {160, 128, 256, 2, 2 * 288 * 128},   // 14: 72 KB, 2 workgroups / CU
-    {160, 128, 512, 3, 3 * 288 * 128},   // 15: 8 waves (2 x 4), wave tile 80 x 32: twice the waves issuing the tile's DMA pieces
-    {160, 128, 512, 2, 2 * 288 * 128},   // 16: the same, 2 workgroups / CU
-    {80, 128, 256, 2, 2 * 208 * 128},    // 17: 52 KB, 3 workgroups / CU, wave tile 80 x 32 (1 x 4 waves)
+    // output channels -- whole multiples of the 256 CUs
+    {160, 128, 256, 2, 2 * 288 * 128},   // 14: 72 KB, 4 waves, 2 workgroups / CU (forward default)
+    {0, 0, 0, 0, 0},
+    {160, 128, 512, 2, 2 * 288 * 128},   // 16: 8 waves (2 x 4), wave tile 80 x 32, 2 workgroups / CU (data-gradient default)
+    {0, 0, 0, 0, 0},
     // producer / consumer specialised (round 3): 4 multiplying waves (2 x 2) + 4 staging waves, one workgroup per CU
-    {160, 128, 512, 4, 4 * 288 * 128},   // 18: 144 KB, wave tile 80 x 64
-    {128, 128, 512, 4, 4 * 256 * 128},   // 19: 128 KB, wave tile 64 x 64
-    {192, 128, 512, 3, 3 * 320 * 128},   // 20: 120 KB, wave tile 96 x 64  (256 x 128, wave tile 128 x 64, spills: 256 VGPRs + scratch)
+    {160, 128, 512, 4, 4 * 288 * 128},   // 18: 144 KB, wave tile 80 x 64: long contractions with about one tile per CU
 };
 
 ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConfigs) ? kCfg[cfg] : kCfg[0]; }
@@ -594,26 +585,13 @@ static void launch_one(const ConvParams &p, hipStream_t s) {
 template <bool DGRAD>
 static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 1: launch_one<DGRAD, 128, 128, 2, 2, 2, 2>(p, s); break;
-    case 2: launch_one<DGRAD, 128, 128, 2, 2, 3, 1>(p, s); break;
-    case 3: launch_one<DGRAD, 256, 128, 4, 2, 3, 2>(p, s); break;
     case 4: launch_one<DGRAD, 128, 256, 2, 4, 3, 2>(p, s); break;
     case 5: launch_one<DGRAD, 64, 128, 2, 2, 3, 2>(p, s); break;
     case 6: launch_one<DGRAD, 64, 128, 2, 2, 2, 3>(p, s); break;
     case 7: launch_one<DGRAD, 256, 256, 4, 2, 2, 1>(p, s); break;
-    case 8: launch_one<DGRAD, 128, 128, 4, 2, 3, 2>(p, s); break;
-    case 9: launch_one<DGRAD, 128, 128, 2, 2, 4, 1>(p, s); break;
-    case 10: launch_one<DGRAD, 160, 128, 2, 2, 3, 1>(p, s); break;
-    case 11: launch_one<DGRAD, 160, 128, 2, 2, 4, 1>(p, s); break;
-    case 12: launch_one<DGRAD, 192, 128, 2, 2, 3, 1>(p, s); break;
-    case 13: launch_one<DGRAD, 160, 256, 2, 2, 3, 1>(p, s); break;
     case 14: launch_one<DGRAD, 160, 128, 2, 2, 2, 2>(p, s); break;
-    case 15: launch_one<DGRAD, 160, 128, 2, 4, 3, 1>(p, s); break;
     case 16: launch_one<DGRAD, 160, 128, 2, 4, 2, 2>(p, s); break;
-    case 17: launch_one<DGRAD, 80, 128, 1, 4, 2, 3>(p, s); break;
     case 18: launch_one<DGRAD, 160, 128, 2, 2, 4, 1, true>(p, s); break;
-    case 19: launch_one<DGRAD, 128, 128, 2, 2, 4, 1, true>(p, s); break;
-    case 20: launch_one<DGRAD, 192, 128, 2, 2, 3, 1, true>(p, s); break;
     default: SN_REQUIRE(false, "conv_dma_launch: unknown configuration %d", cfg);
   }
   SN_CHECK_LAUNCH();

@@ -525,14 +525,27 @@ __device__ unsigned long long radix_select_kth(const int8_t *__restrict__ label_
       if ((comp & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(comp >> shift) & 0xffu], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int acc = 0, bin = 0;
-      for (bin = 0; bin < 256; ++bin) {
-        if (acc + (int)hist[bin] >= k) break;
-        acc += (int)hist[bin];
+    // the bucket that holds rank k: first bin whose inclusive count reaches k.  One wave, four bins per lane, shuffle scan
+    // (a single thread walking the 256 LDS bins took ~7 us per pass, 12 passes per chip: most of this kernel's 157 us)
+    if (tid < 64) {
+      const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const unsigned sum4 = h0 + h1 + h2 + h3;
+      unsigned incl = sum4;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d, 64);
+        if (tid >= d) incl += up;
       }
-      *sh_prefix = prefix | ((unsigned long long)bin << shift);
-      *sh_keep = k - acc;
+      const unsigned excl = incl - sum4;
+      if (excl < (unsigned)k && (unsigned)k <= incl) {       // exactly one lane: 1 <= k <= population of the current bucket
+        unsigned acc = excl;
+        int bin = 4 * tid;
+        if (acc + h0 < (unsigned)k) { acc += h0; ++bin;
+          if (acc + h1 < (unsigned)k) { acc += h1; ++bin;
+            if (acc + h2 < (unsigned)k) { acc += h2; ++bin; } } }
+        *sh_prefix = prefix | ((unsigned long long)bin << shift);
+        *sh_keep = k - (int)acc;
+      }
     }
     __syncthreads();
     prefix = *sh_prefix;

@@ -149,22 +149,15 @@ class Executor(object):
         self.use_infer_graphs = (not for_training and os.environ.get('SNIPER_HIP_GRAPHS', '1') != '0' and
                                  not any(type(st).__name__ == 'CustomStep' for st in self.steps))
         self._infer_graph, self._infer_calls = None, 0
-        # Weight gradients run on a second HIP stream, concurrently with the data-gradient chain: both consume the same
-        # dY, the weight gradient is needed only by the optimizer, and most R101 layers have too few tiles to fill 256
-        # CUs on their own (a 3x3 256->256 weight gradient is 36 tiles before K-splitting).
-        self.side_stream = None
-        # Off by default since round 2: measured on MI355X (profiles/r02_*), the overlap buys nothing (30.15 ms with, 29.72 ms
-        # without) -- both streams' kernels fill the chip -- while every kernel's duration inflates (conv family 25.3 -> 18.8 ms
-        # summed).  SNIPER_WGRAD_STREAM=1 turns it back on.
-        self.use_side_stream = for_training and os.environ.get('SNIPER_WGRAD_STREAM', '0') == '1' and self.device.type == 'cuda'
         self._keepalive = []
-        self._side_reads = set()     # storages the side stream may still be reading (see grad_slot)
         # Weight gradients are DEFERRED and launched as tables of layers (sn_conv_wgrad_batch): one stage-3 layer has 16-36
         # output tiles, so alone it needs a 7-16-way K split with fp32 partial slabs; a few dozen layers per launch fill the
         # 256 CUs with whole-K jobs (csrc/conv_wgrad_ps.hip).  A queued layer keeps its dY / X tensors alive; a dY that another
         # Val would accumulate into IN PLACE before the flush (the residual trunk's shared gradient) is protected by
         # grad_slot (out-of-place accumulation).  SNIPER_WGRAD_DEFER=0: launch per layer, at the layer's backward.
-        self.defer_wgrads = for_training and os.environ.get('SNIPER_WGRAD_DEFER', '1') != '0' and not self.use_side_stream
+        # (Rounds 1-2 ran the weight gradients on a second stream instead; measured, the overlap bought nothing -- 30.15 ms with,
+        # 29.72 ms without, profiles/r02_* -- and round 3 removed it.)
+        self.defer_wgrads = for_training and os.environ.get('SNIPER_WGRAD_DEFER', '1') != '0'
         self._pending_wgrads = []    # [(dy, x, dw, N, H, W, C, x_ps, O, dy_ps, kh, kw, stride, pad, dil)]
         self._pending_reads = set()  # storages queued weight gradients still have to read
         self._graph_fb = self._graph_up = None
@@ -227,9 +220,8 @@ class Executor(object):
         """-> (dst, src): the tensor (v's own format) the caller writes v's gradient contribution into, and the tensor it adds
         to it (None for the first writer; normally dst itself -- later writers add in place).
         A gradient tensor can be shared: a residual add hands the SAME tensor to both operands (add_grad), so the tensor
-        about to be accumulated into may be the dY of a convolution whose weight gradient has not run yet: queued for a
-        batched launch (then the sum goes to a fresh tensor, src = the old one, which the queue keeps alive), or running on the
-        side stream (then the main stream waits for the side stream first)."""
+        about to be accumulated into may be the dY of a convolution whose weight gradient has not run yet -- queued for a
+        batched launch: then the sum goes to a fresh tensor, src = the old one, which the queue keeps alive."""
         if v.grad is None:
             v.grad = self.empty(v.t.shape, v.t.dtype)
             return v.grad, None
@@ -242,11 +234,6 @@ class Executor(object):
             if p.grad is not None and p.grad.data_ptr() == v.grad.data_ptr():
                 p.grad_alias = None
                 v.grad = v.grad.clone()
-        if self._side_reads and v.grad.untyped_storage().data_ptr() in self._side_reads:
-            ev = torch.cuda.Event()
-            ev.record(self.side_stream)
-            torch.cuda.current_stream().wait_event(ev)
-            self._side_reads.clear()
         if self._pending_reads and v.grad.untyped_storage().data_ptr() in self._pending_reads:
             src = v.grad
             v.grad = self.empty(src.shape, src.dtype)
@@ -651,25 +638,8 @@ class Executor(object):
         self.arena_grad.zero_()
 
     def on_side(self, fn, keep=()):
-        """Run fn() (kernel launches through hip.call) on the side stream, ordered after everything enqueued so far on
-        the main stream.  `keep`: tensors fn reads that the caller is about to drop -- they are held until the join at
-        the end of backward so that the caching allocator cannot hand their memory to a main-stream kernel meanwhile."""
-        if not self.use_side_stream:
-            fn()
-            return
-        if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.side_stream.wait_event(ev)
-        self._keepalive.extend(keep)
-        for t in keep:
-            if isinstance(t, torch.Tensor):
-                self._side_reads.add(t.untyped_storage().data_ptr())
-        with torch.cuda.stream(self.side_stream):
-            fn()
-        self._side_used = True
+        """Parameter-gradient launches of a step (weight gradients are queued by _wgrad, bias gradients run here)."""
+        fn()
 
     def backward(self, segment=None):
         """segment None: the whole pass.  With a split (self.split_k): 'a' = the steps split_k.. (their parameter gradients
@@ -677,8 +647,6 @@ class Executor(object):
         k = self.split_k if segment is not None else 0
         if segment in (None, 'a'):
             self.zero_grad()
-            self._side_used = False
-            self._side_reads.clear()
             for v in self.vals.values():
                 v.grad = None
         steps = self.steps if segment is None else (self.steps[k:] if segment == 'a' else self.steps[:k])
@@ -688,12 +656,6 @@ class Executor(object):
         if segment in (None, 'b'):
             for v in self.vals.values():
                 v.grad = None
-        if self._side_used:                       # join: the optimizer / all-reduce read the gradient arena
-            ev = torch.cuda.Event()
-            ev.record(self.side_stream)
-            torch.cuda.current_stream().wait_event(ev)
-            self._side_used = False
-            self._side_reads.clear()
         self._keepalive = []
 
     def _capture(self, fn, what, pool=None):

@@ -14,6 +14,7 @@ def require_gpu():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_GET_DEVICE = hasattr(torch._C, '_cuda_getDevice')      # the raw getter: ~0.1 us, no Python-side device object
 _DEVICE = None      # this process's GPU (one process per GPU); set by use_device(), else looked up per call
 
 
@@ -26,7 +27,9 @@ def use_device(index):
 def stream():
     """hipStream_t of torch's current stream (so our kernels order with torch's allocator/events).  The raw getter costs well
     under a microsecond; torch.cuda.current_stream() builds a Stream object (~8 us, x 1500 launches of an eager inference pass)."""
-    idx = _DEVICE if _DEVICE is not None else torch.cuda.current_device()
+    # torch's current device is per THREAD (a pool worker of sniper_amd.ext.pool binds its own; a second Module on another
+    # device changes it): the recorded index is only a shortcut while it still IS the current device (ADVICE r2)
+    idx = torch._C._cuda_getDevice() if _GET_DEVICE else torch.cuda.current_device()
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 

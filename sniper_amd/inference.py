@@ -205,13 +205,28 @@ class Tester(object):
         return scores, rois, data, im_ids
 
     def detect(self, batch, scales):
+        return self._collect(self._launch(batch))
+
+    # The forward pass of batch b + 1 runs on the GPU while the host post-processes batch b (score threshold, per-class lists,
+    # border pruning: ~30 ms of numpy per 8-image pass, profiles/r02_infer_profile_after.txt -- serial behind each forward in
+    # round 2).  _launch enqueues forward + box decoding + device -> pinned-host copies and returns at once; _collect waits for
+    # that batch's copy event only.  A captured forward replays into the SAME output tensors, so the copies are enqueued before
+    # the next forward on the same stream and land in one of two alternating pinned sets.
+    def _pinned(self, key, like, dtype=None):
+        pool = self.__dict__.setdefault('_pin', {})
+        k = (key, tuple(like.shape), dtype or like.dtype, self.__dict__.setdefault('_pin_flip', 0))
+        t = pool.get(k)
+        if t is None:
+            t = pool[k] = torch.empty(tuple(like.shape), dtype=dtype or like.dtype, pin_memory=True)
+        return t
+
+    def _launch(self, batch):
         data = dict(zip(self.data_names, batch.data))
         outputs = self.forward(batch)
-        scores, preds, maps = [], [], []
-        im_ids = np.array([], dtype=int)
-        chip_ids = np.array([], dtype=int)
+        self._pin_flip = 1 - self.__dict__.get('_pin_flip', 0)
         has_focus_maps = self.rcnn_output_names['scale_map'] in outputs[0]
-        for gpu_out, gpu_scales in zip(outputs, scales):
+        parts = []
+        for g, gpu_out in enumerate(outputs):
             rois = gpu_out[self.rpn_output_names['rois']]._data              # (B*R, 5) device, rows of chip b contiguous
             deltas = gpu_out[self.rcnn_output_names['bbox']]._data           # (B, R, 4)
             infos = gpu_out[self.rcnn_output_names['im_info']]._data         # (B, 3) = h, w, scale
@@ -219,12 +234,37 @@ class Tester(object):
             assert rois.shape[0] == B * R, 'The number of rois per GPU should be fixed!'
             boxes = torch.empty((B, R, 4), dtype=torch.float64, device=rois.device)
             hip.call('sn_bbox_decode', rois.contiguous(), deltas.contiguous(), infos.float().contiguous(), boxes, B, R, hip.stream())
-            gpu_scores = gpu_out[self.rcnn_output_names['cls']].asnumpy()
-            boxes = boxes.cpu().numpy()
+            want = {'boxes': boxes, 'cls': gpu_out[self.rcnn_output_names['cls']]._data,
+                    'im_ids': gpu_out[self.rcnn_output_names['im_ids']]._data,
+                    'chip_ids': gpu_out[self.rcnn_output_names['chip_ids']]._data}
             if has_focus_maps:
-                scale_prob = gpu_out[self.rcnn_output_names['scale_map']].asnumpy()
-            im_ids = np.hstack((im_ids, gpu_out[self.rcnn_output_names['im_ids']].asnumpy().astype(int)))
-            chip_ids = np.hstack((chip_ids, gpu_out[self.rcnn_output_names['chip_ids']].asnumpy().astype(int)))
+                want['maps'] = gpu_out[self.rcnn_output_names['scale_map']]._data
+            host = {}
+            for k, t in want.items():
+                if t.is_cuda:
+                    host[k] = self._pinned((g, k), t)
+                    host[k].copy_(t, non_blocking=True)
+                else:
+                    host[k] = t
+            parts.append((B, host))
+        ev = None
+        if torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record()
+        return data, parts, has_focus_maps, ev
+
+    def _collect(self, handle):
+        data, parts, has_focus_maps, ev = handle
+        if ev is not None:
+            ev.synchronize()
+        scores, preds, maps = [], [], []
+        im_ids = np.array([], dtype=int)
+        chip_ids = np.array([], dtype=int)
+        for B, host in parts:
+            gpu_scores, boxes = host['cls'].numpy().copy(), host['boxes'].numpy().copy()      # the pinned set is reused two batches on
+            im_ids = np.hstack((im_ids, host['im_ids'].numpy().astype(int)))
+            chip_ids = np.hstack((chip_ids, host['chip_ids'].numpy().astype(int)))
+            scale_prob = host['maps'].numpy().copy() if has_focus_maps else None
             for idx in range(B):
                 scores.append(gpu_scores[idx])
                 preds.append(boxes[idx])
@@ -299,10 +339,7 @@ class Tester(object):
         n_chips = [len(r['inference_crops']) for r in self.roidb]
         all_boxes = [[[[] for _ in range(n_chips[i])] for i in range(self.num_images)] for _ in range(self.num_classes)]
         all_maps = [[[] for _ in range(n_chips[i])] for i in range(self.num_images)]
-        for batch in self.test_iter:
-            im_info = batch.data[1].asnumpy()
-            scales = im_info[:, 2].reshape(-1, self.batch_size)
-            scores, boxes, data, im_ids, maps, chip_ids = self.detect(batch, scales)
+        def post(scores, boxes, data, im_ids, maps, chip_ids):
             todo = []
             for i, (cscores, cboxes, im_id, chip_id) in enumerate(zip(scores, boxes, im_ids, chip_ids)):
                 if autofocus:
@@ -333,6 +370,14 @@ class Tester(object):
                                                self.roidb[im_id]['width'], self.roidb[im_id]['height'])
                     for j, d in enumerate(pruned):
                         all_boxes[j + 1][im_id][chip_id] = d
+        pending = None
+        for batch in self.test_iter:
+            handle = self._launch(batch)              # forward of this batch is on the GPU ...
+            if pending is not None:
+                post(*self._collect(pending))         # ... while the host finishes the previous one
+            pending = handle
+        if pending is not None:
+            post(*self._collect(pending))
         return all_boxes, all_maps
 
     def extract_proposals(self, n_proposals=300, cache_name='cache', vis=False, vis_ext='.png'):
@@ -369,10 +414,14 @@ def detect_scale_worker(arguments, module_cache=None):
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
-def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None):
+def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
+                           focus_map_fn=None, return_scale_dets=False):
     """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
     AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips); detections of all scales
-    are aggregated under TEST.VALID_RANGES with per-class NMS."""
+    are aggregated under TEST.VALID_RANGES with per-class NMS.
+    focus_map_fn(scale_i, image, chip, net_map) -> map (benchmarks only): replaces the network's FocusPixel map before the
+    FocusChips are cut -- a random-init network's maps select whole images, a trained one's ~10 % of the pixels in blobs
+    (SURVEY 8(d)); return_scale_dets: also hand back the per-scale detections (what the CPU baseline of the aggregation reads)."""
     for r in roidb:
         r['inference_crops'] = np.array([[0, 0, r['width'], r['height']]])
     detections = []
@@ -382,6 +431,9 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
         detections.append(dets)
         # chips of the next scale from this scale's FocusPixel maps (:497-499)
         if scale_i + 1 < len(config.TEST.SCALES) and config.TEST.DO_PRUNING[scale_i + 1]:
+            if focus_map_fn is not None:
+                maps = [[focus_map_fn(scale_i, i, j, np.asarray(m)) for j, m in enumerate(mi)] for i, mi in enumerate(maps)]
             add_chips(roidb, maps, scale_i, config)
     tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
-    return tester.aggregate(detections, vis=False, cache_name=None)
+    out = tester.aggregate(detections, vis=False, cache_name=None)
+    return (out, detections) if return_scale_dets else out

@@ -166,6 +166,9 @@ class Module(object):
             return
         for ex in self._exes.values():
             d.broadcast(ex.arena_master, src=0)
+            for p in ex.params.values():          # frozen parameters live outside the arena (Executor._alloc_params): a randomly
+                if not p.trainable:               # initialised frozen weight (synthetic runs, names missing from the pretrained
+                    d.broadcast(p.master, src=0)  # file) must be the same on every replica too, as kvstore init + pull makes it
             for t in ex.aux.values():
                 d.broadcast(t, src=0)
             ex.refresh_compute_copies()

@@ -135,3 +135,37 @@ def test_vectorised_post_processing_equals_the_reference_loops():
     for g, w in zip(got, want):
         assert g.dtype == np.float32 and g.shape == w.shape and np.array_equal(g, w)
     assert sum(len(g) for g in got) > 0 and any(len(g) == 0 for g in got)
+
+
+def test_reference_aggregation_baseline_matches_the_vectorised_one():
+    """bench.py's inference cpu_baseline (oracle/inference_ref.py: Tester.aggregate's loops as the reference writes them,
+    lib/inference.py:166-190) builds the same (image, class) NMS problems, row for row, as sniper_amd.inference.aggregate_problems;
+    its soft-NMS (the reference's compiled cpu_nms.pyx where built, else the C restatement) keeps what the oracle's keeps."""
+    import oracle
+    from oracle import inference_ref
+    from sniper_amd.inference import aggregate_problems
+    rs = np.random.RandomState(3)
+    num_images, num_classes = 3, 6
+    vr = ((75, -1), (32, 180), (-1, 75))
+    scale_dets = []
+    for s in range(3):
+        allc = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+        for i in range(num_images):
+            n_chips = 1 + (s * (i + 1)) % 3
+            for j in range(1, num_classes):
+                allc[j][i] = []
+                for c in range(n_chips):
+                    n = int(rs.randint(0, 9))
+                    xy = rs.uniform(0, 400, (n, 2))
+                    wh = rs.uniform(5, 260, (n, 2))
+                    allc[j][i].append(np.hstack((xy, xy + wh, rs.uniform(0.01, 1, (n, 1)))).astype(np.float32) if n else [])
+        scale_dets.append(allc)
+    a = inference_ref.aggregate_problems(scale_dets, vr, num_images, num_classes)
+    b = aggregate_problems(scale_dets, vr, num_images, num_classes)
+    assert len(a) == len(b) == num_images * (num_classes - 1)
+    for u, v in zip(a, b):
+        assert u.shape == v.shape and np.array_equal(u, v)
+    big = max(a, key=len)
+    assert len(big) > 3
+    assert np.array_equal(inference_ref.nms_problem(big, 0.55), oracle.soft_nms(big, sigma=0.55, Nt=0.3, threshold=0.001, method=2))
+    assert inference_ref.kind() in ('reference', 'port')

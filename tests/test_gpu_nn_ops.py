@@ -116,11 +116,11 @@ def test_conv_stem_packed_7x7():
 
 @pytest.fixture
 def conv_tuning():
-    """Restores the built-in kernel selection after a test that forced one (sn_conv_tune / sn_conv_wgrad_tune are process-wide)."""
+    """Restores the built-in kernel selection after a test that forced one (sn_conv_tune / sn_conv_wgrad_impl are process-wide)."""
     hip = _hip()
     yield hip
     hip.call('sn_conv_tune', -1)
-    hip.call('sn_conv_wgrad_tune', -1, -1, 0)
+    hip.call('sn_conv_wgrad_impl', 1, 0)
 
 
 @pytest.mark.parametrize('case', CONV_CASES[:7] + CONV_CASES[8:])
@@ -132,7 +132,7 @@ def test_conv_dgrad_wgrad(case):
 DMA_CASES = [CONV_CASES[i] for i in (0, 2, 3, 8, 9, 11, 12)]
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 21)))
+@pytest.mark.parametrize('cfg', [4, 5, 6, 7, 14, 16, 18])
 def test_conv_dma_configurations(cfg, conv_tuning):
     """conv_dma_kernel (csrc/conv_dma.hip): each (tile, waves, ring depth) configuration forced on layers with padding taps,
     stride 2, dilation, ragged M / Cout tiles, bias + residual + ReLU and the scalar epilogue, against torch-CPU fp32."""
@@ -151,14 +151,46 @@ def test_conv_dma_configurations(cfg, conv_tuning):
         _check_dgrad_wgrad(case, wgrad=False)
 
 
-@pytest.mark.parametrize('mode', [(2, 3, 0), (3, 4, 0), (2, 3, 64), (3, 4, 24), (0, 0, 100)])
-def test_conv_wgrad_dma_kernels(mode, conv_tuning):
-    """wgrad_flat_dma_kernel / wgrad_taps_dma_kernel (csrc/conv_wgrad_dma.hip) forced on 1x1 and 3x3 layers (dilation 2,
-    Wo < 32 and Wo = 32, ragged channel tiles, Cout % 8 != 0), ring depths 2-4, with and without K-splits, against
-    torch-CPU fp32; (0, 0, n) = the register-staged kernel at another split count."""
-    conv_tuning.call('sn_conv_wgrad_tune', *mode)
+@pytest.mark.parametrize('mode', [(1, 0), (1, 2), (1, 7), (1, 1000), (0, 0)])
+def test_conv_wgrad_kernels(mode, conv_tuning):
+    """wgrad_ps_kernel (csrc/conv_wgrad_ps.hip: 4 consumer + 4 producer waves, jobs of a batched table) forced to job lengths of
+    2 / 7 / 1000 K-steps -- many K-splits with slabs + reduce, odd unit counts, no split at all -- and the gather kernel every
+    layer can fall back to (impl 0), on 1x1 and 3x3 layers (stride 2, dilation 2, Wo < 32 and Wo = 32, ragged channel tiles,
+    Cout % 8 != 0), against torch-CPU fp32."""
+    conv_tuning.call('sn_conv_wgrad_impl', *mode)
     for i in (0, 1, 3, 4, 8, 9, 11, 12):
         _check_dgrad_wgrad(CONV_CASES[i], dgrad=False)
+
+
+def test_conv_wgrad_batch_equals_per_layer_launches(conv_tuning):
+    """sn_conv_wgrad_batch: a table of different layers in one launch (whole-K jobs, some problems split) gives each layer the
+    result of its own sn_conv_wgrad launch up to fp32 summation order, and adds into non-zero dw (+= semantics)."""
+    hip = _hip()
+    rs = np.random.RandomState(5)
+    probs, singles = [], []
+    for (N, C, H, W, O, K, s, p, d) in [(3, 128, 20, 20, 256, 1, 1, 0, 1), (3, 64, 20, 20, 72, 3, 1, 2, 2), (2, 256, 40, 33, 128, 3, 2, 1, 1),
+                                        (600, 192, 1, 1, 81, 1, 1, 0, 1), (3, 128, 20, 20, 128, 3, 1, 1, 1)]:
+        Ho, Wo = (H + 2 * p - d * (K - 1) - 1) // s + 1, (W + 2 * p - d * (K - 1) - 1) // s + 1
+        Op = (O + 7) // 8 * 8
+        x = torch.from_numpy(rs.standard_normal((N, H, W, C)).astype(np.float32)).to(dev()).half()
+        dy = torch.zeros((N, Ho, Wo, Op), dtype=torch.float16, device=dev())
+        dy[..., :O] = torch.from_numpy(rs.standard_normal((N, Ho, Wo, O)).astype(np.float32)).to(dev()).half()
+        init = torch.from_numpy(rs.standard_normal((O, K * K, C)).astype(np.float32)).to(dev())
+        probs.append((dy, x, init.clone(), N, H, W, C, C, O, Op, K, K, s, p, d))
+        one = init.clone()
+        need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, d)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev())
+        hip.call('sn_conv_wgrad', dy, x, one, N, H, W, C, C, O, Op, K, K, s, p, d, ws, need, hip.stream())
+        singles.append((one, init))
+    tab = hip.wgrad_table(probs)
+    need = hip.query('sn_conv_wgrad_batch_workspace_bytes', tab, len(probs))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev())
+    hip.call('sn_conv_wgrad_batch', tab, len(probs), ws, need, hip.stream())
+    torch.cuda.synchronize()
+    for pr, (one, init) in zip(probs, singles):
+        got, want = (pr[2] - init).cpu().numpy(), (one - init).cpu().numpy()
+        assert np.abs(want).max() > 1.0
+        assert_close(got, want, 0.0, 2e-5 * np.abs(want).max(), 'batched wgrad %s' % (pr[3:],))
 
 
 def _check_dgrad_wgrad(case, dgrad=True, wgrad=True):
@@ -397,24 +429,20 @@ def test_sgd_and_weight_transpose():
     assert torch.equal(wp[..., :O], wt) and float(wp[..., O:].abs().sum()) == 0
 
 
-CONV_DMA_BM = {1: 128, 2: 128, 3: 256, 4: 128, 5: 64, 6: 64, 7: 256, 8: 128, 9: 128, 18: 160, 19: 128, 20: 192}
+CONV_DMA_BM = {4: 128, 5: 64, 6: 64, 7: 256, 14: 160, 16: 160, 18: 160}
 
 
-@pytest.mark.parametrize('N,H,C,O,K,bm,res', [(3, 17, 64, 192, 1, '64', False), (2, 24, 128, 256, 3, '128', True), (5, 9, 64, 128, 3, '64', True),
-                                              (4, 32, 256, 320, 1, '128', False), (2, 24, 128, 256, 3, 'dma3', True), (3, 17, 64, 192, 1, 'dma6', False),
-                                              (4, 32, 256, 320, 1, 'dma4', False), (5, 9, 64, 128, 3, 'dma8', True), (2, 24, 128, 256, 3, 'dma7', True),
-                                              (2, 24, 128, 256, 3, 'dma18', True), (4, 32, 256, 320, 1, 'dma19', False), (3, 17, 64, 192, 1, 'dma20', False)])
+@pytest.mark.parametrize('N,H,C,O,K,bm,res', [(3, 17, 64, 192, 1, 'dma5', False), (2, 24, 128, 256, 3, 'dma14', True), (5, 9, 64, 128, 3, 'dma6', True),
+                                              (4, 32, 256, 320, 1, 'dma16', False), (3, 17, 64, 192, 1, 'dma6', False),
+                                              (4, 32, 256, 320, 1, 'dma4', False), (5, 9, 64, 128, 3, 'dma16', True), (2, 24, 128, 256, 3, 'dma7', True),
+                                              (2, 24, 128, 256, 3, 'dma18', True), (4, 32, 256, 320, 1, 'dma18', False)])
 def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch, conv_tuning):
     """sn_conv_fwd_stats: same output as sn_conv_fwd, and the per-row-tile partials sum to the statistics of the STORED
-    fp16 tensor (what sn_bn_stats would read back); register-staged kernel at both tile heights and LDS-DMA configurations
+    fp16 tensor (what sn_bn_stats would read back); LDS-DMA configurations (4-wave, 8-wave, producer / consumer specialised)
     with 2 / 4 waves along M, ragged M / Cout tiles, residual epilogue."""
     hip = _hip()
-    if bm.startswith('dma'):
-        hip.call('sn_conv_tune', int(bm[3:]))
-        bm = str(CONV_DMA_BM[int(bm[3:])])
-    else:
-        hip.call('sn_conv_tune', 0)
-        monkeypatch.setenv('SNIPER_CONV_BM', bm)
+    hip.call('sn_conv_tune', int(bm[3:]))
+    bm = str(CONV_DMA_BM[int(bm[3:])])
     rs = np.random.RandomState(N * H + O)
     x = rs.standard_normal((N, H, H, C)).astype(np.float32)
     w = (rs.standard_normal((O, K * K, C)) / np.sqrt(K * K * C)).astype(np.float32)
@@ -456,19 +484,15 @@ def test_conv_fwd_stats_epilogue(N, H, C, O, K, bm, res, monkeypatch, conv_tunin
     assert hip.query('sn_conv_fwd_stats_blocks', N, H, H, C, C, 48, 48, 0, 1, 1, 1, 0, 1) == 0
 
 
-@pytest.mark.parametrize('N,H,C,O,K,bm,act', [(3, 17, 128, 192, 1, '64', 1), (2, 24, 128, 256, 3, '128', 1), (4, 12, 192, 64, 3, '64', 0),
-                                              (2, 16, 320, 128, 1, '128', 2), (2, 24, 128, 256, 3, 'dma1', 1), (3, 17, 128, 192, 1, 'dma5', 1),
-                                              (2, 24, 128, 256, 3, 'dma18', 1), (3, 17, 128, 192, 1, 'dma19', 2)])
+@pytest.mark.parametrize('N,H,C,O,K,bm,act', [(3, 17, 128, 192, 1, 'dma6', 1), (2, 24, 128, 256, 3, 'dma16', 1), (4, 12, 192, 64, 3, 'dma5', 0),
+                                              (2, 16, 320, 128, 1, 'dma14', 2), (2, 24, 128, 256, 3, 'dma14', 1), (3, 17, 128, 192, 1, 'dma5', 1),
+                                              (2, 24, 128, 256, 3, 'dma18', 1), (3, 17, 128, 192, 1, 'dma18', 2)])
 def test_conv_dgrad_bn_epilogue(N, H, C, O, K, bm, act, monkeypatch, conv_tuning):
     """sn_conv_dgrad_bn: same dx as sn_conv_dgrad, and partials that make sn_bn_backward_blocks reproduce sn_bn_backward
-    (dx of the BatchNorm below, dgamma, dbeta) -- ReLU / none / ReLU6 masks, both tile heights, ragged tiles."""
+    (dx of the BatchNorm below, dgamma, dbeta) -- ReLU / none / ReLU6 masks, several tile configurations, ragged tiles."""
     hip = _hip()
-    if bm.startswith('dma'):
-        hip.call('sn_conv_tune', int(bm[3:]))
-        bm = str(CONV_DMA_BM[int(bm[3:])])
-    else:
-        hip.call('sn_conv_tune', 0)
-        monkeypatch.setenv('SNIPER_CONV_BM', bm)
+    hip.call('sn_conv_tune', int(bm[3:]))
+    bm = str(CONV_DMA_BM[int(bm[3:])])
     rs = np.random.RandomState(N + H + C)
     M = N * H * H
     dy = torch.from_numpy(rs.standard_normal((N, H, H, O)).astype(np.float32)).to(dev()).half()

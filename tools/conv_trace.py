@@ -2,7 +2,7 @@
 index prologue + first operand stage in flight, K loop, epilogue stores, statistics -- and how the workgroups of one launch
 overlap in time.  The library must be loaded with SNIPER_CONV_TRACE=1 (this script sets it before importing sniper_amd).
 
-    python tools/conv_trace.py [--batch 20] [--cfgs 1,6] [--only 's3 ']
+    python tools/conv_trace.py [--batch 20] [--cfgs 14,18] [--only 's3 ']
 """
 import argparse
 import os
@@ -21,7 +21,7 @@ from conv_tune import LAYERS  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=20)
-    ap.add_argument('--cfgs', default='1,6')
+    ap.add_argument('--cfgs', default='14,18')
     ap.add_argument('--only', default='s3 ')
     ap.add_argument('--wgrad', action='store_true', help='trace conv_wgrad_tr_kernel (weight gradient) instead')
     a = ap.parse_args()

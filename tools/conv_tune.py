@@ -2,7 +2,7 @@
 for every (layer shape, direction) time each configuration with HIP events, check its output against the
 register-staged kernel (cfg 0) and print the table conv_plan()'s built-in choice is filled from.
 
-    python tools/conv_tune.py [--batch 20] [--iters 20] [--cfgs 0,1,3,5] [--only stage3]
+    python tools/conv_tune.py [--batch 20] [--iters 20] [--cfgs 0,14,16,18] [--only stage3]
 """
 import argparse
 import os
@@ -61,7 +61,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--cfgs', default='0,1,2,3,4,5,6,7,8,9,10,11,12,13,14')
+    ap.add_argument('--cfgs', default='0,4,5,6,7,14,16,18')
     ap.add_argument('--only', default='')
     ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (> L2 + Infinity Cache = 288): '
                     'every launch then reads operands no XCD has cached, as in the training step, where the producer of a tensor '

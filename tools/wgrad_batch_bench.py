@@ -1,5 +1,5 @@
 """Batched weight gradient (sn_conv_wgrad_batch, csrc/conv_wgrad_ps.hip) against per-layer launches, R101 / batch-20 shapes:
-every group is checked against the per-layer result of the round-1/2 kernels (impl 0) and timed with distinct operands per layer.
+every group is checked against the per-layer result of the gather fallback kernel (impl 0) and timed with distinct operands per layer.
 
     python tools/wgrad_batch_bench.py [--iters 10]
 """
@@ -63,7 +63,7 @@ def main():
             pr, f = make(name, copies)
             probs += pr
             fl += f
-        # reference: per-layer launches of the round-1/2 kernels
+        # reference: per-layer launches of the gather kernel (impl 0)
         hip.call('sn_conv_wgrad_impl', 0, 0)
         need0 = max(hip.query('sn_conv_wgrad_workspace_bytes', *pr[3:]) for pr in probs)
         ws0 = torch.empty(max(need0, 16), dtype=torch.uint8, device=d)

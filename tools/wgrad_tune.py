@@ -1,6 +1,7 @@
-"""Sweep the weight-gradient kernel choices (sn_conv_wgrad_tune) over the R101 / batch-20 layer shapes (BASELINE C2):
-register-staged tap-per-workgroup kernel vs the LDS-DMA flat / all-taps kernels, each checked against an fp32 torch
-contraction on a sub-sampled set of output elements and against the register-staged result.
+"""Per-layer launches of the weight gradient (sn_conv_wgrad) over the R101 / batch-20 layer shapes (BASELINE C2), modes =
+(impl, job_steps) of sn_conv_wgrad_impl: the wave-specialised kernel with its built-in or a forced job length, or the gather
+fallback (impl 0); each checked against an fp32 torch contraction on a sub-sampled set of output elements and against the first
+mode's result.  (The training step launches TABLES of layers: tools/wgrad_batch_bench.py.)
 
     python tools/wgrad_tune.py [--batch 20] [--iters 20] [--only s3]
 """
@@ -37,7 +38,7 @@ LAYERS = [
     ('fc_new_2 1024->1024 x6000', 0, 0, 1024, 1024, 1, 1, 0, 1, 1),
     ('fc cls 1024->81 x6000', 0, 0, 1024, 81, 1, 1, 0, 1, 1),
 ]
-MODES = [(-1, -1, 0), (0, 0, 512), (0, 0, 256), (0, 0, 384), (2, 4, 512), (2, 4, 256), (3, 3, 512)]
+MODES = [(1, 0), (1, 40), (1, 10), (0, 0)]
 
 
 def timeit(fn, iters, warm=3):
@@ -73,7 +74,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--cold', type=int, default=0, help='MB of distinct operand sets to cycle through (see tools/conv_tune.py)')
-    ap.add_argument('--modes', default='', help='e.g. "-1/-1/0,0/0/256" (flat stages / taps stages / workgroup target)')
+    ap.add_argument('--modes', default='', help='e.g. "1/0,1/40,0/0" (impl / job K-steps)')
     a = ap.parse_args()
     global MODES
     if a.modes:
@@ -83,7 +84,7 @@ def main():
     g = torch.Generator(device=d)
     g.manual_seed(0)
     h = lambda *s: (torch.randn(*s, device=d, generator=g) * 0.5).half()
-    print('device', torch.cuda.get_device_name(0), 'batch', B, 'modes (flat stages, taps stages)', MODES, flush=True)
+    print('device', torch.cuda.get_device_name(0), 'batch', B, 'modes (impl, job steps)', MODES, flush=True)
     tot = {m: 0.0 for m in MODES}
     for (name, H, W, C, O, K, s, p, dl, cnt) in LAYERS:
         if a.only and a.only not in name:
@@ -108,7 +109,7 @@ def main():
         ref = reference_samples(x, dy, K, s, p, dl, Ho, Wo, cos, cis)
         row, base = {}, None
         for m in MODES:
-            hip.call('sn_conv_wgrad_tune', m[0], m[1], m[2])
+            hip.call('sn_conv_wgrad_impl', m[0], m[1])
             need = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, dl)
             wsb = torch.empty(max(need, 16), dtype=torch.uint8, device=d)
             dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=d)
@@ -127,15 +128,15 @@ def main():
                 dself = float((dw - base).abs().max() / base.abs().max().clamp_min(1e-6))
             us = timeit(run, max(a.iters, 2 * nbuf))
             row[m] = (us, err, dself)
-        hip.call('sn_conv_wgrad_tune', -1, -1, 0)
-        cells = ' '.join('%s:%7.1f%s' % ('%d/%d/%d' % m, row[m][0], '' if (row[m][1] < 2e-3 and row[m][2] < 2e-3) else '!ERR(ref %.1e self %.1e)' % row[m][1:])
+        hip.call('sn_conv_wgrad_impl', 1, 0)
+        cells = ' '.join('%s:%7.1f%s' % ('%d/%d' % m, row[m][0], '' if (row[m][1] < 2e-3 and row[m][2] < 2e-3) else '!ERR(ref %.1e self %.1e)' % row[m][1:])
                          for m in MODES)
         bm = min(row, key=lambda m: row[m][0])
         print('%-28s P=%6d Cout=%4d Cin=%5d taps=%d x%2d | %s | best %s %.0f TF/s (legacy %.0f TF/s)' % (
-            name, N * Ho * Wo, O, C, K * K, cnt, cells, '%d/%d/%d' % bm, fl / row[bm][0] / 1e6, fl / row[MODES[0]][0] / 1e6), flush=True)
+            name, N * Ho * Wo, O, C, K * K, cnt, cells, '%d/%d' % bm, fl / row[bm][0] / 1e6, fl / row[MODES[0]][0] / 1e6), flush=True)
         for m in MODES:
             tot[m] += row[m][0] * cnt
-    print('per-step totals (ms): ' + ' '.join('%d/%d/%d:%.2f' % (m[0], m[1], m[2], tot[m] / 1e3) for m in MODES))
+    print('per-step totals (ms): ' + ' '.join('%d/%d:%.2f' % (m[0], m[1], tot[m] / 1e3) for m in MODES))
 
 
 if __name__ == '__main__':
