@@ -8,6 +8,7 @@
 // channels, so each lane moves 16 bytes per corner and a wave covers 512 channels of one sample.
 // HBM-bound: DPSROIPool forward writes R*49*C*2 bytes and reads the (L2-resident) feature map.
 #include "common.h"
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -192,7 +193,35 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
 #pragma unroll
     for (int j = 0; j < 8; ++j) sum[j] = 0.f;
     const half_t *img = img0 + ch;
-    if (!b.slow) {
+    if (!b.slow && b.nx > 0 && b.nx <= 4 && b.ny <= 4) {
+      // the common case (a bin of a training RoI covers 2-4 cells per axis): all window cells are requested back to back --
+      // N x N independent 16-byte loads in flight per lane instead of a load / FMA chain inside two data-dependent loops (the
+      // kernel was latency-bound on its gathers: 1.5 TB/s of a write stream that alone would run at 5+).  Cells beyond the
+      // window repeat its last row / column (a cached line) with weight 0.
+      const int nx = b.nx, ny = b.ny;
+      const half_t *base = img + ((size_t)b.y_lo * W + b.x_lo) * C;
+      auto window = [&](auto n_tag) {
+        constexpr int NW = decltype(n_tag)::value;
+        half8 v[NW][NW];
+#pragma unroll
+        for (int ky = 0; ky < NW; ++ky) {
+          const half_t *row = base + (size_t)min(ky, ny - 1) * W * C;
+#pragma unroll
+          for (int kx = 0; kx < NW; ++kx) v[ky][kx] = *reinterpret_cast<const half8 *>(row + (size_t)min(kx, nx - 1) * C);
+        }
+#pragma unroll
+        for (int ky = 0; ky < NW; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < NW; ++kx) {
+            const float wgt = b.wy[ky] * b.wx[kx];      // zero beyond (ny, nx): BinWin pads its weights with zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += wgt * (float)v[ky][kx][j];
+          }
+      };
+      if (nx <= 2 && ny <= 2) window(std::integral_constant<int, 2>{});
+      else if (nx <= 3 && ny <= 3) window(std::integral_constant<int, 3>{});
+      else window(std::integral_constant<int, 4>{});
+    } else if (!b.slow) {
       for (int ky = 0; ky < b.ny; ++ky) {
         const float wy = b.wy[ky];
         if (wy == 0.f) continue;

@@ -12,6 +12,7 @@ moved to the GPU (MI355X first, not a translation of the host loops):
 Dataset I/O (imdb, pickled caches, visualisation) is out of scope: `imdb` only needs `result_path`, `num_classes`,
 `classes`, `name`."""
 import math
+import threading
 
 import numpy as np
 import torch
@@ -24,6 +25,9 @@ from .ext import cpu_nms as _cpu_nms
 from .ext import gpu_nms as _gpu_nms
 from .iterators.MNIteratorTestAutoFocus import MNIteratorTestAutoFocus
 from .iterators.PrefetchingIter import PrefetchingIter
+
+
+_PINNED = {}     # (output, shape, dtype, ping / pong) -> pinned host tensor of Tester._launch
 
 
 class nms_wrapper(object):
@@ -213,11 +217,13 @@ class Tester(object):
     # that batch's copy event only.  A captured forward replays into the SAME output tensors, so the copies are enqueued before
     # the next forward on the same stream and land in one of two alternating pinned sets.
     def _pinned(self, key, like, dtype=None):
-        pool = self.__dict__.setdefault('_pin', {})
-        k = (key, tuple(like.shape), dtype or like.dtype, self.__dict__.setdefault('_pin_flip', 0))
-        t = pool.get(k)
+        # process-wide and never released: a pinned block returned to torch's host allocator from a garbage-collected Tester
+        # makes that allocator query events / free host memory at an arbitrary moment -- inside another executor's hipGraph
+        # capture that is an illegal call and the process aborts (seen once, in the -m gpu suite).  One entry per output shape.
+        k = (threading.get_ident(), key, tuple(like.shape), dtype or like.dtype, self.__dict__.setdefault('_pin_flip', 0))
+        t = _PINNED.get(k)
         if t is None:
-            t = pool[k] = torch.empty(tuple(like.shape), dtype=dtype or like.dtype, pin_memory=True)
+            t = _PINNED[k] = torch.empty(tuple(like.shape), dtype=dtype or like.dtype, pin_memory=True)
         return t
 
     def _launch(self, batch):

@@ -20,6 +20,7 @@ def main():
     from sniper_amd import config as cfgmod
     from sniper_amd.inference import imdb_detection_wrapper
     from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+    from bench import focus_map_blobs
 
     class Imdb(object):
         num_classes, classes, name, result_path = 81, None, 'synthetic', None
@@ -35,7 +36,8 @@ def main():
         t0 = time.perf_counter()
         if pr:
             pr.enable()
-        imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache)
+        imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache,
+                               focus_map_fn=focus_map_blobs)
         torch.cuda.synchronize()
         if pr:
             pr.disable()
