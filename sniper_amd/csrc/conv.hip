@@ -563,11 +563,14 @@ static int wgrad_legacy(const void *dy, const void *x, float *dw, int N, int H, 
 }
 
 // ---- entry points: one layer, or a table of layers in one launch (conv_wgrad_ps.hip) ----
+static int g_wgrad_na = 0;     // 0 = by layer width (Cout > 128: 256 x 128 tiles), 1 / 2 = forced (sn_conv_wgrad_impl's job_steps >= 100000)
 static int g_wgrad_impl = 1;   // 1 = wave-specialised batched kernel, 0 = the gather kernel (sn_conv_wgrad_impl: tests, A/B)
 SN_EXPORT int sn_conv_wgrad_impl(int impl, int job_steps) {
   SN_REQUIRE((impl == 0 || impl == 1) && job_steps >= 0, "sn_conv_wgrad_impl: impl in {0, 1}, job_steps >= 0");
   g_wgrad_impl = impl;
-  wgrad_ps_set_job_steps(job_steps);
+  g_wgrad_na = job_steps / 100000;                 // tuning only: 100000 / 200000 + steps forces 128- / 256-row tiles for every layer
+  SN_REQUIRE(g_wgrad_na >= 0 && g_wgrad_na <= 2, "sn_conv_wgrad_impl: bad tile selector");
+  wgrad_ps_set_job_steps(job_steps % 100000);
   return SN_OK;
 }
 
@@ -593,34 +596,44 @@ static bool wgrad_desc_params(const sn_wgrad_desc &d, WgradParams &p) {
 static int wgrad_batch_run(const sn_wgrad_desc *descs, int n, void *ws, size_t ws_bytes, hipStream_t s, bool launch, size_t *need) {
   size_t off = 0;
   WgradParams chunk[kWgradMaxProblems];
-  int nc = 0;
+  int nc = 0, na = 1;
   auto flush = [&]() -> int {
     if (!nc) return SN_OK;
     WgradBatch tab;
     char *base = ws ? static_cast<char *>(ws) + off : nullptr;
-    size_t bytes = wgrad_ps_plan(chunk, nc, tab, base);
+    size_t bytes = wgrad_ps_plan(chunk, nc, tab, base, true, na);
     if (launch) {
       // too little scratch (or none): the chunk runs unsplit -- slower, same result modulo summation order, never atomics
-      if (bytes && !(ws && off + bytes <= ws_bytes && ((uintptr_t)base % 16) == 0)) bytes = wgrad_ps_plan(chunk, nc, tab, nullptr, false);
-      if (int rc = wgrad_ps_launch(tab, s)) return rc;
+      if (bytes && !(ws && off + bytes <= ws_bytes && ((uintptr_t)base % 16) == 0)) bytes = wgrad_ps_plan(chunk, nc, tab, nullptr, false, na);
+      if (int rc = wgrad_ps_launch(tab, s, na)) return rc;
     }
     off += bytes;
     nc = 0;
     return SN_OK;
   };
+  for (int i = 0; i < n; ++i) {
+    WgradParams p;
+    SN_REQUIRE(wgrad_desc_params(descs[i], p), "sn_conv_wgrad_batch: bad dims in problem %d", i);
+    if (launch) SN_REQUIRE(descs[i].dy && descs[i].x && descs[i].dw, "sn_conv_wgrad_batch: null pointer in problem %d", i);
+  }
+  // Two passes over the table: the wide layers (Cout > 128) on 256 x 128 tiles with eight consumer waves, the narrow ones on
+  // 128 x 128 tiles with four (a 256-row tile of a 128-channel layer would multiply zeros in half of its waves).
   // chunks: <= 24 problems (the table is a kernel argument), cut where the job count fills whole rounds of the 256 CUs -- a chunk
   // of 528 equal jobs runs as long as one of 768; one of 492 runs like 512
-  long jobs = 0;
   auto fill = [](long j) { return j <= 0 ? 0.0 : (double)j / (256.0 * (double)((j + 255) / 256)); };
-  for (int i = 0; i < n; ++i) {
-    const sn_wgrad_desc &d = descs[i];
-    WgradParams p;
-    SN_REQUIRE(wgrad_desc_params(d, p), "sn_conv_wgrad_batch: bad dims in problem %d", i);
-    if (launch) SN_REQUIRE(d.dy && d.x && d.dw, "sn_conv_wgrad_batch: null pointer in problem %d", i);
-    if (g_wgrad_impl == 1 && wgrad_ps_ok(p)) {
+  for (int pass = 2; pass >= 1; --pass) {
+    na = pass;
+    long jobs = 0;
+    for (int i = 0; i < n; ++i) {
+      const sn_wgrad_desc &d = descs[i];
+      WgradParams p;
+      wgrad_desc_params(d, p);
+      if (!(g_wgrad_impl == 1 && wgrad_ps_ok(p))) continue;
+      const int want = g_wgrad_na ? g_wgrad_na : (p.Cout > 128 ? 2 : 1);
+      if (want != pass) continue;
       const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
       const long steps = flat ? sn_div_up(sn_div_up(p.N * p.H * p.W, 32), 2) : sn_div_up(p.N * p.Ho * sn_div_up(p.Wo, 32), 2);
-      const long j = (long)sn_div_up(p.Cout, 128) * sn_div_up(p.Cin, 128) * p.KH * p.KW * ((steps + 399) / 400);
+      const long j = (long)sn_div_up(p.Cout, 128 * na) * sn_div_up(p.Cin, 128) * p.KH * p.KW * ((steps + 399) / 400);
       if (nc && jobs >= 200 && fill(jobs) >= 0.93 && fill(jobs + j) < fill(jobs) - 0.02) {
         if (int rc = flush()) return rc;
         jobs = 0;
@@ -631,19 +644,24 @@ static int wgrad_batch_run(const sn_wgrad_desc *descs, int n, void *ws, size_t w
         if (int rc = flush()) return rc;
         jobs = 0;
       }
-    } else {
-      const size_t bytes = wgrad_legacy_workspace_bytes(d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad, d.dil);
-      if (launch) {
-        char *base = ws ? static_cast<char *>(ws) + off : nullptr;
-        const size_t have = ws && off + bytes <= ws_bytes ? bytes : 0;
-        if (int rc = wgrad_legacy(d.dy, d.x, d.dw, d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad,
-                                  d.dil, have ? base : nullptr, have, s))
-          return rc;
-      }
-      off += bytes;
     }
+    if (int rc = flush()) return rc;
   }
-  if (int rc = flush()) return rc;
+  for (int i = 0; i < n; ++i) {      // what the batched kernel cannot take: the gather kernel, one launch per layer
+    const sn_wgrad_desc &d = descs[i];
+    WgradParams p;
+    wgrad_desc_params(d, p);
+    if (g_wgrad_impl == 1 && wgrad_ps_ok(p)) continue;
+    const size_t bytes = wgrad_legacy_workspace_bytes(d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad, d.dil);
+    if (launch) {
+      char *base = ws ? static_cast<char *>(ws) + off : nullptr;
+      const size_t have = ws && off + bytes <= ws_bytes ? bytes : 0;
+      if (int rc = wgrad_legacy(d.dy, d.x, d.dw, d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad,
+                                d.dil, have ? base : nullptr, have, s))
+        return rc;
+    }
+    off += bytes;
+  }
   if (need) *need = off;
   return SN_OK;
 }

@@ -90,8 +90,9 @@ struct WgradBatch {
   WgradProblem p[kWgradMaxProblems];
 };
 bool wgrad_ps_ok(const WgradParams &p);                                           // operands 16-byte addressable, < 1 GB each
-size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bool allow_split = true);   // -> scratch bytes of the split problems
-int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s);
+// na = 128-channel dY sub-tiles per job (1: 128 x 128 output tiles, 2: 256 x 128); every problem of a table uses the same
+size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bool allow_split, int na);   // -> scratch bytes of the split problems
+int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s, int na);
 void wgrad_ps_set_job_steps(int steps);
 void wgrad_ps_set_trace(unsigned long long *buf);
 

@@ -29,6 +29,7 @@
 // per 20.  Jobs are numbered problem-major and every XCD gets a contiguous range of them, so the tiles that share a problem's dY / X
 // panels fetch them through ONE L2.  Problems whose jobs would be much longer than the rest are still split (slab + reduce).
 #include "conv_common.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef short short4v __attribute__((vector_size(8)));
@@ -59,14 +60,23 @@ __device__ __forceinline__ half8 tr_frag(const half_t *lds_tile, int off) {
 // offset can bring it back under a descriptor's num_records, so it reads zeros for the whole job without a select per piece
 constexpr unsigned kPoison = 0x80000000u;
 
-constexpr int kTile = 64 * 128;       // half_t per operand and stage: 64 pixels x 128 channels
-constexpr int kStage = 2 * kTile;     // dY tile, then X tile
+constexpr int kTile = 64 * 128;       // half_t per 128-channel operand sub-tile and stage: 64 pixels x 128 channels
 
 // TRACE: wave 0 (consumer) and wave 4 (producer) of every workgroup sum the shader-clock cycles of their phases into tab.trace
 // [job][8] = {life, K loop, consumer barrier wait, epilogue, producer vmcnt wait, producer barrier wait, producer issue, K-steps}
-template <int S, bool TRACE>
-__global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
-  constexpr int MI = 4, NI = 4, L = 8;   // L: LDS-DMA pieces a producer issues per stage
+// NA = 128-channel sub-tiles of dY per job: the job's output tile is (128 NA) co x 128 ci.  NA = 1: 4-stage ring of 32 KB (narrow
+// layers, Cout <= 128).  NA = 2: 3-stage ring of 48 KB: a K-step of two tiles' worth of MFMAs is staged with 48 pieces instead of 64.
+// MI = 16-row co blocks per consumer wave (wave tile 16 MI x 64): 4.  NA = 2 runs EIGHT consumer waves of 64 x 64 (two per SIMD).
+// Measured (profiles/r03_wgrad_ps_trace.txt): a K-step costs 893-933 cycles for NA = 1 and 1375-1450 for NA = 2 with twice the
+// work -- both about (LDS-DMA bytes + fragment bytes) / 128 B per clock: the LDS, not the matrix pipe (512 / 1024 cycles per SIMD)
+// and not HBM, is what a step waits for.  Tried and removed: NA = 2 with FOUR consumers of 128 x 64 (MI = 8; 96 KB instead of
+// 128 KB of fragment reads per step, quarter-step register schedule to stay under 256 VGPRs): 1444-1817 cycles per step -- one
+// wave per SIMD exposes every MFMA issue stall that a second wave on the SIMD hides -- 23.4 ms per training step against 22.1.
+template <int S, int NA, int MI, bool TRACE>
+__global__ __launch_bounds__(64 * (16 * NA / MI + 4)) void wgrad_ps_kernel(const WgradBatch tab) {
+  constexpr int NI = 4, NC = 16 * NA / MI, L = 4 * (NA + 1);   // NC consumer waves (8 NA / MI along co x 2 along ci); L: LDS-DMA pieces a producer issues per stage
+  constexpr int kStage = (NA + 1) * kTile;                       // NA dY sub-tiles, then the X tile
+  static_assert((S - 1) * L < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) half_t lds[S * kStage];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,26 +95,30 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
   const int by = r / gx, bx = r - by * gx;
   const int split = bz / taps, tap = bz - split * taps;
   const int kh = tap / P.KW, kw = tap - kh * P.KW;
-  const int co0 = bx * 128, ci0 = by * 128;
+  const int co0 = bx * (128 * NA), ci0 = by * 128;
   const int Cout = P.Cout, Cin = P.Cin;
   const int u_begin = split * P.units_per_split, u_end = min(P.nunits, u_begin + P.units_per_split);
   const int nk = u_end > u_begin ? (u_end - u_begin + 1) >> 1 : 0;
 
-  if (wave >= 4) {
+  if (wave >= NC) {
     // ================================ producer ================================
-    const int h = (wave - 4) >> 1, sub = (wave - 4) & 1;   // 32-pixel unit of every K-step, 16-pixel half of that unit
+    const int h = (wave - NC) >> 1, sub = (wave - NC) & 1;   // 32-pixel unit of every K-step, 16-pixel half of that unit
     const int r4 = lane >> 4, slot = lane & 15;
     const unsigned dy_ps_b = (unsigned)P.dy_ps * 2u, x_ps_b = (unsigned)P.x_ps * 2u;
     const int stride = P.stride, Wo = P.Wo, Ho = P.Ho, H = P.H, W = P.W, cpr = P.cpr;
     const int row_shift = kh * P.dil - P.pad;      // source row of output row oy: oy * stride + row_shift
     // piece j = 0..3: unit rows 16 sub + 4j + r4, tile rows 32h + 16 sub + 4j + r4; (tile row & 7) = ((j & 1) << 2) | r4 -> the source
     // chunk that belongs in this lane's 16-byte slot differs between even and odd pieces
-    unsigned a_base[2], b_base[2];
+    unsigned a_base[NA][2], b_base[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const int gc = ((((slot >> 1) ^ ((o << 2) | r4)) << 1) | (slot & 1));
       const int ur = 16 * sub + r4;
-      a_base[o] = co0 + gc * 8 < Cout ? (unsigned)ur * dy_ps_b + (unsigned)(co0 + gc * 8) * 2u : kPoison;
+#pragma unroll
+      for (int ta = 0; ta < NA; ++ta) {
+        const int co = co0 + ta * 128 + gc * 8;
+        a_base[ta][o] = co < Cout ? (unsigned)ur * dy_ps_b + (unsigned)co * 2u : kPoison;
+      }
       b_base[o] = ci0 + gc * 8 < Cin ? (unsigned)((ur * stride - P.pad + kw * P.dil) * (int)x_ps_b) + (unsigned)(ci0 + gc * 8) * 2u : kPoison;
     }
     const unsigned a_step = 4u * dy_ps_b, b_step = 4u * (unsigned)stride * x_ps_b;   // piece j -> j + 1
@@ -124,9 +138,11 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
       const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(dyb) + dy_off, 0, have ? (int)((unsigned)(Wo - ox0) * dy_ps_b) : 0, 0x00020000);
       const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbp) + x_off, 0, rok ? (int)((unsigned)W * x_ps_b) : 0, 0x00020000);
       const unsigned b_ox = (unsigned)(ox0 * stride) * x_ps_b;
-      half_t *const sa = dst0 + buf * kStage, *const sb = sa + kTile;
+      half_t *const sa = dst0 + buf * kStage, *const sb = sa + NA * kTile;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dma16(rdy, sa + j * 512, a_base[j & 1] + (unsigned)j * a_step);
+      for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(rdy, sa + ta * kTile + j * 512, a_base[ta][j & 1] + (unsigned)j * a_step);
 #pragma unroll
       for (int j = 0; j < 4; ++j) dma16(rxx, sb + j * 512, b_base[j & 1] + b_ox + (unsigned)j * b_step);
       // advance by two units
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
       nxt = nxt + 1 == S ? 0 : nxt + 1;
       if (TRACE) { c_wait += t1 - t0; c_bar += t2 - t1; c_issue += __builtin_amdgcn_s_memtime() - t2; }
     }
-    if (TRACE && wave == 4 && lane == 0 && tab.trace) {
+    if (TRACE && wave == NC && lane == 0 && tab.trace) {
       unsigned long long *o = tab.trace + (size_t)item * 8;
       o[4] = c_wait; o[5] = c_bar; o[6] = c_issue;
     }
@@ -167,13 +183,16 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
   }
 
   // ================================ consumer ================================
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;          // wm: block of 16 MI co rows of the tile
   const int fr = lane & 15, fq = lane >> 4;
   // fragment reads: lane (fr, fq) points at row fq*4 + fr/4, 8-byte piece fr%4 of the fragment's 32-byte segment
   const int row0 = fq * 4 + (fr >> 2), q7 = row0 & 7;
   int a_off[MI], b_off[NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) a_off[i] = row0 * 128 + ((((wm * 4 + i) ^ q7) << 4) | ((fr & 3) << 2));
+  for (int i = 0; i < MI; ++i) {
+    const int rb = wm * MI + i;                      // 16-row co block of the tile: sub-tile rb >> 3, 32-byte segment rb & 7 of its rows
+    a_off[i] = (rb >> 3) * kTile + row0 * 128 + ((((rb & 7) ^ q7) << 4) | ((fr & 3) << 2));
+  }
 #pragma unroll
   for (int jn = 0; jn < NI; ++jn) b_off[jn] = row0 * 128 + ((((wn * 4 + jn) ^ q7) << 4) | ((fr & 3) << 2));
   floatx4 acc[MI][NI];
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
   const unsigned long long t_loop = TRACE ? __builtin_amdgcn_s_memtime() : 0;
   half8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
   auto read = [&](int buf, int ks, half8 (&fa)[MI], half8 (&fb)[NI]) {
-    const half_t *const sa = lds + buf * kStage + ks * 32 * 128, *const sb = sa + kTile;
+    const half_t *const sa = lds + buf * kStage + ks * 32 * 128, *const sb = sa + NA * kTile;
 #pragma unroll
     for (int i = 0; i < MI; ++i) fa[i] = tr_frag(sa, a_off[i]);
 #pragma unroll
@@ -214,11 +233,13 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
   // reads behind the last MFMA that uses their destination registers (what it does on its own: 32 reads back to back, then a
   // wait at the next step's first MFMA).
   auto interleave = [&]() {
+    constexpr int NR = 2 * (MI + NI), NM = MI * NI;     // transposing reads / MFMAs of a region
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < NR; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
     }
+    if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
   if (nk > 0) {
@@ -251,38 +272,42 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const WgradBatch tab) {
   if ((Cin & 3) == 0) {
     // every lane's 16 accesses are 16 bytes; an unsplit job first brings all 16 of its dw vectors in (loads back to back, one wait
     // chain), then adds and stores -- a load / wait / add / store per vector is 16 dependent memory round trips per lane
-    float *q[MI][NI];
-    bool ok[MI][NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i0 = 0; i0 < MI; i0 += 4) {          // four co blocks (16 vectors per lane) at a time: 64 registers of dw in flight
+      float *q[4][NI];
+      bool ok[4][NI];
 #pragma unroll
-      for (int jn = 0; jn < NI; ++jn) {
-        const int co = co0 + wm * 64 + i * 16 + fr, ci = ci0 + wn * 64 + jn * 16 + fq * 4;
-        ok[i][jn] = co < Cout && ci < Cin;
-        q[i][jn] = dst + ((size_t)co * taps + tap) * Cin + ci;
-      }
-    if (!to_slab) {
-      float4 o[MI][NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) o[i][jn] = ok[i][jn] ? *reinterpret_cast<const float4 *>(q[i][jn]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jn = 0; jn < NI; ++jn) {
-          acc[i][jn][0] += o[i][jn].x; acc[i][jn][1] += o[i][jn].y; acc[i][jn][2] += o[i][jn].z; acc[i][jn][3] += o[i][jn].w;
+          const int co = co0 + (wm * MI + i0 + i) * 16 + fr, ci = ci0 + wn * 64 + jn * 16 + fq * 4;
+          ok[i][jn] = co < Cout && ci < Cin;
+          q[i][jn] = dst + ((size_t)co * taps + tap) * Cin + ci;
         }
+      if (!to_slab) {
+        float4 o[4][NI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn) o[i][jn] = ok[i][jn] ? *reinterpret_cast<const float4 *>(q[i][jn]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn) {
+            floatx4 &a = acc[i0 + i][jn];
+            a[0] += o[i][jn].x; a[1] += o[i][jn].y; a[2] += o[i][jn].z; a[3] += o[i][jn].w;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+          if (ok[i][jn]) *reinterpret_cast<float4 *>(q[i][jn]) = make_float4(acc[i0 + i][jn][0], acc[i0 + i][jn][1], acc[i0 + i][jn][2], acc[i0 + i][jn][3]);
     }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int jn = 0; jn < NI; ++jn)
-        if (ok[i][jn]) *reinterpret_cast<float4 *>(q[i][jn]) = make_float4(acc[i][jn][0], acc[i][jn][1], acc[i][jn][2], acc[i][jn][3]);
   } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int co = co0 + wm * 64 + i * 16 + fr;
+      const int co = co0 + (wm * MI + i) * 16 + fr;
       if (co >= Cout) continue;
 #pragma unroll
       for (int jn = 0; jn < NI; ++jn) {
@@ -346,7 +371,7 @@ void wgrad_ps_set_job_steps(int steps) { g_wgrad_job_steps = steps; }
 
 // Fill tab (geometry, splits, item ranges) from n problems; slab pointers are offsets into `ws` (nullptr = size query).
 // Returns the scratch bytes the split problems need.
-size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bool allow_split) {
+size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bool allow_split, int na) {
   tab.n = n;
   long total_steps = 0;
   for (int i = 0; i < n; ++i) {
@@ -358,16 +383,37 @@ size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bo
     q.Ho = flat ? 1 : p.Ho; q.Wo = flat ? p.N * p.H * p.W : p.Wo;
     q.Cin = p.Cin; q.Cout = p.Cout; q.dy_ps = p.dy_ps; q.x_ps = p.x_ps;
     q.KH = p.KH; q.KW = p.KW; q.stride = p.stride; q.pad = p.pad; q.dil = p.dil;
-    q.gx = sn_div_up(p.Cout, 128); q.gy = sn_div_up(p.Cin, 128); q.taps = p.KH * p.KW;
+    q.gx = sn_div_up(p.Cout, 128 * na); q.gy = sn_div_up(p.Cin, 128); q.taps = p.KH * p.KW;
     q.cpr = sn_div_up(q.Wo, 32);
     q.nunits = q.N * q.Ho * q.cpr;
     q.slab_stride = (size_t)p.Cout * q.taps * p.Cin;
     total_steps += (long)q.gx * q.gy * q.taps * sn_div_up(q.nunits, 2);
   }
-  // longest job: about one CU's share of the launch, at most 400 K-steps (a stage-3 layer is 320), at least 16
-  long cap = g_wgrad_job_steps > 0 ? g_wgrad_job_steps : (total_steps + 255) / 256;
-  if (g_wgrad_job_steps <= 0) { if (cap > 400) cap = 400; if (cap < 16) cap = 16; }
-  if (!allow_split) cap = 1l << 30;     // no scratch: every job runs its whole K range (one owner per element, same result)
+  // Longest job (`cap`, in K-steps).  All jobs of a launch run in rounds of 256 (one workgroup per CU), so the launch takes about
+  // rounds(cap) * cap with rounds = ceil(jobs(cap) / 256): dividing the longest problem's K by s = 1, 2, ... the cheapest s wins
+  // (126 whole-K jobs of 320 steps: s = 2 -> 252 jobs of 160, one round; s = 3 -> 378 jobs of 107, TWO rounds = 214).  A split
+  // costs its slabs and a reduce launch (weighted 5 %), jobs under 16 steps are all fill and drain.
+  long cap = g_wgrad_job_steps;
+  if (cap <= 0) {
+    long longest = 1;
+    for (int i = 0; i < n; ++i) { const long st = sn_div_up(tab.p[i].nunits, 2); longest = st > longest ? st : longest; }
+    double best = 1e300;
+    cap = longest;
+    for (int sdiv = 1; sdiv <= 32; ++sdiv) {
+      const long c = (longest + sdiv - 1) / sdiv;
+      if (c < 16 && sdiv > 1) break;
+      long jobs = 0;
+      bool any_split = false;
+      for (int i = 0; i < n; ++i) {
+        const long st = sn_div_up(tab.p[i].nunits, 2), sp = (st + c - 1) / c;
+        jobs += (long)tab.p[i].gx * tab.p[i].gy * tab.p[i].taps * sp;
+        any_split |= sp > 1;
+      }
+      const double cost = (double)((jobs + 255) / 256) * (double)(c + 12) * (any_split ? 1.05 : 1.0);   // + 12: a job's fill and drain
+      if (cost < best - 1e-9) { best = cost; cap = c; }
+    }
+    (void)total_steps;
+  }
   size_t off = 0;
   int item = 0;
   for (int i = 0; i < n; ++i) {
@@ -409,10 +455,16 @@ size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bo
   return off;
 }
 
-int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s) {
+int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s, int na) {
   if (tab.total_items <= 0) return SN_OK;
-  if (tab.trace) hipLaunchKernelGGL((wgrad_ps_kernel<4, true>), dim3(8u * (unsigned)tab.per_xcd), dim3(512), 0, s, tab);
-  else hipLaunchKernelGGL((wgrad_ps_kernel<4, false>), dim3(8u * (unsigned)tab.per_xcd), dim3(512), 0, s, tab);
+  const dim3 grid(8u * (unsigned)tab.per_xcd);
+  if (na == 2) {
+    if (tab.trace) hipLaunchKernelGGL((wgrad_ps_kernel<3, 2, 4, true>), grid, dim3(768), 0, s, tab);
+    else hipLaunchKernelGGL((wgrad_ps_kernel<3, 2, 4, false>), grid, dim3(768), 0, s, tab);
+  } else {
+    if (tab.trace) hipLaunchKernelGGL((wgrad_ps_kernel<4, 1, 4, true>), grid, dim3(512), 0, s, tab);
+    else hipLaunchKernelGGL((wgrad_ps_kernel<4, 1, 4, false>), grid, dim3(512), 0, s, tab);
+  }
   SN_CHECK_LAUNCH();
   for (int i = 0; i < tab.n; ++i) {
     const WgradProblem &q = tab.p[i];

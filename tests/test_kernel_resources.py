@@ -39,8 +39,10 @@ def test_hot_kernels_keep_their_accumulators_in_registers():
         assert res['VGPRs'] <= 256, (name, res)
     ps = {k: v for k, v in _resources('conv_wgrad_ps').items() if 'wgrad_ps_kernel' in k}
     assert ps, 'wgrad_ps_kernel not built'
-    for name, res in ps.items():        # 64 accumulator + 64 fragment registers per consumer wave; 8 waves share 4 SIMDs: <= 256
-        assert res['ScratchSize'] == 0 and res['VGPRs Spill'] == 0 and res['VGPRs'] <= 256, (name, res)
+    for name, res in ps.items():        # 64 accumulator + 64 fragment registers per consumer wave; the 12-wave form (256 x 128 tiles:
+        # 8 consumers + 4 producers) has three waves per SIMD, i.e. at most 168 registers each
+        wide = 'ELi3ELi2E' in name
+        assert res['ScratchSize'] == 0 and res['VGPRs Spill'] == 0 and res['VGPRs'] <= (168 if wide else 256), (name, res)
     for frag in ('dpsroi_bwd_data_mfma_kernel', 'deform_col2im_data_mfma_kernel', 'dpsroi_bwd_trans_roi_kernel', 'dpsroi_fwd_roi_kernel'):
         hits = {k: v for k, v in roi.items() if frag in k}
         assert hits, frag

@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--iters', type=int, default=10)
-    ap.add_argument('--job-steps', type=int, default=0)
+    ap.add_argument('--job-steps', type=int, default=0, help='+100000 / +200000: force 128- / 256-row tiles')
     ap.add_argument('--trace', action='store_true', help='phase cycles per job (median over jobs) of the batched launch')
     ap.add_argument('--only', default='')
     a = ap.parse_args()
