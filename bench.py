@@ -17,14 +17,16 @@ Extra objects on the JSON line:
   roofline      the dominant kernel family (implicit-GEMM MFMA convolution: forward + data gradient + weight gradient
                 launches) measured live with HIP events recorded on the stream each kernel is launched on, in extra untimed
                 steps run eagerly (the timed region replays hipGraphs, inside which nothing can be bracketed):
-                  achieved / frac        IN SITU: the step as it is timed -- weight gradients on the side stream, overlapping the
-                                         data-gradient chain.  Sum of algorithmic FLOPs / sum of the launches' durations; this
-                                         is the figure `rocprofv3 --kernel-trace --stats` of this command reproduces
-                                         (profiles/r02_bench_kernel_stats.csv: FLOPs / summed conv-kernel time).
-                  achieved_isolated      the same launches on ONE stream (a launch's duration is its own).
+                  achieved / frac        IN SITU: the kernels and the one stream of the timed step.  Sum of algorithmic FLOPs / sum of
+                                         the launches' durations; this is the figure `rocprofv3 --kernel-trace --stats` of this
+                                         command reproduces (tools/roofline_check.py, profiles/r03_roofline_check.json).
                   step_tflops            conv FLOPs of a step / the timed ms_per_step (end to end, everything else included).
-                peak = 2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).  traffic = HBM bytes per conv launch from rocprofv3 --pmc
-                passes, reported only when they were collected on THIS build of the convolution sources (else null).
+                peak = 2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).  traffic = HBM bytes per KERNEL launch of the family from
+                rocprofv3 --pmc passes (traffic_detail: bytes per step, kernel launches per step), reported only when they were
+                collected on THIS build of the convolution sources (else null); entry_calls_per_step counts C-ABI calls (one
+                batched weight-gradient call covers up to 24 layers and several kernel launches).
+                roofline_hbm = the memory-bound kernels of the step (RoI pooling, deformable sampling, BatchNorm, NMS, anchor
+                labelling, SGD) against the 8 TB/s HBM roofline, from the same kind of PMC passes (profiles/pmc_kernels.json).
   cpu_baseline  the reference's CPU iterator path (chip extraction + box assignment + RPN anchor labelling) timed on this
                 node's host cores on a bounded sample, chips/s: kind "reference" = the reference's own
                 lib/data_utils/data_workers.py (lib2to3 artefact) over its compiled chips / bbox modules (oracle/_ref), kind
@@ -32,7 +34,9 @@ Extra objects on the JSON line:
                 baseline, never a speed-up claim.  `c1` inside it:
                 BASELINE configs[0] -- MobileNetV2 Faster-RCNN, 2 x 512 x 512 chips, one training step (forward + backward)
                 through the reference-semantics CPU operators of oracle/graph_cpu.py.
-  inference     BASELINE configs[4] (AutoFocus inference, `inf images/sec`); --no-inference skips it.
+  inference     BASELINE configs[4] (AutoFocus inference, `inf images/sec`) on injected FocusPixel maps (~10 % positive pixels in
+                blobs), with its own cpu_baseline (the reference's aggregation + compiled soft-NMS under Pool(32));
+                --no-inference skips it.
 """
 import argparse
 import json
@@ -149,6 +153,47 @@ def conv_sources_hash():
     return h.hexdigest()[:16]
 
 
+def library_sources_hash():
+    """Identity of the whole kernel library (every .hip / .h under csrc): what the per-kernel PMC report was collected on."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, 'sniper_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h')):
+            with open(os.path.join(csrc, f), 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+HBM_KERNELS = ('dpsroi_fwd_roi_kernel', 'dpsroi_bwd_data_mfma_kernel', 'dpsroi_bwd_trans_roi_kernel', 'deform_im2col_kernel',
+               'deform_col2im_offset_kernel', 'deform_col2im_data_mfma_kernel', 'bn_apply_kernel', 'bn_bwd_dx_kernel',
+               'bn_bwd_reduce_kernel', 'nms_lazy_kernel', 'topk_select_sort_kernel', 'anchor_finish_kernel', 'chips_generate_kernel',
+               'sgd_dev_kernel', 'maxpool_kernel')
+
+
+def roofline_hbm():
+    """The memory-bound kernels of the step against the HBM roofline (8 TB/s): per kernel the launches, average duration and
+    HBM bytes fetched / written per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    (tools/gpu_session.sh pmc -> tools/pmc_report.py -> profiles/pmc_kernels.json; FETCH doubled, the gfx950 correction).  None
+    unless that report was collected on THIS build of the kernel library."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_kernels.json')) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if d.get('library_sources_hash') != library_sources_hash():
+        return None
+    out = []
+    for name in HBM_KERNELS:
+        hit = [(k, v) for k, v in d.get('kernels', {}).items() if name in k]
+        for k, v in hit[:1]:
+            gbs = v.get('hbm_gb_per_s')
+            out.append({'kernel': name, 'launches_profiled': v['launches'], 'avg_us': v['avg_us'],
+                        'fetch_mb': round(v['fetch_bytes_per_launch'] / 1e6, 2), 'write_mb': round(v['write_bytes_per_launch'] / 1e6, 2),
+                        'achieved_gb_s': gbs, 'frac_of_8tb_s': round(gbs / HBM_PEAK_GBS, 3) if gbs else None})
+    return out or None
+
+
 def pmc_traffic():
     """HBM bytes per conv-family launch from the committed rocprofv3 --pmc passes of this same command
     (tools/pmc_traffic.py -> profiles/pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
@@ -193,7 +238,8 @@ def cpu_baseline(seconds_target=15.0):
     what = ('the reference\'s own chip_worker.chip_extractor + box_assigner + anchor_worker.worker (lib/data_utils/data_workers.py '
             'translated by lib2to3, over its compiled chips.pyx / cchips.cpp / bbox.pyx; oracle/_ref)' if use_ref else
             'chip_extractor + box_assigner + anchor_worker (oracle/data_path.py, restating lib/data_utils/data_workers.py)')
-    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'kind': 'reference' if use_ref else 'port',
+    return {'value': n_chips / dt, 'unit': 'chips/s', 'cores': P, 'node_cores': os.cpu_count(),      # cores = the pool the work ran on
+            'kind': 'reference' if use_ref else 'port',
             'scope': 'data path only (a3-a6 of SURVEY section 8): a reported baseline, not comparable with the training-step '
                      'throughput above',
             'sample': '%d synthetic images -> %d chips: %s under multiprocessing.Pool(%d), %.1f s' % (n_img, n_chips, what, P, dt)}
@@ -488,6 +534,7 @@ def main():
             'step_tflops': round(tot_fl / 2 / (ms_per_step * 1e-3) / 1e12, 2), 'event_bracket_overhead_us': round(profile.overhead_us, 2),
             'traffic': pmc_traffic(),         # HBM bytes per KERNEL launch of the family (incl. the slab-reduce kernels)
             'traffic_detail': getattr(pmc_traffic, 'detail', None),
+            'roofline_hbm': roofline_hbm(),      # the memory-bound kernels of the step (RoI pooling, sampling, BatchNorm, NMS, labelling)
             'entry_calls_per_step': n_launch // 2,   # C-ABI calls bracketed with events (one batched weight-gradient call = up to 24 layers)
             'avg_launch_ms': round(tot_ms / max(1, n_launch), 4),
             'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),

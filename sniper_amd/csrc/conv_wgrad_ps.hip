@@ -414,6 +414,7 @@ size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bo
     }
     (void)total_steps;
   }
+  if (!allow_split) cap = 1l << 30;     // no scratch: every job runs its whole K range (one owner per element, same result)
   size_t off = 0;
   int item = 0;
   for (int i = 0; i < n; ++i) {

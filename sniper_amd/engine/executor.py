@@ -619,6 +619,10 @@ class Executor(object):
                 return self.outputs
             self._infer_calls += 1
             if self._infer_calls > 1:            # the first call ran eagerly: lazy allocations, parameter packing
+                import gc
+                gc.collect()
+                gc_was = gc.isenabled()
+                gc.disable()             # (no collection -- no foreign destructor freeing memory -- on a capturing stream: _capture)
                 try:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
@@ -631,6 +635,9 @@ class Executor(object):
                     warnings.warn('sniper_amd: hipGraph capture of the inference forward failed (%r); running eagerly' % (e,))
                     self.use_infer_graphs = False
                     torch.cuda.synchronize()
+                finally:
+                    if gc_was:
+                        gc.enable()
         self._forward_body()
         return self.outputs
 
@@ -661,6 +668,13 @@ class Executor(object):
     def _capture(self, fn, what, pool=None):
         """Capture fn() into a hipGraph; on failure fall back to eager execution for good.  pool: share the memory pool
         of an earlier capture that is always replayed right before this one (tensors live across the two)."""
+        # No garbage collection while capturing: a collected object of an earlier executor (its hipGraphs and their private
+        # memory pool, pinned buffers, events) frees device or host memory in its destructor, which is illegal on a capturing
+        # stream and aborts the process from inside whatever Python line happened to allocate (seen in the -m gpu suite).
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -674,6 +688,9 @@ class Executor(object):
             self.use_graphs = False
             torch.cuda.synchronize()
             return None
+        finally:
+            if gc_was:
+                gc.enable()
 
     def forward_backward(self, inputs, between=None):
         """One training forward + backward pass (graph replay once captured).  With a backward split, `between()` runs

@@ -41,6 +41,7 @@ pmc)
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json > /dev/null
   python tools/pmc_report.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_kernels.json | head -60
+  # (copy gpurun_out/pmc_traffic.json and gpurun_out/pmc_kernels.json to profiles/: bench.py reads them there, keyed on the source hash)
   find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete ;;
 esac
 done

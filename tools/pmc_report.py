@@ -51,6 +51,12 @@ def durations(d):
     return out
 
 
+def _lib_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import library_sources_hash
+    return library_sources_hash()
+
+
 def main():
     fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
     flt = [s for s in (sys.argv[4].split(',') if len(sys.argv) > 4 else []) if s]
@@ -68,7 +74,7 @@ def main():
                   'hbm_gb_per_s': round((fb + wb) / (us * 1e-6) / 1e9, 1) if us > 0 else None}
     doc = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); KiB -> bytes, FETCH_SIZE x2 '
                      '(gfx950 correction, MI355X_MICROARCH.md); durations from the kernel trace of the FETCH pass (profiled clocks)',
-           'peak_gb_per_s': 8000, 'kernels': res}
+           'peak_gb_per_s': 8000, 'library_sources_hash': _lib_hash(), 'kernels': res}
     with open(out, 'w') as fh:
         json.dump(doc, fh, indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -(kv[1]['avg_us'] * kv[1]['launches'])):
