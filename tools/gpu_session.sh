@@ -25,11 +25,11 @@ bench)
   echo "bench exit $?" >> gpurun_out/bench.log
   tail -2 gpurun_out/bench.log ;;
 prof)
-  # kernel stats of the SAME command (minus the CPU / inference legs): 3 + 10 + 1 + 6 = 20 steps of conv launches
+  # kernel stats of the SAME command (minus the CPU / inference legs): 3 + 10 + 1 + 3 = 17 steps of conv launches
   (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_bench" -o bench -- \
       python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-inference > "$ROOT/gpurun_out/rocprof_bench.log" 2>&1; echo "rocprof exit $?")
   F=$(find gpurun_out/prof_bench -name "*kernel_stats.csv" | head -1)
-  [ -n "$F" ] && head -30 "$F" && python tools/roofline_check.py "$F" gpurun_out/rocprof_bench.log 20 gpurun_out/roofline_check.json
+  [ -n "$F" ] && head -30 "$F" && python tools/roofline_check.py "$F" gpurun_out/rocprof_bench.log 17 gpurun_out/roofline_check.json
   T=$(find gpurun_out/prof_bench -name "*kernel_trace.csv" | head -1)
   [ -n "$T" ] && python tools/trace_gaps.py "$T" gpurun_out/trace_gaps.json --lo 0.45 --hi 0.75
   find gpurun_out/prof_bench -name "*kernel_trace.csv" -size +30M -delete ;;

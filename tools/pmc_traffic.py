@@ -38,7 +38,7 @@ def collect(d, counter):
 
 def main():
     fdir, wdir = sys.argv[1], sys.argv[2]
-    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10      # steps the profiled command ran: warmup 1 + 2 timed + 1 idle-device + 2 x 3 eager
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 7       # steps the profiled command ran: warmup 1 + 2 timed + 1 idle-device + 3 eager
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                              'profiles', 'pmc_traffic.json')
     fetch, write = collect(fdir, 'FETCH_SIZE'), collect(wdir, 'WRITE_SIZE')

@@ -3,8 +3,8 @@
 
     python tools/roofline_check.py <kernel_stats.csv> <bench json line file> <steps profiled> [out.json]
 
-steps profiled = warmup + steps + 1 (idle-device step) + 6 (the two eager profiling passes) of that bench.py run: every one of
-them launches the same conv kernels."""
+steps profiled = warmup + steps + 1 (idle-device step) + 3 (the eager profiling pass: one settling step, two bracketed) of that
+bench.py run: every one of them launches the same conv kernels."""
 import csv
 import json
 import sys
