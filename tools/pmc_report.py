@@ -17,6 +17,7 @@ import sys
 
 
 def short(name):
+    name = name.replace('(anonymous namespace)::', '')
     name = re.sub(r'\(.*', '', name)
     name = re.sub(r'^void ', '', name)
     m = re.match(r'_Z\d+([A-Za-z_0-9]+?)(I[A-Z].*|P.*|v)?$', name)
