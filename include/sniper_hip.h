@@ -131,6 +131,15 @@ int sn_im_prepare(const uint8_t *d_src_bgr, int src_h, int src_w, int crop_x1, i
  * rois (B*R,5) f32 with rows of chip b contiguous, deltas (B,R,4) f32, im_info (B,3) f32 -> boxes (B,R,4) f64. */
 int sn_bbox_decode(const float *d_rois, const float *d_deltas, const float *d_im_info, double *d_boxes, int B, int R,
                    sn_stream_t stream);
+/* The per-class score threshold of Tester.get_detections (lib/inference.py:289-295: inds = where(scores[:, j] > thresh), rows
+ * hstack(boxes[inds, 0:4], scores[inds, j])) and, when h_crops != NULL, the AutoFocus border pruning that follows it (:336-353,
+ * check_valid :236-259: rows shifted by the chip origin, dropped within `delta` px of a chip border that is not an image
+ * border), for the B <= 64 chips of a batch.  scores (B,R,NC) f32, boxes (B,R,4) f64 (sn_bbox_decode); h_crops (B,4) f64 and
+ * h_im_wh (B,2) f64 are HOST arrays (chip [x1,y1,x2,y2] in image coordinates; image width, height), passed to the kernel by
+ * value.  -> rows (B,(NC-1)*R,5) f64: the surviving rows of chip b, grouped by class 1..NC-1, RoIs ascending inside a class;
+ * counts (B,NC-1) i32 rows per class.  float64 adds and compares only: bit-exact with the numpy loops. */
+int sn_det_compact(const float *d_scores, const double *d_boxes, const double *h_crops, const double *h_im_wh, float thresh,
+                   double delta, int B, int R, int NC, double *d_rows, int32_t *d_counts, sn_stream_t stream);
 
 /* ================================================================ network operators ===========
  * The graph operators of the un-vendored SNIPER-mxnet fork, at the call sites of

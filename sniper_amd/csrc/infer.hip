@@ -10,6 +10,7 @@
 //    the image scale, as lib/inference.py:127-131 applies them per chip; float64 like the numpy original
 //    (boxes.astype(np.float)), compiled with -ffp-contract=off, exp() in double.
 #include "common.h"
+#include <string.h>
 
 __global__ __launch_bounds__(256) void im_prepare_kernel(const unsigned char *__restrict__ src, int SH, int SW, int x1, int y1,
                                                          int cw, int ch, float scale, int flip, float m0, float m1, float m2,
@@ -98,6 +99,90 @@ SN_EXPORT int sn_bbox_decode(const float *d_rois, const float *d_deltas, const f
   SN_REQUIRE(d_rois && d_deltas && d_im_info && d_boxes && B > 0 && R > 0, "sn_bbox_decode: bad arguments");
   hipLaunchKernelGGL(bbox_decode_kernel, dim3(sn_div_up(B * R, 256)), dim3(256), 0, sn_stream(stream), d_rois, d_deltas, d_im_info,
                      d_boxes, B, R);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// det_compact: the per-class score threshold of Tester.get_detections (lib/inference.py:289-295) and, for AutoFocus chips,
+// the border pruning that follows it (:336-353 with check_valid :236-259), for every chip of a batch on the GPU.  The host
+// loop does, per chip and class j, `inds = where(scores[:, j] > thresh)` -> rows [boxes[inds, 0:4], scores[inds, j]] (float64),
+// then shifts the rows by the chip's origin and drops those within `delta` px of a chip border that is not an image border.
+// Here one wave owns one (chip, class): a counting pass, then a writing pass that places the class's surviving rows (RoIs
+// ascending, as np.where walks them) behind those of the classes before it -- the host receives rows already grouped by class
+// plus the per-class counts and only slices.  All arithmetic in double, adds and compares only: bit-exact with numpy.
+struct DetChips {
+  double crop[64][4];     // chip [x1, y1, x2, y2] in image coordinates
+  double wh[64][2];       // image width, height
+};
+
+__device__ __forceinline__ bool det_keep(const float *__restrict__ scores, const double *__restrict__ boxes, const DetChips &ch,
+                                         int prune, float thresh, double delta, int b, int r, int j, int R, int NC, double *row) {
+  const float s = scores[((size_t)b * R + r) * NC + j];
+  if (!(s > thresh)) return false;
+  const double *bx = boxes + ((size_t)b * R + r) * 4;
+  double x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+  if (prune) {
+    const double cx1 = ch.crop[b][0], cy1 = ch.crop[b][1], cx2 = ch.crop[b][2], cy2 = ch.crop[b][3];
+    x1 += cx1; x2 += cx1; y1 += cy1; y2 += cy1;
+    // ~(abs(d - c) < delta): a NaN coordinate keeps the row, as the numpy mask does
+    if (cx1 >= 0.5 && fabs(x1 - cx1) < delta) return false;
+    if (cy1 >= 0.5 && fabs(y1 - cy1) < delta) return false;
+    if (cx2 < ch.wh[b][0] - 0.5 && fabs(x2 - cx2) < delta) return false;
+    if (cy2 < ch.wh[b][1] - 0.5 && fabs(y2 - cy2) < delta) return false;
+  }
+  row[0] = x1; row[1] = y1; row[2] = x2; row[3] = y2; row[4] = (double)s;
+  return true;
+}
+
+// grid (NC - 1, B), one wave per block.  WRITE = false: counts[b][j - 1]; WRITE = true: rows, after the counts are complete.
+template <bool WRITE>
+__global__ __launch_bounds__(64) void det_compact_kernel(const float *__restrict__ scores, const double *__restrict__ boxes,
+                                                         const DetChips ch, int prune, float thresh, double delta, int R, int NC,
+                                                         double *__restrict__ rows, int *__restrict__ counts) {
+  const int j = blockIdx.x + 1, b = blockIdx.y, lane = threadIdx.x;
+  int base = 0;
+  if (WRITE) {                                  // rows of the classes before this one
+    for (int k = lane; k < j - 1; k += 64) base += counts[b * (NC - 1) + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+  }
+  int n = 0;
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int r = r0 + lane;
+    double row[5];
+    const bool keep = r < R && det_keep(scores, boxes, ch, prune, thresh, delta, b, r, j, R, NC, row);
+    const unsigned long long m = __ballot(keep);
+    if (WRITE && keep) {
+      const int at = base + n + __popcll(m & ((1ull << lane) - 1ull));
+      double *dst = rows + ((size_t)b * (NC - 1) * R + at) * 5;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) dst[k] = row[k];
+    }
+    n += __popcll(m);
+  }
+  if (!WRITE && lane == 0) counts[b * (NC - 1) + j - 1] = n;
+}
+
+SN_EXPORT int sn_det_compact(const float *d_scores, const double *d_boxes, const double *h_crops, const double *h_im_wh,
+                             float thresh, double delta, int B, int R, int NC, double *d_rows, int32_t *d_counts,
+                             sn_stream_t stream) {
+  SN_REQUIRE(d_scores && d_boxes && d_rows && d_counts && B > 0 && B <= 64 && R > 0 && NC > 1,
+             "sn_det_compact: bad arguments (at most 64 chips per call)");
+  SN_REQUIRE((h_crops == nullptr) == (h_im_wh == nullptr), "sn_det_compact: crops and image sizes come together");
+  DetChips ch;
+  memset(&ch, 0, sizeof(ch));
+  if (h_crops)
+    for (int b = 0; b < B; ++b) {
+      for (int k = 0; k < 4; ++k) ch.crop[b][k] = h_crops[b * 4 + k];
+      ch.wh[b][0] = h_im_wh[b * 2];
+      ch.wh[b][1] = h_im_wh[b * 2 + 1];
+    }
+  const dim3 grid(NC - 1, B);
+  hipLaunchKernelGGL(det_compact_kernel<false>, grid, dim3(64), 0, sn_stream(stream), d_scores, d_boxes, ch, h_crops ? 1 : 0, thresh,
+                     delta, R, NC, d_rows, d_counts);
+  hipLaunchKernelGGL(det_compact_kernel<true>, grid, dim3(64), 0, sn_stream(stream), d_scores, d_boxes, ch, h_crops ? 1 : 0, thresh,
+                     delta, R, NC, d_rows, d_counts);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -109,6 +109,18 @@ _PRODUCES_ACT = {'Convolution', 'FullyConnected', 'BatchNorm', 'Activation', 'Po
                  'DeformablePSROIPooling', 'clip', 'Deconvolution', 'pick'}
 
 
+_CAPTURE_ALLOWED = True
+
+
+def set_capture_allowed(flag):
+    """Process-wide switch for NEW hipGraph captures (replays of captured graphs are unaffected).  Off while several threads drive
+    the GPU at once (the concurrent test-time jobs of sniper_amd.inference): a capture is not safe beside another thread's
+    allocations / synchronisations ("operation failed due to a previous error during capture"), so an executor that has no
+    graph yet runs eagerly until the jobs are back to one at a time."""
+    global _CAPTURE_ALLOWED
+    _CAPTURE_ALLOWED = bool(flag)
+
+
 class Executor(object):
     def __init__(self, symbol, input_shapes, for_training=True, fixed_param_names=(), device=None, data_names=None,
                  label_names=None, loss_scale_hint=None, split_backward=False):
@@ -618,7 +630,7 @@ class Executor(object):
                 self._infer_graph.replay()
                 return self.outputs
             self._infer_calls += 1
-            if self._infer_calls > 1:            # the first call ran eagerly: lazy allocations, parameter packing
+            if self._infer_calls > 1 and _CAPTURE_ALLOWED:   # the first call ran eagerly: lazy allocations, parameter packing
                 import gc
                 gc.collect()
                 gc_was = gc.isenabled()

@@ -50,6 +50,31 @@ def soft_nms_batch(problems, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
     return out
 
 
+def soft_nms_stacked(rows, sizes, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
+    """soft_nms_batch for problems that already are one (total, 5) float32 array + rows per problem (empty problems allowed):
+    one upload, one launch, one download; the results are views of the downloaded array."""
+    import torch
+
+    from .. import hip
+    rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 5)
+    sizes = np.asarray(sizes, np.int64).reshape(-1)
+    P = len(sizes)
+    if P == 0 or rows.shape[0] == 0:
+        return [np.zeros((0, 5), np.float32) for _ in range(P)]
+    cap = hip.query('sn_soft_nms_max_boxes')
+    if int(sizes.max()) > cap:
+        raise ValueError('soft-NMS problem with %d boxes (at most %d fit the LDS of one workgroup)' % (int(sizes.max()), cap))
+    off = np.zeros(P + 1, np.int32)
+    off[1:] = np.cumsum(sizes)
+    d, d_off = hip.dev(rows), hip.dev(off)
+    cnt = torch.empty((P,), dtype=torch.int32, device=d.device)
+    hip.call('sn_soft_nms_batch', d, d_off, P, int(sizes.max()), float(sigma), float(Nt), float(threshold), int(method), cnt,
+             hip.stream())
+    h, c = d.cpu().numpy(), cnt.cpu().numpy()
+    starts, ends = off[:-1].tolist(), (off[:-1] + c).tolist()
+    return [h[a:b] for a, b in zip(starts, ends)]
+
+
 def cpu_soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
     """Reference signature (cpu_nms.pyx:17): mutates `boxes` like the original and returns the surviving rows."""
     res = soft_nms_batch([boxes], sigma, Nt, threshold, method)[0]

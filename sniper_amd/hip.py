@@ -3,6 +3,8 @@ kernels are ours.  `call("sn_xxx", tensor_or_scalar, ...)` passes `tensor.data_p
 None -> NULL, and appends nothing implicitly -- the stream is passed explicitly via `stream()`."""
 import ctypes
 
+import numpy as np
+
 import torch
 
 from ._lib import SniperHipError, lib  # noqa: F401
@@ -36,6 +38,10 @@ def stream():
 def _conv(a):
     if isinstance(a, torch.Tensor):
         return ctypes.c_void_p(a.data_ptr())
+    if isinstance(a, np.ndarray):        # a HOST array argument (the entry point reads it before returning)
+        if not a.flags['C_CONTIGUOUS']:
+            raise ValueError('host array arguments must be C-contiguous')
+        return ctypes.c_void_p(a.ctypes.data)
     return a
 
 

@@ -27,7 +27,8 @@ from .iterators.MNIteratorTestAutoFocus import MNIteratorTestAutoFocus
 from .iterators.PrefetchingIter import PrefetchingIter
 
 
-_PINNED = {}     # (output, shape, dtype, ping / pong) -> pinned host tensor of Tester._launch
+_PINNED = {}     # (thread, (lane, ping / pong, gpu, output), shape, dtype) -> pinned host tensor of Tester._launch
+_LANE_STREAMS = {}        # thread -> the side streams of Tester's lanes (created once: streams are not free to make)
 
 
 class nms_wrapper(object):
@@ -54,6 +55,13 @@ class nms_wrapper(object):
         for i in big:       # keep the best-scoring `cap` boxes of an oversized problem (the rest could only lose score)
             problems[i] = problems[i][np.argsort(-problems[i][:, 4], kind='stable')[:cap]]
         return _cpu_nms.soft_nms_batch(problems, sigma=self.sigma, Nt=0.3, threshold=0.001, method=2)
+
+
+    def process_stacked(self, rows, sizes):
+        """process_many for problems given as one (total, 5) float32 array + rows per problem."""
+        if self.thresh <= 0 and (len(sizes) == 0 or int(np.max(sizes)) <= int(hip.query('sn_soft_nms_max_boxes'))):
+            return _cpu_nms.soft_nms_stacked(rows, sizes, sigma=self.sigma, Nt=0.3, threshold=0.001, method=2)
+        return self.process_many(_split_rows(rows, sizes))
 
 
 class nms_worker(object):
@@ -97,16 +105,22 @@ def _stack_rows(per_class, dtype):
     return big, lens
 
 
+def _split_rows(rows, counts):
+    """np.split(rows, cumsum(counts)[:-1]) as plain slices (np.split spends 2 us per piece on axis bookkeeping; a chip has 80)."""
+    ends = np.cumsum(counts).tolist()
+    return [rows[a:b] for a, b in zip([0] + ends[:-1], ends)]
+
+
 def threshold_detections(cscores, cboxes, cls_thresh, num_classes):
     """Tester.get_detections' score threshold for every class of one chip (lib/inference.py:289-295): list over classes
     1..num_classes-1 of `hstack(cboxes[inds, 0:4], cscores[inds, j, None])`, inds = where(cscores[:, j] > cls_thresh) -- one mask,
     one gather and one split instead of a where / hstack pair per class."""
-    mask = (cscores[:, 1:num_classes] > cls_thresh).T            # (classes, RoIs): nonzero() walks a class's RoIs in order
-    cls_idx, roi_idx = np.nonzero(mask)
+    mask = np.ascontiguousarray((cscores[:, 1:num_classes] > cls_thresh).T)   # (classes, RoIs): a class's RoIs in order
+    cls_idx, roi_idx = np.divmod(np.flatnonzero(mask), mask.shape[1])        # (flatnonzero: 5x faster than the 2-D nonzero)
     dets = np.empty((len(roi_idx), 5), np.result_type(cboxes.dtype, cscores.dtype))
     dets[:, 0:4] = cboxes[roi_idx, 0:4]
     dets[:, 4] = cscores[roi_idx, cls_idx + 1]
-    return np.split(dets, np.cumsum(mask.sum(1))[:-1])
+    return _split_rows(dets, mask.sum(1))
 
 
 def prune_chip_border(per_class, crop, im_width, im_height):
@@ -120,22 +134,28 @@ def prune_chip_border(per_class, crop, im_width, im_height):
     ok = Tester._valid_mask(big, crop, im_width, im_height)
     cls_id = np.repeat(np.arange(nc), lens)
     kept = np.bincount(cls_id[ok], minlength=nc)
-    return np.split(big[ok], np.cumsum(kept)[:-1])
+    return _split_rows(big[ok], kept)
 
 
-def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes):
+def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes, stacked=False):
     """The per (image, class) NMS problems of Tester.aggregate (lib/inference.py:170-190): for image i and class j the rows of
     every scale's every chip that pass that scale's valid range, in (scale, chip, row) order.  Built per image with a handful
     of array operations instead of classes x scales x chips Python iterations: every (scale, chip) part is stacked class-major
     and masked once, and since each part already is class-major the regrouping by class is a block permutation computed from the
-    per (part, class) counts -- no sort.  Returns the problems in (image, class) order, float32 (n, 5)."""
+    per (part, class) counts -- no sort.  Returns the problems in (image, class) order, float32 (n, 5); stacked=True: the same
+    rows as ONE (total, 5) array + the rows per problem (what the batched soft-NMS launch uploads)."""
     nc = num_classes - 1
-    problems = []
+    problems, sizes = [], []
     for i in range(num_images):
         parts, counts = [], []
         for all_cls_dets, vr in zip(scale_cls_dets, valid_ranges):
+            ready = getattr(all_cls_dets, 'compact', {})
             for c in range(len(all_cls_dets[1][i])):
-                big, lens = _stack_rows([all_cls_dets[j][i][c] for j in range(1, num_classes)], np.float32)
+                if (i, c) in ready:              # rows of this chip already stacked class-major (Tester.get_detections)
+                    big, lens = ready[(i, c)]
+                    big = big.astype(np.float32)
+                else:
+                    big, lens = _stack_rows([all_cls_dets[j][i][c] for j in range(1, num_classes)], np.float32)
                 if len(big) == 0:
                     continue
                 areas = (big[:, 3] - big[:, 1]) * (big[:, 2] - big[:, 0])      # float32 products, as _valid_range_filter
@@ -147,7 +167,10 @@ def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes):
                 parts.append(big[ok])
                 counts.append(np.bincount(np.repeat(np.arange(nc), lens)[ok], minlength=nc))
         if not parts:
-            problems.extend(np.empty((0, 5), np.float32) for _ in range(nc))
+            if stacked:
+                sizes.append(np.zeros(nc, np.int64))
+            else:
+                problems.extend(np.empty((0, 5), np.float32) for _ in range(nc))
             continue
         big = np.concatenate(parts)                  # rows ordered (part, class, row)
         cnt = np.stack(counts)                       # (parts, classes)
@@ -156,19 +179,43 @@ def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes):
         start = src.reshape(cnt.shape).T.ravel()
         total = int(length.sum())
         order = np.repeat(start - (np.cumsum(length) - length), length) + np.arange(total)
-        problems.extend(np.split(big[order], np.cumsum(cnt.sum(0))[:-1]))
+        if stacked:
+            problems.append(big[order])
+            sizes.append(cnt.sum(0))
+        else:
+            problems.extend(_split_rows(big[order], cnt.sum(0)))
+    if stacked:
+        rows = np.concatenate(problems) if problems else np.zeros((0, 5), np.float32)
+        return rows, (np.concatenate(sizes) if sizes else np.zeros(0, np.int64))
     return problems
 
 
+class _Detections(list):
+    """all_boxes[class][image][chip] of Tester.get_detections, plus `compact`: {(image, chip): (rows grouped by class, rows per
+    class)} for the chips whose rows came back from the GPU already in that form (what aggregate_problems stacks anyway)."""
+
+    def __init__(self, *a):
+        super(_Detections, self).__init__(*a)
+        self.compact = {}
+
+
 class Tester(object):
+    device_compact = True        # threshold + prune on the GPU (sn_det_compact); False: the numpy statement of the same (tests)
+
     def __init__(self, module, imdb, roidb, test_iter, cfg, rcnn_output_names=None, rpn_output_names=None, logger=None,
                  batch_size=None):
         self.test_iter = test_iter
+        self._own_iter = False
         if test_iter is not None and not isinstance(test_iter, PrefetchingIter):
-            self.test_iter = PrefetchingIter(self.test_iter)
+            self.test_iter = PrefetchingIter(self.test_iter, depth=len(module) if isinstance(module, (list, tuple)) else 1)
+            self._own_iter = True
             self.scale = test_iter.test_scale
         self.cfg = cfg
-        self.module = module
+        # `module` may be a list of identical bound Modules ("lanes"): batch k runs on lane k % len(lanes), each lane on its own
+        # HIP stream, so up to that many forwards are in flight (get_detections)
+        self.modules = list(module) if isinstance(module, (list, tuple)) else [module]
+        self.module = self.modules[0]
+        self._lane_streams = None
         if test_iter is not None:
             self.data_names = [k[0] for k in test_iter.provide_data_single]
         self.rcnn_output_names = rcnn_output_names or {
@@ -187,9 +234,10 @@ class Tester(object):
         self.verbose = len(roidb) > 1
 
     # ---- forward ------------------------------------------------------------------------------
-    def forward(self, batch):
-        self.module.forward(batch, is_train=False)
-        return [dict(zip(self.module.output_names, i)) for i in zip(*self.module.get_outputs(merge_multi_context=False))]
+    def forward(self, batch, lane=0):
+        mod = self.modules[lane]
+        mod.forward(batch, is_train=False)
+        return [dict(zip(mod.output_names, i)) for i in zip(*mod.get_outputs(merge_multi_context=False))]
 
     def get_proposals(self, batch, scales):
         data = dict(zip(self.data_names, batch.data))
@@ -220,16 +268,40 @@ class Tester(object):
         # process-wide and never released: a pinned block returned to torch's host allocator from a garbage-collected Tester
         # makes that allocator query events / free host memory at an arbitrary moment -- inside another executor's hipGraph
         # capture that is an illegal call and the process aborts (seen once, in the -m gpu suite).  One entry per output shape.
-        k = (threading.get_ident(), key, tuple(like.shape), dtype or like.dtype, self.__dict__.setdefault('_pin_flip', 0))
+        k = (threading.get_ident(), key, tuple(like.shape), dtype or like.dtype)
         t = _PINNED.get(k)
         if t is None:
             t = _PINNED[k] = torch.empty(tuple(like.shape), dtype=dtype or like.dtype, pin_memory=True)
         return t
 
-    def _launch(self, batch):
+    def _stream(self, lane):
+        """The HIP stream of a lane: the caller's current stream for a single lane, one side stream per lane otherwise."""
+        if len(self.modules) == 1 or not torch.cuda.is_available():
+            return None
+        if self._lane_streams is None:
+            self._lane_streams = _LANE_STREAMS.setdefault(threading.get_ident(), [])
+            while len(self._lane_streams) < len(self.modules):
+                self._lane_streams.append(torch.cuda.Stream())
+        return self._lane_streams[lane]
+
+    def _launch(self, batch, lane=0, compact=None):
+        """Enqueue one batch on `lane`.  compact = (cls_thresh, do_pruning): threshold (+ prune) the detections on the GPU
+        (sn_det_compact) and bring back rows already grouped by class instead of the raw scores / boxes."""
+        st = self._stream(lane)
+        if st is None:
+            return self._launch_on(batch, lane, compact)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            return self._launch_on(batch, lane, compact)
+
+    def _launch_on(self, batch, lane, compact):
+        ready = getattr(batch, 'ready_event', None)        # the prefetch thread's image-preparation launches (PrefetchingIter)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
         data = dict(zip(self.data_names, batch.data))
-        outputs = self.forward(batch)
-        self._pin_flip = 1 - self.__dict__.get('_pin_flip', 0)
+        outputs = self.forward(batch, lane)
+        flips = self.__dict__.setdefault('_pin_flip', {})
+        flip = flips[lane] = 1 - flips.get(lane, 0)
         has_focus_maps = self.rcnn_output_names['scale_map'] in outputs[0]
         parts = []
         for g, gpu_out in enumerate(outputs):
@@ -240,15 +312,31 @@ class Tester(object):
             assert rois.shape[0] == B * R, 'The number of rois per GPU should be fixed!'
             boxes = torch.empty((B, R, 4), dtype=torch.float64, device=rois.device)
             hip.call('sn_bbox_decode', rois.contiguous(), deltas.contiguous(), infos.float().contiguous(), boxes, B, R, hip.stream())
-            want = {'boxes': boxes, 'cls': gpu_out[self.rcnn_output_names['cls']]._data,
-                    'im_ids': gpu_out[self.rcnn_output_names['im_ids']]._data,
+            cls = gpu_out[self.rcnn_output_names['cls']]._data
+            want = {'im_ids': gpu_out[self.rcnn_output_names['im_ids']]._data,
                     'chip_ids': gpu_out[self.rcnn_output_names['chip_ids']]._data}
+            if compact is not None and cls.is_cuda and B <= 64:
+                cls_thresh, do_pruning = compact
+                NC = int(cls.shape[-1])
+                crops = wh = None
+                if do_pruning:       # the chips of this batch, from the batch's own (host) id inputs
+                    ids = np.asarray(data['im_ids'].asnumpy()).astype(int).reshape(-1)[g * B:(g + 1) * B]
+                    cids = np.asarray(data['chip_ids'].asnumpy()).astype(int).reshape(-1)[g * B:(g + 1) * B]
+                    crops = np.ascontiguousarray([self.roidb[i]['inference_crops'][c] for i, c in zip(ids, cids)], np.float64)
+                    wh = np.ascontiguousarray([[self.roidb[i]['width'], self.roidb[i]['height']] for i in ids], np.float64)
+                rows = torch.empty((B, (NC - 1) * R, 5), dtype=torch.float64, device=cls.device)
+                counts = torch.empty((B, NC - 1), dtype=torch.int32, device=cls.device)
+                hip.call('sn_det_compact', cls.contiguous(), boxes, crops, wh, float(cls_thresh), 10.0, B, R, NC, rows, counts,
+                         hip.stream())
+                want['rows'], want['counts'] = rows, counts
+            else:
+                want['boxes'], want['cls'] = boxes, cls
             if has_focus_maps:
                 want['maps'] = gpu_out[self.rcnn_output_names['scale_map']]._data
             host = {}
             for k, t in want.items():
                 if t.is_cuda:
-                    host[k] = self._pinned((g, k), t)
+                    host[k] = self._pinned((lane, flip, g, k), t)
                     host[k].copy_(t, non_blocking=True)
                 else:
                     host[k] = t
@@ -260,23 +348,32 @@ class Tester(object):
         return data, parts, has_focus_maps, ev
 
     def _collect(self, handle):
+        """-> scores, boxes, data, im_ids, maps, chip_ids; after a compacting launch `scores` is None and boxes[i] is the pair
+        (rows of chip i grouped by class, float64 (n, 5); rows per class, (NC - 1,))."""
         data, parts, has_focus_maps, ev = handle
         if ev is not None:
             ev.synchronize()
         scores, preds, maps = [], [], []
         im_ids = np.array([], dtype=int)
         chip_ids = np.array([], dtype=int)
+        compacted = False
         for B, host in parts:
-            gpu_scores, boxes = host['cls'].numpy().copy(), host['boxes'].numpy().copy()      # the pinned set is reused two batches on
             im_ids = np.hstack((im_ids, host['im_ids'].numpy().astype(int)))
             chip_ids = np.hstack((chip_ids, host['chip_ids'].numpy().astype(int)))
-            scale_prob = host['maps'].numpy().copy() if has_focus_maps else None
-            for idx in range(B):
-                scores.append(gpu_scores[idx])
-                preds.append(boxes[idx])
-                if has_focus_maps:
-                    maps.append(scale_prob[idx])
-        return scores, preds, data, im_ids, maps, chip_ids
+            scale_prob = host['maps'].numpy().copy() if has_focus_maps else None     # (the pinned set is reused two batches on)
+            if 'rows' in host:
+                compacted = True
+                counts, rows = host['counts'].numpy().astype(np.int64), host['rows'].numpy()
+                for idx in range(B):
+                    preds.append((rows[idx, :int(counts[idx].sum())].copy(), counts[idx]))
+            else:
+                gpu_scores, boxes = host['cls'].numpy().copy(), host['boxes'].numpy().copy()
+                for idx in range(B):
+                    scores.append(gpu_scores[idx])
+                    preds.append(boxes[idx])
+            if has_focus_maps:
+                maps.extend(scale_prob[idx] for idx in range(B))
+        return (None if compacted else scores), preds, data, im_ids, maps, chip_ids
 
     def set_scale(self, scale):
         it = self.test_iter.iters[0] if isinstance(self.test_iter, PrefetchingIter) else self.test_iter
@@ -294,8 +391,9 @@ class Tester(object):
         n_scales = len(scale_cls_dets)
         assert n_scales == len(self.cfg.TEST.VALID_RANGES), 'A valid range should be specified for each test scale'
         all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
-        problems = aggregate_problems(scale_cls_dets, self.cfg.TEST.VALID_RANGES, self.num_images, self.num_classes)
-        final = self.nms_worker.worker_many(problems)          # one batched launch instead of Pool(32).map
+        # one batched launch instead of Pool(32).map; the problems go up as the one stacked array they are built as
+        rows, sizes = aggregate_problems(scale_cls_dets, self.cfg.TEST.VALID_RANGES, self.num_images, self.num_classes, stacked=True)
+        final = self.nms_worker.nms_wrapper.process_stacked(rows, sizes)
         k = 0
         for i in range(self.num_images):
             for j in range(1, self.num_classes):
@@ -343,20 +441,34 @@ class Tester(object):
     def get_detections(self, cls_thresh=1e-3, cache_name='cache', evaluate=False, vis=False, vis_path=None, do_pruning=False,
                        autofocus=False, vis_ext='.png'):
         n_chips = [len(r['inference_crops']) for r in self.roidb]
-        all_boxes = [[[[] for _ in range(n_chips[i])] for i in range(self.num_images)] for _ in range(self.num_classes)]
+        all_boxes = _Detections([[[] for _ in range(n_chips[i])] for i in range(self.num_images)] for _ in range(self.num_classes))
         all_maps = [[[] for _ in range(n_chips[i])] for i in range(self.num_images)]
+        nc = self.num_classes - 1
+
         def post(scores, boxes, data, im_ids, maps, chip_ids):
             todo = []
-            for i, (cscores, cboxes, im_id, chip_id) in enumerate(zip(scores, boxes, im_ids, chip_ids)):
+            for i, (cboxes, im_id, chip_id) in enumerate(zip(boxes, im_ids, chip_ids)):
                 if autofocus:
                     all_maps[im_id][chip_id] = maps[i]
+                if scores is None:
+                    # thresholded (and pruned) on the GPU: rows grouped by class + rows per class -- only slice
+                    big, lens = cboxes
+                    ends = np.cumsum(lens).tolist()
+                    start = 0
+                    for j in range(nc):
+                        all_boxes[j + 1][im_id][chip_id] = big[start:ends[j]]
+                        start = ends[j]
+                    all_boxes.compact[(im_id, chip_id)] = (big, lens)
+                    continue
                 # all classes at once: rows grouped by class, RoIs ascending inside a class (= np.where per class, :290-295)
-                per_class = threshold_detections(cscores, cboxes, cls_thresh, self.num_classes)
+                per_class = threshold_detections(scores[i], cboxes, cls_thresh, self.num_classes)
                 for j in range(1, self.num_classes):
                     if evaluate:
                         todo.append((j, im_id, chip_id, per_class[j - 1]))
                     else:
                         all_boxes[j][im_id][chip_id] = per_class[j - 1]
+            if scores is None:
+                return
             if evaluate:
                 final = self.nms_worker.worker_many([t[3] for t in todo])
                 for (j, im_id, chip_id, _), d in zip(todo, final):
@@ -376,14 +488,20 @@ class Tester(object):
                                                self.roidb[im_id]['width'], self.roidb[im_id]['height'])
                     for j, d in enumerate(pruned):
                         all_boxes[j + 1][im_id][chip_id] = d
-        pending = None
-        for batch in self.test_iter:
-            handle = self._launch(batch)              # forward of this batch is on the GPU ...
-            if pending is not None:
-                post(*self._collect(pending))         # ... while the host finishes the previous one
-            pending = handle
-        if pending is not None:
-            post(*self._collect(pending))
+        # Without the per-chip NMS of `evaluate` the threshold and the pruning are one predicate per (RoI, class): the GPU applies
+        # it and compacts the rows (sn_det_compact).  Batch k runs on lane k % lanes; a lane's previous batch is collected (in
+        # batch order) before the lane is reused, so `lanes` forwards are in flight while the host slices an earlier batch.
+        compact = None if (evaluate or not self.device_compact) else (cls_thresh, do_pruning)
+        lanes = len(self.modules)
+        pending = []
+        for k, batch in enumerate(self.test_iter):
+            if len(pending) >= lanes:
+                post(*self._collect(pending.pop(0)))
+            pending.append(self._launch(batch, k % lanes, compact))
+        while pending:
+            post(*self._collect(pending.pop(0)))
+        if self._own_iter:
+            self.test_iter.close()               # (the prefetch thread this Tester started)
         return all_boxes, all_maps
 
     def extract_proposals(self, n_proposals=300, cache_name='cache', vis=False, vis_ext='.png'):
@@ -397,49 +515,113 @@ class Tester(object):
         return all_boxes
 
 
-def detect_scale_worker(arguments, module_cache=None):
+def detect_scale_worker(arguments, module_cache=None, lanes=1):
     """One test scale: bind the test graph for that scale's batch shape and run the Tester (:411-436).
     module_cache (dict, optional): keeps the bound Module of each scale across calls (its executors are cached per
     batch shape), which is what a long-running inference service -- and the throughput benchmark -- wants; the
-    reference rebuilds the Module per call."""
+    reference rebuilds the Module per call.
+    lanes: identical bound Modules (same parameters) whose forwards run concurrently on their own HIP streams when the scale
+    has more than one batch (Tester.get_detections): a batch of two FocusChips at the finest scale fills half of the 256 CUs
+    and most of its ~190 kernels are latency-bound."""
     [scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis] = arguments
     nGPUs = len(context)
     test_iter = MNIteratorTestAutoFocus(roidb=roidb, config=config, batch_size=nGPUs * nbatch, nGPUs=nGPUs, threads=32,
                                         pad_rois_to=400, crop_size=None, test_scale=scale)
-    mod = module_cache.get((tuple(scale), nbatch)) if module_cache is not None else None
-    if mod is None:
+    n_batches = max(1, test_iter.size // max(1, nGPUs * nbatch))
+    lanes = max(1, min(int(lanes), n_batches))
+    mods = module_cache.get((tuple(scale), nbatch)) if module_cache is not None else None
+    mods = list(mods) if isinstance(mods, (list, tuple)) else ([mods] if mods is not None else [])
+    while len(mods) < lanes:
         sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
         sym = sym_inst.get_symbol_rcnn(config, is_train=False)
         mod = mx.mod.Module(symbol=sym, context=context, data_names=[k[0] for k in test_iter.provide_data_single], label_names=None)
         mod.bind(test_iter.provide_data, test_iter.provide_label, for_training=False)
-        mod.init_params(arg_params=arg_params, aux_params=aux_params, allow_missing=arg_params is None)
-        if module_cache is not None:
-            module_cache[(tuple(scale), nbatch)] = mod
-    tester = Tester(mod, imdb, roidb, test_iter, cfg=config, batch_size=nbatch)
+        if mods:                 # a further lane: the first lane's parameters (a random initialisation must not differ per lane)
+            a0, x0 = mods[0].get_params()
+            mod.init_params(arg_params=a0, aux_params=x0, allow_missing=False)
+        else:
+            mod.init_params(arg_params=arg_params, aux_params=aux_params, allow_missing=arg_params is None)
+        mods.append(mod)
+    if module_cache is not None:
+        module_cache[(tuple(scale), nbatch)] = mods
+    tester = Tester(mods[:lanes], imdb, roidb, test_iter, cfg=config, batch_size=nbatch)
     return tester.get_detections(vis=False, evaluate=False, cache_name='dets_scale_{}x{}'.format(scale[0], scale[1]),
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
 def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
-                           focus_map_fn=None, return_scale_dets=False):
+                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=3):
     """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
     AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips); detections of all scales
     are aggregated under TEST.VALID_RANGES with per-class NMS.
+    concurrent_jobs (TEST.CONCURRENT_JOBS, :452-500): the roidb is cut into that many contiguous parts and every scale runs the
+    parts CONCURRENTLY -- the reference forks one model process per part; here one thread per part, each with its own bound
+    Module and its own HIP stream on this process's GPU (a batch of two FocusChips at the finest scale leaves most of the 256
+    CUs idle; two streams fill them).  Results are merged in part order, as the reference does (:494-500).
+    lanes: batches of one scale in flight at once, each on its own bound Module and HIP stream, driven by ONE host thread
+    (detect_scale_worker / Tester.get_detections) -- the form of concurrency that measured faster here than threads.
     focus_map_fn(scale_i, image, chip, net_map) -> map (benchmarks only): replaces the network's FocusPixel map before the
     FocusChips are cut -- a random-init network's maps select whole images, a trained one's ~10 % of the pixels in blobs
     (SURVEY 8(d)); return_scale_dets: also hand back the per-scale detections (what the CPU baseline of the aggregation reads)."""
     for r in roidb:
         r['inference_crops'] = np.array([[0, 0, r['width'], r['height']]])
+    jobs = max(1, min(int(concurrent_jobs), len(roidb)))
+    per_job = int(math.ceil(float(len(roidb)) / jobs))
+    parts = [roidb[j * per_job:min((j + 1) * per_job, len(roidb))] for j in range(jobs)]
+    parts = [p for p in parts if p]
+    streams, pool = None, None
+    if len(parts) > 1:
+        from multiprocessing.pool import ThreadPool
+        pool = ThreadPool(len(parts))
+        if torch.cuda.is_available():
+            streams = module_cache.setdefault('__streams__', [torch.cuda.Stream() for _ in parts]) if module_cache is not None \
+                else [torch.cuda.Stream() for _ in parts]
     detections = []
     for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
-        dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis],
-                                         module_cache)
+        def job(j):
+            cache = None if module_cache is None else module_cache.setdefault(('__job__', j), {})
+            args = [scale, scale_i, nbatch, context, config, sym_def, parts[j], imdb, arg_params, aux_params, vis]
+            if streams is None:
+                return detect_scale_worker(args, cache, lanes)
+            main = torch.cuda.current_stream()
+            streams[j].wait_stream(main)
+            with torch.cuda.stream(streams[j]):
+                out = detect_scale_worker(args, cache, lanes)
+            streams[j].synchronize()
+            return out
+        if len(parts) == 1:
+            dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis],
+                                             module_cache, lanes)
+        else:
+            # the first two passes over a module cache run the parts one after the other: that is when the bound executors
+            # capture their forward graphs, which must not happen beside another thread's GPU work (engine/executor.py)
+            warm = module_cache is None or module_cache.get('__passes__', 0) < 2
+            if warm:
+                results = [job(j) for j in range(len(parts))]
+            else:
+                from .engine import executor as _ex
+                _ex.set_capture_allowed(False)
+                try:
+                    results = pool.map(job, range(len(parts)))
+                finally:
+                    _ex.set_capture_allowed(True)
+            dets, maps = results[0]
+            for d, m in results[1:]:
+                first = len(maps)                # image ids of a part are local to it
+                for j in range(imdb.num_classes):
+                    dets[j] += d[j]
+                maps += m
+                dets.compact.update({(first + i, c): v for (i, c), v in getattr(d, 'compact', {}).items()})
         detections.append(dets)
         # chips of the next scale from this scale's FocusPixel maps (:497-499)
         if scale_i + 1 < len(config.TEST.SCALES) and config.TEST.DO_PRUNING[scale_i + 1]:
             if focus_map_fn is not None:
                 maps = [[focus_map_fn(scale_i, i, j, np.asarray(m)) for j, m in enumerate(mi)] for i, mi in enumerate(maps)]
             add_chips(roidb, maps, scale_i, config)
+    if pool is not None:
+        pool.close()
+    if module_cache is not None:
+        module_cache['__passes__'] = module_cache.get('__passes__', 0) + 1
     tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
     out = tester.aggregate(detections, vis=False, cache_name=None)
     return (out, detections) if return_scale_dets else out

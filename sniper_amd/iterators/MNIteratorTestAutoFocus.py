@@ -25,7 +25,11 @@ class MNIteratorTestAutoFocus(MNIteratorBase):
         self.im_worker = im_worker(crop_size=None if not self.crop_size else self.crop_size[0], cfg=config,
                                    target_size=test_scale)
         self.test_scale = test_scale
+        # the base constructor assembles one batch only to learn the shapes provide_data reports (MNIteratorBase.py:23-24):
+        # that one allocates the tensors and skips the image preparation (a pass re-creates this iterator per scale)
+        self._shapes_only = True
         super(MNIteratorTestAutoFocus, self).__init__(roidb, config, batch_size, threads, nGPUs, pad_rois_to, True)
+        self._shapes_only = False
         self.reset()
 
     def set_scale(self, scale):
@@ -48,7 +52,7 @@ class MNIteratorTestAutoFocus(MNIteratorBase):
             scales.append(scale)
         im_tensor = torch.empty((n_batch, 3, max_size[0], max_size[1]), dtype=torch.float32, device=hip.require_gpu())
         im_info = np.zeros((n_batch, 3), np.float32)
-        for i in range(n_batch):
+        for i in range(n_batch if not self._shapes_only else 0):
             scale, (h, w) = self.im_worker.worker_autofocus([roidb[i]['image'], max_size, roidb[i]['flipped'], chips[i], scales[i]],
                                                             im_tensor[i])
             im_info[i] = [h, w, scale]

@@ -1,14 +1,18 @@
-"""One-deep background prefetch around a single iterator, contract of lib/iterators/PrefetchingIter.py:15-148
-(used by main_train.py:142 and Tester.__init__, lib/inference.py:33-34).  The worker thread binds the iterator's GPU:
-batch assembly here is kernel launches (anchor labelling, image preparation), enqueued while the main thread is
-busy with the previous step; both threads use the device's default stream, so ordering needs no extra events."""
+"""Background prefetch around a single iterator, contract of lib/iterators/PrefetchingIter.py:15-148 (used by main_train.py:142
+and Tester.__init__, lib/inference.py:33-34): one batch ahead by default, like the reference; `depth` batches ahead for a consumer
+that keeps several batches in flight (the lanes of Tester.get_detections).  The worker thread binds the iterator's GPU: batch
+assembly here is kernel launches (anchor labelling, image preparation), enqueued while the main thread is busy with the previous
+step.  A batch carries `ready_event`, recorded on the worker's stream behind those launches: a consumer on ANOTHER stream waits for
+it on the device (stream.wait_event) -- the host never blocks on the assembly; a consumer on the same (default) stream is ordered
+behind it anyway."""
+import collections
 import threading
 
 import sniper_amd.mx as mx
 
 
 class PrefetchingIter(mx.io.DataIter):
-    def __init__(self, iters, rename_data=None, rename_label=None):
+    def __init__(self, iters, rename_data=None, rename_label=None, depth=1):
         super(PrefetchingIter, self).__init__()
         if not isinstance(iters, list):
             iters = [iters]
@@ -18,13 +22,14 @@ class PrefetchingIter(mx.io.DataIter):
         self.rename_data, self.rename_label = rename_data, rename_label
         self.batch_size = self.iters[0].get_batch_size() if hasattr(self.iters[0], 'get_batch_size') else \
             self.provide_data[0][1][0]
-        self.data_ready = threading.Event()
-        self.data_taken = threading.Event()
-        self.data_taken.set()
+        self.depth = max(1, int(depth))
+        self._cv = threading.Condition()
+        self._queue = collections.deque()       # (batch or None at the end of the epoch, exception or None)
+        self._epoch = 0                         # bumped by reset(): a batch assembled across a reset is dropped
+        self._exhausted = False
+        self._busy = False
         self.started = True
         self.current_batch = None
-        self.next_batch = None
-        self.error = None
         try:
             import torch
             self._device = torch.cuda.current_device() if torch.cuda.is_available() else None
@@ -36,23 +41,44 @@ class PrefetchingIter(mx.io.DataIter):
                 import torch
                 torch.cuda.set_device(self._device)
             while True:
-                self.data_taken.wait()
-                if not self.started:
-                    break
+                with self._cv:
+                    while self.started and (self._exhausted or len(self._queue) >= self.depth):
+                        self._cv.wait()
+                    if not self.started:
+                        break
+                    epoch, self._busy = self._epoch, True
+                batch, error = None, None
                 try:
-                    self.next_batch = self.iters[0].next()
+                    batch = self.iters[0].next()
+                    if self._device is not None:
+                        import torch
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        batch.ready_event = ev
                 except StopIteration:
-                    self.next_batch = None
+                    batch = None
                 except Exception as e:  # noqa: BLE001 -- surface worker failures in the consumer thread
-                    self.next_batch, self.error = None, e
-                self.data_taken.clear()
-                self.data_ready.set()
+                    batch, error = None, e
+                with self._cv:
+                    self._busy = False
+                    if epoch == self._epoch:
+                        self._queue.append((batch, error))
+                        self._exhausted = batch is None
+                    self._cv.notify_all()
         self.prefetch_thread = threading.Thread(target=prefetch_func, daemon=True)
         self.prefetch_thread.start()
 
+    def close(self):
+        """End the worker thread (it otherwise waits for a reset() for as long as the process lives)."""
+        self.__del__()
+
     def __del__(self):
         self.started = False
-        self.data_taken.set()
+        try:
+            with self._cv:
+                self._cv.notify_all()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def get_batch_size(self):
         if not hasattr(self.iters[0], 'get_batch_size'):
@@ -85,21 +111,30 @@ class PrefetchingIter(mx.io.DataIter):
         return self.iters[0].provide_label_single
 
     def reset(self):
-        self.data_ready.wait()
-        self.iters[0].reset()
-        self.data_ready.clear()
-        self.data_taken.set()
+        with self._cv:
+            while self._busy:                   # the worker is inside iters[0].next(): let it finish, then drop what it made
+                self._cv.wait()
+            self._queue.clear()
+            self._epoch += 1
+            self.iters[0].reset()
+            self._exhausted = False
+            self._cv.notify_all()
 
     def iter_next(self):
-        self.data_ready.wait()
-        if self.error is not None:
-            e, self.error = self.error, None
-            raise e
-        if self.next_batch is None:
+        with self._cv:
+            while not self._queue:
+                self._cv.wait()
+            batch, error = self._queue[0]
+            if batch is not None:
+                self._queue.popleft()           # (the end-of-epoch marker stays: every further call answers False until reset)
+                self._cv.notify_all()
+            elif error is not None:
+                self._queue[0] = (None, None)
+        if error is not None:
+            raise error
+        if batch is None:
             return False
-        self.current_batch = self.next_batch
-        self.data_ready.clear()
-        self.data_taken.set()
+        self.current_batch = batch
         return True
 
     def next(self):

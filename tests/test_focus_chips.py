@@ -135,6 +135,23 @@ def test_vectorised_post_processing_equals_the_reference_loops():
     for g, w in zip(got, want):
         assert g.dtype == np.float32 and g.shape == w.shape and np.array_equal(g, w)
     assert sum(len(g) for g in got) > 0 and any(len(g) == 0 for g in got)
+    # the stacked form (one array + rows per problem: what the batched soft-NMS uploads) holds the same rows
+    rows, sizes = aggregate_problems(scales, vr, n_img, NC, stacked=True)
+    assert rows.dtype == np.float32 and np.array_equal(sizes, [len(w) for w in want])
+    assert np.array_equal(rows, np.concatenate([w.reshape(-1, 5) for w in want]))
+    # ... and so does the path that reads the chips' rows as the GPU returns them (grouped by class + rows per class)
+    from sniper_amd.inference import _Detections
+    marked = []
+    for sc in scales:
+        d = _Detections(sc)
+        for i in range(n_img):
+            for c in range(len(sc[1][i])):
+                per = [np.asarray(sc[j][i][c], np.float64).reshape(-1, 5) for j in range(1, NC)]
+                d.compact[(i, c)] = (np.concatenate(per), np.array([len(a) for a in per]))
+        marked.append(d)
+    rows2, sizes2 = aggregate_problems(marked, vr, n_img, NC, stacked=True)
+    assert np.array_equal(rows2, rows) and np.array_equal(sizes2, sizes)
+    assert aggregate_problems([], (), 2, NC, stacked=True)[1].tolist() == [0] * (2 * (NC - 1))
 
 
 def test_reference_aggregation_baseline_matches_the_vectorised_one():

@@ -163,6 +163,94 @@ def test_autofocus_pipeline_end_to_end():
         assert np.array_equal(m, w.worker(p.copy()))
 
 
+def test_det_compact_equals_the_host_threshold_and_prune():
+    """sn_det_compact == threshold_detections (lib/inference.py:289-295) followed by prune_chip_border (:336-353) for every
+    chip of a batch, bit for bit: rows grouped by class, RoIs ascending, float64; with and without pruning; a chip with no
+    surviving row, a chip whose every row survives, chips on the image border (those sides never prune)."""
+    from sniper_amd import hip
+    from sniper_amd.inference import threshold_detections, prune_chip_border
+    rs = np.random.RandomState(11)
+    B, R, NC = 5, 150, 21
+    scores = rs.dirichlet(np.ones(NC) * 0.08, (B, R)).astype(np.float32)
+    scores[1] = 0.0                                   # nothing passes
+    scores[2] = 0.5                                   # everything passes
+    boxes = rs.uniform(0, 200, (B, R, 4))
+    boxes[..., 2:] += boxes[..., :2]
+    boxes[3, :40, 0] = rs.uniform(0, 12, 40)          # rows hugging the left / top chip border
+    boxes[4, :40, 1] = rs.uniform(0, 12, 40)
+    crops = np.array([[30., 20., 430., 420.], [0., 0., 400., 400.], [100., 50., 500., 450.], [64., 0., 464., 400.],
+                      [0., 48., 400., 448.]])
+    wh = np.array([[640., 480.], [400., 400.], [500., 450.], [640., 400.], [400., 640.]])
+    td = lambda z: torch.from_numpy(np.ascontiguousarray(z)).to(dev())
+    for prune in (False, True):
+        rows = torch.full((B, (NC - 1) * R, 5), float('nan'), dtype=torch.float64, device=dev())
+        counts = torch.zeros((B, NC - 1), dtype=torch.int32, device=dev())
+        hip.call('sn_det_compact', td(scores), td(boxes), crops if prune else None, wh if prune else None, 1e-3, 10.0, B, R, NC,
+                 rows, counts, hip.stream())
+        rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
+        for b in range(B):
+            want = threshold_detections(scores[b], boxes[b], 1e-3, NC)
+            if prune:
+                want = prune_chip_border(want, crops[b], wh[b][0], wh[b][1])
+            assert np.array_equal(counts[b], [len(w) for w in want]), (prune, b)
+            stacked = np.concatenate([np.asarray(w, np.float64).reshape(-1, 5) for w in want])
+            assert np.array_equal(rows[b, :len(stacked)], stacked), (prune, b)
+        assert counts[1].sum() == 0 and (prune or counts[2].sum() == (NC - 1) * R)
+
+
+def test_lanes_and_device_compaction_equal_the_host_loops():
+    """The coarse-to-fine wrapper with three lanes (forwards of consecutive batches on their own streams) and the GPU threshold /
+    prune returns exactly the per-scale detections and final boxes of one lane with the numpy loops -- on the eager first pass,
+    the capturing second pass and a replayed third pass."""
+    import copy
+    import sniper_amd.mx as mx
+    from sniper_amd import config as cfgmod
+    from sniper_amd import inference
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+    rs = np.random.RandomState(5)
+    base = _roidb(6, rs, sizes=((240, 320),))
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.SCALES = ((240, 320), (480, 640))
+    cfg.TEST.BATCH_IMAGES = (2, 2)
+    cfg.TEST.VALID_RANGES = ((40, -1), (-1, 60))
+    cfg.TEST.DO_PRUNING = (False, True)
+    cfg.TEST.CHIP_HYPERPARAMS = ((3, 0.3, 4), (-1, -1, -1))
+    cfg.TEST.MAX_PER_IMAGE = 50
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 500, 100
+    cache = {}
+
+    def fmap(scale_i, image, chip, net_map):          # (15, 20) map: one FocusChip, two far-apart ones for the odd images
+        out = np.zeros_like(np.asarray(net_map, np.float32))
+        out[0] = 1.0
+        out[1, 1:3, 1:3] = 0.9
+        if image % 2:
+            out[1, -3:-1, -3:-1] = 0.9
+        out[0] -= out[1]
+        return out
+
+    def run(lanes, device_compact):
+        inference.Tester.device_compact = device_compact
+        try:
+            roidb = [dict(r) for r in base]
+            return inference.imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, _Imdb(81), roidb, [mx.gpu(0)], None, None,
+                                                    module_cache=cache, focus_map_fn=fmap, return_scale_dets=True, lanes=lanes)
+        finally:
+            inference.Tester.device_compact = True
+    for _ in range(3):
+        want_final, want_scales = run(1, False)
+        got_final, got_scales = run(3, True)
+        assert sum(len(c) for c in got_scales[1][1]) > 6           # some image did get two chips
+        for ws, gs in zip(want_scales, got_scales):
+            for j in range(1, 81):
+                for wi, gi in zip(ws[j], gs[j]):
+                    assert len(wi) == len(gi)
+                    for wc, gc in zip(wi, gi):
+                        assert np.array_equal(np.asarray(wc, np.float64).reshape(-1, 5), np.asarray(gc, np.float64).reshape(-1, 5))
+        for j in range(1, 81):
+            for wi, gi in zip(want_final[j], got_final[j]):
+                assert np.array_equal(wi, gi)
+
+
 def test_inference_forward_graph_replay_equals_eager():
     """A bound test-time executor runs eagerly once, captures its forward on the second call and replays it from then on
     (sniper_amd/engine/executor.py): every output of the replayed graph equals the eager forward of a second Module on the same

@@ -419,6 +419,19 @@ def test_sgd_and_weight_transpose():
     assert_close(md.cpu().numpy(), nm, 1e-5, 1e-6, 'sgd mom')
     assert_close(wd.cpu().numpy(), w + nm, 1e-5, 1e-6, 'sgd w')
     assert torch.equal(w16, wd.half())
+    # the captured-graph flavour (hyper-parameters in device memory) on arena slices that start off a 16-byte boundary:
+    # scalar head, four-wide body, scalar tail must equal the plain kernel
+    hyper = torch.tensor([0.01, 0.001, 0.9, 0.5], dtype=torch.float32, device=dev())
+    for off, cnt in ((0, n), (3, n - 5), (1, 2), (2, 65541), (4, 64)):
+        w1, g1, m1, w2, m2 = td(w), td(g), td(m), td(w), td(m)
+        h1 = torch.zeros(n, dtype=torch.float16, device=dev())
+        h2 = torch.zeros(n, dtype=torch.float16, device=dev())
+        hip.call('sn_sgd_mom_update_dev', w1[off:], g1[off:], m1[off:], h1[off:], cnt, hyper, 2.0, 0.5, hip.stream())
+        hip.call('sn_sgd_mom_update', w2[off:], g1[off:], m2[off:], h2[off:], cnt, 0.02, 0.0005, 0.9, 0.5, hip.stream())
+        # (the two kernels may contract their multiply-adds differently: one ulp, not bit for bit)
+        assert torch.allclose(w1, w2, rtol=1e-6, atol=1e-7) and torch.allclose(m1, m2, rtol=1e-6, atol=1e-7), (off, cnt)
+        assert torch.equal(h1[off:off + cnt], w1[off:off + cnt].half()) and not h1[:off].any() and not h1[off + cnt:].any()
+        assert torch.equal(w1[:off], td(w)[:off]) and torch.equal(w1[off + cnt:], td(w)[off + cnt:])
     O, T, I = 40, 9, 24
     ww = rs.standard_normal((O, T, I)).astype(np.float32)
     wt = torch.empty((I, T, O), dtype=torch.float16, device=dev())

@@ -1,7 +1,7 @@
 """Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
 cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
 
-    python tools/infer_profile.py [n_top]
+    python tools/infer_profile.py [n_top] [lanes]
 """
 import cProfile
 import os
@@ -28,16 +28,23 @@ def main():
     base = [{'image': rs.randint(0, 256, (480, 640, 3)).astype(np.uint8), 'width': 640, 'height': 480, 'flipped': False,
              'gt_overlaps': np.zeros((1, 81), np.float32)} for _ in range(8)]
     cfg = cfgmod.res101_e2e_autofocus()
-    cache = {}
-    for p in range(5):
+    lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    cache, blobs = {}, {}
+
+    def fmap(scale_i, image, chip, net_map):        # (drawn once per (scale, image, chip), as bench.py does)
+        key = (scale_i, image, chip, tuple(net_map.shape))
+        if key not in blobs:
+            blobs[key] = focus_map_blobs(scale_i, image, chip, net_map)
+        return blobs[key]
+    for p in range(7):                      # bind, capture, four replays timed plainly, one under cProfile
         roidb = [dict(r) for r in base]
         torch.cuda.synchronize()
-        pr = cProfile.Profile() if p == 4 else None
+        pr = cProfile.Profile() if p == 6 else None
         t0 = time.perf_counter()
         if pr:
             pr.enable()
         imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache,
-                               focus_map_fn=focus_map_blobs)
+                               focus_map_fn=fmap, lanes=lanes)
         torch.cuda.synchronize()
         if pr:
             pr.disable()
