@@ -23,7 +23,6 @@ def main():
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--cfgs', default='14,18')
     ap.add_argument('--only', default='s3 ')
-    ap.add_argument('--wgrad', action='store_true', help='trace conv_wgrad_tr_kernel (weight gradient) instead')
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(',')]
     d = torch.device('cuda', 0)
@@ -52,17 +51,12 @@ def main():
         reduce_ = K == 1 and s == 1 and C == 4 * O
         res = h(N, Ho, Wo, O) if expand else None
         acc = h(N, H, W, C) if reduce_ else None
-        dw = torch.zeros((O, K * K, C), dtype=torch.float32, device=d)
-        wsb = hip.query('sn_conv_wgrad_workspace_bytes', N, H, W, C, C, O, Op, K, K, s, p, dl) if a.wgrad else 0
-        wsp = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device=d)
-        for direction, cnt in ((('wgrad', nd),) if a.wgrad else (('fwd', nf), ('dgrad', nd))):
+        for direction, cnt in (('fwd', nf), ('dgrad', nd)):
             if cnt == 0:
                 continue
 
             def run():
-                if direction == 'wgrad':
-                    hip.call('sn_conv_wgrad', dy, x, dw, N, H, W, C, C, O, Op, K, K, s, p, dl, wsp, int(wsb), hip.stream())
-                elif direction == 'fwd':
+                if direction == 'fwd':
                     if hip.query('sn_conv_fwd_stats_blocks', N, H, W, C, C, O, O, O if res is not None else 0, K, K, s, p, dl) > 0:
                         hip.call('sn_conv_fwd_stats', x, w, None, res, y, N, H, W, C, C, O, O, O if res is not None else 0, K, K, s, p, dl, 0,
                                  part, hip.stream())
@@ -70,8 +64,8 @@ def main():
                         hip.call('sn_conv_fwd', x, w, None, None, y, N, H, W, C, C, O, O, O, K, K, s, p, dl, 0, 0, hip.stream())
                 else:
                     hip.call('sn_conv_dgrad', dy, wt, acc, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
-            for c in ([0] if a.wgrad else cfgs):
-                hip.call('sn_conv_tune', -1 if a.wgrad else c)
+            for c in cfgs:
+                hip.call('sn_conv_tune', c)
                 os.environ['SNIPER_CONV_TRACE_PTR'] = ''
                 for _ in range(2):
                     run()
@@ -90,8 +84,6 @@ def main():
                     os.environ['SNIPER_CONV_TRACE_PTR'] = ''
                     t = trace.cpu().numpy().reshape(-1, 8)
                     t = t[t[:, 0] > 0][:, :5].astype(np.float64)
-                    if a.wgrad:
-                        t[:, 4] = t[:, 3]
                     if not len(t):
                         print('%-26s %-5s cfg %d: no stamps (register-staged kernel chosen)' % (name, direction, c))
                         continue

@@ -9,8 +9,7 @@ import csv
 import json
 import sys
 
-FAMILY = ('conv_dma_kernel', 'conv_igemm_p2_kernel', 'conv_igemm_kernel', 'conv_wgrad_tr_kernel', 'conv_wgrad_kernel', 'wgrad_flat_dma_kernel',
-          'wgrad_taps_dma_kernel', 'wgrad_reduce_kernel', 'wgrad_ps_kernel', 'wgrad_reduce2_kernel')
+FAMILY = ('conv_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_kernel', 'wgrad_ps_kernel', 'wgrad_reduce2_kernel')
 
 
 def main():
