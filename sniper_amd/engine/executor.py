@@ -35,7 +35,7 @@ def _pad8(n):
 class Val(object):
     """One tensor of the graph.  fmt 'act': fp16 channels-last, t has shape (N,H,W,C) (2-D logical
     tensors use H=W=1); fmt 'f32': fp32, reference order, t has the logical shape."""
-    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer', 'grad_alias')
+    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer', 'grad_group')
 
     def __init__(self, name, shape, fmt):
         self.name, self.shape, self.fmt = name, tuple(shape), fmt
@@ -46,7 +46,7 @@ class Val(object):
         self.stem = None     # (src f32 NCHW Val, scale, shift) for a BN-folded image input
         self.consumers = 0
         self.producer = None  # the Step whose output this is
-        self.grad_alias = None   # the Val that was handed the SAME gradient tensor by a residual add (Executor.grad_slot)
+        self.grad_group = None   # the Vals that were handed the SAME gradient tensor by residual adds (one shared list; Executor.grad_slot)
 
     def nhwc(self):
         s = self.shape
@@ -240,12 +240,13 @@ class Executor(object):
         # copy on write: the tensor is also the (not yet consumed) gradient of the residual add's other operand.  In ResNet /
         # MobileNetV2 that operand's producer has run its backward and dropped the tensor by now (no copy); any other
         # graph order gets a private copy instead of a silently corrupted dY.
-        p = getattr(v, 'grad_alias', None)
-        if p is not None:
-            v.grad_alias = None
-            if p.grad is not None and p.grad.data_ptr() == v.grad.data_ptr():
-                p.grad_alias = None
-                v.grad = v.grad.clone()
+        group = getattr(v, 'grad_group', None)
+        if group is not None:
+            v.grad_group = None
+            ptr = v.grad.data_ptr()
+            if any(m is not v and m.grad is not None and m.grad.data_ptr() == ptr for m in group):
+                v.grad = v.grad.clone()          # (v leaves the group: its tensor is its own from here on)
+            group[:] = [m for m in group if m is not v]
         if self._pending_reads and v.grad.untyped_storage().data_ptr() in self._pending_reads:
             src = v.grad
             v.grad = self.empty(src.shape, src.dtype)
@@ -617,6 +618,7 @@ class Executor(object):
         for v in self.vals.values():
             v.alt = None
             v.grad = None
+            v.grad_group = None
         for s in self.steps:
             s.forward()
         self.outputs = [self.as_f32(self.vals[(id(n), i)]) for n, i in self.sym._heads]
@@ -668,6 +670,7 @@ class Executor(object):
             self.zero_grad()
             for v in self.vals.values():
                 v.grad = None
+                v.grad_group = None
         steps = self.steps if segment is None else (self.steps[k:] if segment == 'a' else self.steps[:k])
         for s in reversed(steps):
             s.backward()
@@ -675,6 +678,7 @@ class Executor(object):
         if segment in (None, 'b'):
             for v in self.vals.values():
                 v.grad = None
+                v.grad_group = None
         self._keepalive = []
 
     def _capture(self, fn, what, pool=None):

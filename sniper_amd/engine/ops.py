@@ -831,8 +831,18 @@ class BinaryStep(Step):
         if op in ('_plus', 'elemwise_add'):
             ex.add_grad(self.lhs, g, fmt)
             ex.add_grad(self.rhs, g, fmt)
-            if self.lhs.grad is not None and self.lhs.grad is self.rhs.grad:      # one tensor, two owners: see Executor.grad_slot
-                self.lhs.grad_alias, self.rhs.grad_alias = self.rhs, self.lhs
+            if self.lhs.grad is not None and self.lhs.grad is self.rhs.grad:      # one tensor, several owners: see Executor.grad_slot
+                # the owners of ONE gradient tensor share one list.  Nested adds (d = a + e, a = b + c) hand d's tensor to e, b
+                # and c: the inner add extends the list its own output already belongs to (minus that output: consumed here)
+                group = getattr(self.y, 'grad_group', None)
+                if group is None or self.y.grad is not self.lhs.grad:
+                    group = []
+                elif self.y in group:
+                    group.remove(self.y)
+                for v in (self.lhs, self.rhs):
+                    if not any(v is m for m in group):
+                        group.append(v)
+                    v.grad_group = group
         elif op == '_minus':
             ex.add_grad(self.lhs, g, fmt)
             if self.rhs.needs_grad:

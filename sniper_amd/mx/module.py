@@ -303,6 +303,9 @@ class Module(object):
         self.exe.update(lr, self.opt['wd'], self.opt['momentum'], self.opt['rescale_grad'])
 
     def get_outputs(self, merge_multi_context=True):
+        """The executor's output tensors, NOT copies: a test-time executor replays a captured forward into the same tensors, so
+        what this returned for batch i is overwritten by forward(i + 1) -- asnumpy() / copy what must outlive the next forward
+        (Tester copies to pinned host memory on the same stream before it launches the next batch)."""
         outs = [nd.NDArray(t) for t in self.exe.outputs]
         if merge_multi_context:
             return outs

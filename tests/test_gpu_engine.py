@@ -168,6 +168,98 @@ def test_executor_small_graph_vs_torch_autograd():
         assert torch.equal(p.w16.float(), p.master.half().float())
 
 
+@pytest.mark.parametrize('defer', ['1', '0'])
+def test_nested_residual_adds_share_one_gradient_tensor_safely(monkeypatch, defer):
+    """d = (b + c) + t with t also the input of the convolutions behind b and c: the add chain hands ONE gradient tensor to b, c
+    and t.  The data gradients of conv_b / conv_c accumulate into t's gradient while that tensor is still the dY of the other
+    convolution (and, with deferred weight gradients, of queued launches): Executor.grad_slot must give the accumulation a
+    tensor of its own.  Parameter gradients against fp32 autograd."""
+    import sniper_amd.mx as mx
+    from sniper_amd.engine.executor import Executor
+    monkeypatch.setenv('SNIPER_WGRAD_DEFER', defer)
+    B, C, S = 2, 64, 16
+    data, target = mx.sym.Variable('data'), mx.sym.Variable('target')
+    t = mx.sym.Convolution(data=data, kernel=(1, 1), num_filter=C, no_bias=True, name='stem')
+    b = mx.sym.Convolution(data=t, kernel=(3, 3), pad=(1, 1), num_filter=C, no_bias=True, name='conv_b')
+    c = mx.sym.Convolution(data=t, kernel=(1, 1), num_filter=C, no_bias=True, name='conv_c')
+    d = (b + c) + t
+    out = mx.sym.Convolution(data=mx.sym.Activation(data=d, act_type='relu', name='relu_d'), kernel=(1, 1), num_filter=8, name='head')
+    loss = mx.sym.MakeLoss(name='loss', data=mx.sym.smooth_l1(name='loss_', scalar=1.0, data=(out - target)), grad_scale=1.0)
+    shapes = dict(data=(B, C, S, S), target=(B, 8, S, S))
+    ex = Executor(loss, shapes, True, [])
+    rs = np.random.RandomState(2)
+    args, _, _ = loss.infer_shape(**shapes)
+    P = {}
+    for name, shp in zip(loss.list_arguments(), args):
+        if name in shapes:
+            continue
+        P[name] = (rs.standard_normal(shp) * (0.1 if name.endswith('_bias') else np.sqrt(1.0 / np.prod(shp[1:])))).astype(np.float32)
+    ex.set_params(P, {})
+    inp = dict(data=rs.standard_normal(shapes['data']).astype(np.float32), target=rs.standard_normal(shapes['target']).astype(np.float32))
+    ex.forward(inp, is_train=True)
+    ex.backward()
+    torch.cuda.synchronize()
+    w = {k: torch.from_numpy(f16r(v) if v.ndim > 1 else v.copy()).requires_grad_(True) for k, v in P.items()}
+    x = torch.from_numpy(f16r(inp['data']))
+    tt = Fnn.conv2d(x, w['stem_weight'])
+    dd = Fnn.conv2d(tt, w['conv_b_weight'], None, 1, 1) + Fnn.conv2d(tt, w['conv_c_weight']) + tt
+    o = Fnn.conv2d(torch.relu(dd), w['head_weight'], w['head_bias'])
+    df = o - torch.from_numpy(inp['target'])
+    torch.where(df.abs() < 1, 0.5 * df * df, df.abs() - 0.5).sum().backward()
+    for name, p in ex.params.items():
+        got, want = p.to_reference(p.grad.detach().cpu().numpy()), w[name].grad.numpy()
+        scale = np.abs(want).max()
+        assert np.linalg.norm(got - want) <= 2e-2 * np.linalg.norm(want), (name, np.linalg.norm(got - want) / np.linalg.norm(want))
+        assert_close(got, want, 5e-2, 3e-2 * scale, 'nested adds: grad %s' % name)
+
+
+def test_small_graph_reads_no_uninitialised_memory():
+    """The small graph of test_executor_small_graph_vs_torch_autograd (32-channel bottlenecks on the register-staged kernels,
+    Concat, a 36-step contraction on the producer/consumer kernel, one-tile grids) over allocator blocks full of 0x00 and of
+    0xFF bytes: outputs and gradients finite and identical.  Freshly mapped device memory is usually zero, which hides a read
+    of a partial-sum row or padded pitch nobody wrote -- until a box hands out dirty pages."""
+    import sniper_amd.mx as mx
+    from sniper_amd.engine.executor import Executor
+    A, B, S = 3, 2, 64
+    sym = _mini_graph(mx, A)
+    F = S // 8
+    shapes = dict(data=(B, 3, S, S), label=(B, A * F * F), bbox_target=(B, 4 * A, F, F), bbox_weight=(B, 4 * A, F, F))
+    fixed = [n for n in sym.list_arguments() if any(p in n for p in ('conv0', 'bn0', 'bn_data'))]
+    rs = np.random.RandomState(0)
+    args, _, auxs = sym.infer_shape(**shapes)
+    P = {n: (rs.uniform(0.5, 1.5, s) if n.endswith('_gamma') else rs.standard_normal(s) * (0.1 if len(s) == 1 else np.sqrt(2.0 / np.prod(s[1:])))
+             ).astype(np.float32) for n, s in zip(sym.list_arguments(), args) if n not in shapes}
+    AUX = {n: (rs.uniform(0.5, 1.5, s) if n.endswith('_var') else rs.standard_normal(s) * 0.1).astype(np.float32)
+           for n, s in zip(sym.list_auxiliary_states(), auxs)}
+    inp = dict(data=(rs.standard_normal((B, 3, S, S)) * 2).astype(np.float32),
+               label=rs.choice([-1, 0, 1], size=(B, A * F * F), p=[0.5, 0.3, 0.2]).astype(np.float32),
+               bbox_target=rs.standard_normal((B, 4 * A, F, F)).astype(np.float32),
+               bbox_weight=(rs.uniform(size=(B, 4 * A, F, F)) < 0.2).astype(np.float32))
+    runs = []
+    for poison in (0x00, 0xFF, 0x3C):        # zeros, NaN patterns, finite garbage (fp16 1.06, fp32 0.0115)
+        torch.cuda.empty_cache()
+        junk = torch.full((2 << 30,), poison, dtype=torch.uint8, device='cuda')
+        del junk                             # back into the allocator's free list: the executor's torch.empty calls land on it
+        ex = Executor(sym, shapes, True, fixed)
+        ex.use_graphs = False
+        ex.set_params(P, AUX)
+        for _ in range(2):                   # (the second step runs on recycled gradient / workspace buffers)
+            outs = ex.forward(inp, is_train=True)
+            ex.backward()
+        torch.cuda.synchronize()
+        o = [t.double().cpu().numpy().copy() for t in outs]
+        g = {n: p.grad.double().cpu().numpy().copy() for n, p in ex.params.items() if p.trainable}
+        assert all(np.isfinite(t).all() for t in o), 'non-finite output over 0x%02x blocks' % poison
+        assert all(np.isfinite(t).all() for t in g.values()), 'non-finite gradient over 0x%02x blocks' % poison
+        runs.append((o, g))
+        del ex
+    for o, g in runs[1:]:
+        for u, v in zip(runs[0][0], o):
+            assert np.array_equal(u, v)
+        for n in g:
+            assert np.array_equal(runs[0][1][n], g[n]), n
+
+
 def test_chip_worker_mirror_golden():
     """sniper_amd.data.chip_worker (GPU, batched) reproduces the reference's chip_extractor / box_assigner
     outputs recorded in the golden fixture, when fed the recorded candidate permutations."""
