@@ -40,7 +40,9 @@ pmc)
         python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference > "$ROOT/gpurun_out/rocprof_pmc_$C.log" 2>&1; echo "pmc $C exit $?")
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json > /dev/null
-  python tools/pmc_report.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_kernels.json | head -60
+  # (rates also over the un-countered durations of the `prof` step's kernel statistics, when that step ran in this visit)
+  python tools/pmc_report.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_kernels.json "" \
+      "$(find gpurun_out/prof_bench -name '*kernel_stats.csv' 2>/dev/null | head -1)" | head -60
   # (copy gpurun_out/pmc_traffic.json and gpurun_out/pmc_kernels.json to profiles/: bench.py reads them there, keyed on the source hash)
   find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete ;;
 esac
