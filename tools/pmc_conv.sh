@@ -19,18 +19,29 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for d in sorted(glob.glob('gpurun_out/pmc_conv[0-9]')):
     for f in glob.glob(d + '/**/*counter_collection*.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            k = re.sub(r'\(.*', '', r['Kernel_Name'])[:64]
+            k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', ''))[:64]
             if 'conv' not in k and 'wgrad' not in k and 'bn_' not in k: continue
             acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
     for f in glob.glob(d + '/**/*kernel_trace*.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            k = re.sub(r'\(.*', '', r['Kernel_Name'])[:64]
+            k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', ''))[:64]
             dur[k].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 for k, v in sorted(acc.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
     d_ = dur.get(k, [0])
     print('%s   launches %d  avg %.1f us' % (k, len(d_), sum(d_) / max(len(d_), 1) / 1e3))
-    for c, x in sorted(v.items()):
-        print('   %-28s %16.0f per launch' % (c, x / max(n[(k, c)], 1)))
+    per = {c: x / max(n[(k, c)], 1) for c, x in v.items()}
+    for c, x in sorted(per.items()):
+        print('   %-28s %16.0f per launch' % (c, x))
+    # derived (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles, summed over the SIMDs; GRBM_GUI_ACTIVE is reported per
+    # XCD and summed over the 8 of them; 256 CUs x 4 SIMDs): share of SIMD-cycles with the matrix pipe busy
+    if per.get('GRBM_GUI_ACTIVE') and per.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+        print('   %-28s %16.3f  (MFMA busy cycles / (GUI_ACTIVE / 8 x 1024 SIMDs))' % (
+            'derived mfma_busy_frac', per['SQ_VALU_MFMA_BUSY_CYCLES'] / (per['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)))
+    if per.get('SQ_LDS_IDX_ACTIVE'):
+        print('   %-28s %16.4f  (bank-conflict cycles / LDS active cycles)' % (
+            'derived lds_conflict_frac', per.get('SQ_LDS_BANK_CONFLICT', 0.0) / per['SQ_LDS_IDX_ACTIVE']))
+    if per.get('TCC_REQ_sum'):
+        print('   %-28s %16.3f  (L2 hits / requests)' % ('derived l2_hit_frac', per.get('TCC_HIT_sum', 0.0) / per['TCC_REQ_sum']))
 PY
 head -150 gpurun_out/pmc_conv_insitu.txt
 find gpurun_out/pmc_conv[0-9] -name "*.csv" -size +6M -delete
