@@ -7,6 +7,8 @@ mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.txt
 nproc >> gpurun_out/device.txt
+# which physical card this visit ran on (a misbehaving box shows up as the same id across visits)
+{ hostname; rocm-smi --showuniqueid --showserial --showbus 2>/dev/null | grep -E "Unique|Serial|PCI"; } >> gpurun_out/device.txt
 for WHAT in "${@:-bench}"; do
 case $WHAT in
 tests)
