@@ -1,7 +1,7 @@
 """Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
 cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
 
-    python tools/infer_profile.py [n_top] [lanes]
+    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2)]
 """
 import cProfile
 import os
@@ -29,6 +29,8 @@ def main():
              'gt_overlaps': np.zeros((1, 81), np.float32)} for _ in range(8)]
     cfg = cfgmod.res101_e2e_autofocus()
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    if len(sys.argv) > 3:
+        cfg.TEST.BATCH_IMAGES = tuple(int(b) for b in sys.argv[3].split(','))
     cache, blobs = {}, {}
 
     def fmap(scale_i, image, chip, net_map):        # (drawn once per (scale, image, chip), as bench.py does)
