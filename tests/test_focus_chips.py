@@ -186,3 +186,34 @@ def test_reference_aggregation_baseline_matches_the_vectorised_one():
     assert len(big) > 3
     assert np.array_equal(inference_ref.nms_problem(big, 0.55), oracle.soft_nms(big, sigma=0.55, Nt=0.3, threshold=0.001, method=2))
     assert inference_ref.kind() in ('reference', 'port')
+
+
+def test_bench_focus_maps_give_the_specified_c5_workload():
+    """bench.py's injected FocusPixel maps (~10 % positive pixels in blobs) through the real FocusChip generation:
+    the positive fraction of every map, the chips per image at the two finer scales (what BENCH prints as
+    chips_per_image_by_scale) and the share of the finest scale's pixels that is actually processed."""
+    from bench import focus_map_blobs
+    from sniper_amd import config as cfgmod
+    from sniper_amd.chips_inference import add_chips
+    from sniper_amd.data.im_worker import target_scale
+    cfg = cfgmod.res101_e2e_autofocus()
+    roidb = [{'width': 640, 'height': 480, 'inference_crops': np.array([[0, 0, 640, 480]])} for _ in range(8)]
+    chips, areas = [], []
+    for s in range(2):
+        maps = []
+        for i, r in enumerate(roidb):
+            sc = target_scale(640, 480, cfg.TEST.SCALES[s])
+            per = []
+            for j, c in enumerate(r['inference_crops']):
+                h, w = int(np.ceil((c[3] - c[1]) * sc / 16)), int(np.ceil((c[2] - c[0]) * sc / 16))
+                m = focus_map_blobs(s, i, j, np.zeros((2, h, w), np.float32))
+                assert m.shape == (2, h, w) and np.allclose(m.sum(0), 1.0)
+                assert 0.07 <= float((m[1] > 0.5).mean()) <= 0.13
+                assert np.array_equal(m, focus_map_blobs(s, i, j, np.zeros((2, h, w), np.float32)))      # deterministic
+                per.append(m)
+            maps.append(per)
+        areas.append(add_chips(roidb, maps, s, cfg))
+        chips.append([len(r['inference_crops']) for r in roidb])
+    assert chips[0] == [1] * 8 and all(1 <= n <= 4 for n in chips[1]) and 12 <= sum(chips[1]) <= 24
+    assert sum(chips[1]) == 17                                      # the line profiles/r03_bench_v2.json reports
+    assert 0.2 <= areas[1][0] / areas[1][1] <= 0.5                  # a third of the finest scale's pixels is run
