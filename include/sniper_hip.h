@@ -131,6 +131,12 @@ int sn_im_prepare(const uint8_t *d_src_bgr, int src_h, int src_w, int crop_x1, i
  * rois (B*R,5) f32 with rows of chip b contiguous, deltas (B,R,4) f32, im_info (B,3) f32 -> boxes (B,R,4) f64. */
 int sn_bbox_decode(const float *d_rois, const float *d_deltas, const float *d_im_info, double *d_boxes, int B, int R,
                    sn_stream_t stream);
+/* `gmask` of lib/chips/chips_inference.py:12-89 on the HOST (no device work, no stream): FocusPixel map (H,W) f32 -> FocusChips.
+ * threshold (>= thresh), cv2.dilate d x d, bounding rectangles of the RETR_LIST contours (8-connected components + holes), minimum
+ * side ms cells, paint-and-repeat until the chip count is stable, x16, clamp to (im_width, im_height), / cscale.
+ * chips_xyxy (max_chips,4) f64 host, n_chips host.  Restatement of the cv2 calls: parity unpinned (no OpenCV here). */
+int sn_focus_chips_host(const float *map_hw, int H, int W, int d, float thresh, int ms, double im_width, double im_height,
+                        double cscale, double *chips_xyxy, int max_chips, int32_t *n_chips);
 /* The per-class score threshold of Tester.get_detections (lib/inference.py:289-295: inds = where(scores[:, j] > thresh), rows
  * hstack(boxes[inds, 0:4], scores[inds, j])) and, when h_crops != NULL, the AutoFocus border pruning that follows it (:336-353,
  * check_valid :236-259: rows shifted by the chip origin, dropped within `delta` px of a chip border that is not an image

@@ -24,6 +24,7 @@ EXTRA = {
     "nms.hip": ["-ffp-contract=off"],
     "proposal.hip": ["-ffp-contract=off"],
     "infer.hip": ["-ffp-contract=off"],
+    "focus_chips_host.cpp": ["-ffp-contract=off"],
     "mask.hip": ["-ffp-contract=off"],
 }
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
@@ -46,7 +47,8 @@ def _is_remark_context(line):
 
 
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    """Kernel sources (.hip) and host-only sources (.cpp) of the one library."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def _stale(obj, src):
@@ -65,7 +67,7 @@ def build(force=False, verbose=True):
     objs = []
     for f in sources():
         src = os.path.join(CSRC, f)
-        obj = os.path.join(OBJ_DIR, f[:-4] + ".o")
+        obj = os.path.join(OBJ_DIR, os.path.splitext(f)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, src):
             jobs.append([hipcc] + BASE + EXTRA.get(f, []) + ["-c", src, "-o", obj])

@@ -1,0 +1,169 @@
+// focus_chips_host.cpp -- host-only code of the library (no kernels: a .cpp, so that the identity of the DEVICE sources that
+// bench.py keys its counter reports on -- every .hip / .h of this directory -- does not move with it).
+#include "common.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// focus_chips_host: `gmask` of lib/chips/chips_inference.py:12-89 on the HOST, in one call -- threshold the FocusPixel map, dilate
+// (cv2.dilate with a d x d kernel), bounding rectangles of the contours cv2.findContours(RETR_LIST) reports (every 8-connected
+// foreground component, and every hole = 4-connected background component that does not touch the map border, grown by one
+// cell), minimum side `ms`, paint-and-repeat until the chip count is stable, x16, clamp to the crop, / cscale.  The maps are at
+// most 125 x 88 cells: this is host work in the reference too (OpenCV); the Python statement of the same steps over
+// scipy.ndimage (sniper_amd/chips_inference.py::gmask_reference, 250 us per map) stays as the definition this is tested against,
+// component order included (raster order of a component's first cell, as scipy.ndimage.label numbers them).
+// The cv2 calls themselves are restated, not linked: PARITY UNPINNED, exactly as for the Python statement.
+namespace {
+struct CellRect { int x, y, w, h; };
+
+// The map lives in a frame of one sentinel cell (value 1: neither background 0 nor foreground 255), so a flood fill needs no
+// bounds checks.  Bounding boxes of the connected components of `want`-valued cells (8- or 4-connectivity), in raster order of a
+// component's first cell; holes_only: components that touch the map border are skipped and the box grows by one cell.
+void component_rects(const unsigned char *mp, int H, int W, unsigned char want, bool conn8, bool holes_only, unsigned char *seen,
+                     int *stack, CellRect *out, int cap, int *n, int wy0, int wy1, int wx0, int wx1) {
+  const int Wp = W + 2;
+  const int off8[8] = {-Wp - 1, -Wp, -Wp + 1, -1, 1, Wp - 1, Wp, Wp + 1}, off4[4] = {-Wp, -1, 1, Wp};
+  const int dx8[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dx4[4] = {0, -1, 1, 0};
+  const int *off = conn8 ? off8 : off4, *dxs = conn8 ? dx8 : dx4;
+  const int noff = conn8 ? 8 : 4;
+  // only the window [wy0, wy1] x [wx0, wx1] (map coordinates) is walked: everything outside it counts as visited
+  memset(seen, 1, (size_t)(H + 2) * Wp);
+  for (int y = wy0; y <= wy1; ++y) memset(seen + (y + 1) * Wp + wx0 + 1, 0, (size_t)(wx1 - wx0 + 1));
+  for (int y = wy0 + 1; y <= wy1 + 1; ++y)
+    for (int x = wx0 + 1; x <= wx1 + 1; ++x) {
+      const int i0 = y * Wp + x;
+      if (mp[i0] != want || seen[i0]) continue;
+      // the stack holds (cell, its column): rows follow from the smallest / largest cell index, no division per cell
+      int x0 = x, x1 = x, lo = i0, hi = i0, top = 0;
+      stack[top++] = i0;
+      stack[top++] = x;
+      seen[i0] = 1;
+      while (top) {
+        const int cx = stack[--top], i = stack[--top];
+        x0 = cx < x0 ? cx : x0; x1 = cx > x1 ? cx : x1; lo = i < lo ? i : lo; hi = i > hi ? i : hi;
+        for (int k = 0; k < noff; ++k) {
+          const int j = i + off[k];
+          if (mp[j] == want && !seen[j]) {
+            seen[j] = 1;
+            stack[top++] = j;
+            stack[top++] = cx + dxs[k];
+          }
+        }
+      }
+      int y0 = lo / Wp, y1 = hi / Wp;
+      --x0; --x1; --y0; --y1;                      // frame coordinates -> map coordinates
+      if (holes_only) {
+        // open background, not a hole: it reaches a side of the window, and every side of the window is either the map border
+        // or a foreground-free ring around the foreground's bounding box (connected to the map border outside it)
+        if (x0 == wx0 || y0 == wy0 || x1 == wx1 || y1 == wy1) continue;
+        if (*n < cap) out[*n] = CellRect{x0 - 1, y0 - 1, x1 - x0 + 3, y1 - y0 + 3};
+      } else if (*n < cap) {
+        out[*n] = CellRect{x0, y0, x1 - x0 + 1, y1 - y0 + 1};
+      }
+      ++*n;
+    }
+}
+
+CellRect place_rect(CellRect r, int ms, int iw, int ih) {
+  const int cx = (r.x + r.x + r.w) / 2, cy = (r.y + r.y + r.h) / 2;
+  const int w = r.w > ms ? r.w : ms, h = r.h > ms ? r.h : ms;
+  int x, y;
+  if (cx + w / 2 >= iw) x = iw - w >= 0 ? iw - w : 0;
+  else if (cx - w / 2 < 0) x = 0;
+  else x = cx - w / 2;
+  if (cy + h / 2 >= ih) y = ih - h >= 0 ? ih - h : 0;
+  else if (cy - h / 2 < 0) y = 0;
+  else y = cy - h / 2;
+  return CellRect{x, y, w, h};
+}
+}  // namespace
+
+SN_EXPORT int sn_focus_chips_host(const float *map_hw, int H, int W, int d, float thresh, int ms, double im_width, double im_height,
+                                  double cscale, double *chips_xyxy, int max_chips, int32_t *n_chips) {
+  SN_REQUIRE(map_hw && chips_xyxy && n_chips && H > 0 && W > 0 && H * W <= (1 << 20) && max_chips > 0 && cscale > 0.0,
+             "sn_focus_chips_host: bad arguments");
+  const int iw = (int)ceil(im_width / 16.0), ih = (int)ceil(im_height / 16.0);
+  const int cap = 4096, Wp = W + 2;
+  const size_t cells = (size_t)(H + 2) * Wp;
+  // per-thread scratch that only grows: a 128 KB malloc per call is an mmap / munmap pair (page faults: most of the call's time)
+  thread_local std::vector<unsigned char> bytes;
+  thread_local std::vector<int> ints;
+  thread_local std::vector<CellRect> boxes;
+  if (bytes.size() < cells * 3) bytes.resize(cells * 3);
+  if (ints.size() < cells * 2) ints.resize(cells * 2);
+  if (boxes.size() < (size_t)cap * 2) boxes.resize((size_t)cap * 2);
+  unsigned char *m = bytes.data();                            // framed map, threshold scratch, flood-fill marks
+  int *stack = ints.data();
+  CellRect *rects = boxes.data();
+  unsigned char *t = m + cells, *seen = m + 2 * cells;
+  CellRect *chips = rects + cap;
+  memset(m, 1, cells);                                        // the frame (the interior is written below)
+  memset(t, 0, cells);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) t[(y + 1) * Wp + x + 1] = map_hw[y * W + x] >= thresh ? 1 : 0;
+  // cv2.dilate(d x d): anchor (d / 2, d / 2) -> window [y - d/2, y + d - 1 - d/2], cells outside the map do not contribute
+  const int lo = d > 1 ? d / 2 : 0, hi = d > 1 ? d - 1 - d / 2 : 0;
+  // (output cell y sees source rows [y - lo, y + hi]: source row yy reaches output rows [yy - hi, yy + lo]; the few set cells paint)
+  for (int y = 0; y < H; ++y) memset(m + (y + 1) * Wp + 1, 0, (size_t)W);
+  for (int yy = 0; yy < H; ++yy)
+    for (int xx = 0; xx < W; ++xx) {
+      if (!t[(yy + 1) * Wp + xx + 1]) continue;
+      for (int y = (yy - hi < 0 ? 0 : yy - hi); y <= yy + lo && y < H; ++y)
+        for (int x = (xx - hi < 0 ? 0 : xx - hi); x <= xx + lo && x < W; ++x) m[(y + 1) * Wp + x + 1] = 255;
+    }
+  auto all_rects = [&](int *n) {
+    *n = 0;
+    component_rects(m, H, W, 255, true, false, seen, stack, rects, cap, n, 0, H - 1, 0, W - 1);   // 8-connected components
+    if (*n == 0 || *n > cap) return;
+    // holes lie inside the foreground's bounding box: label the background of that box and a one-cell ring around it only
+    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
+    for (int k = 0; k < *n; ++k) {
+      bx0 = rects[k].x < bx0 ? rects[k].x : bx0; bx1 = rects[k].x + rects[k].w - 1 > bx1 ? rects[k].x + rects[k].w - 1 : bx1;
+      by0 = rects[k].y < by0 ? rects[k].y : by0; by1 = rects[k].y + rects[k].h - 1 > by1 ? rects[k].y + rects[k].h - 1 : by1;
+    }
+    component_rects(m, H, W, 0, false, true, seen, stack, rects, cap, n, by0 > 0 ? by0 - 1 : 0, by1 < H - 1 ? by1 + 1 : H - 1,
+                    bx0 > 0 ? bx0 - 1 : 0, bx1 < W - 1 ? bx1 + 1 : W - 1);
+  };
+  int nr = 0, nchips = -1, nc = 0;
+  all_rects(&nr);
+  bool overflow = nr > cap;
+  while (!overflow && nchips != nc) {
+    nchips = nc;
+    nc = 0;
+    bool painted = false;
+    for (int k = 0; k < nr; ++k) {
+      const CellRect r = place_rect(rects[k], ms, iw, ih);
+      for (int y = r.y; y < r.y + r.h && y < H; ++y)          // numpy slicing clips at the map's edge
+        for (int x = r.x; x < r.x + r.w && x < W; ++x) {
+          unsigned char &c = m[(y + 1) * Wp + x + 1];
+          painted |= c != 255;
+          c = 255;
+        }
+    }
+    if (painted) all_rects(&nr);                              // (an unchanged map has the contours it had)
+    if (nr > cap) { overflow = true; break; }
+    for (int k = 0; k < nr; ++k) chips[nc++] = place_rect(rects[k], ms, iw, ih);
+  }
+  int status = SN_OK;
+  if (overflow || nc > max_chips) {
+    status = 1;
+  } else {
+    for (int k = 0; k < nc; ++k) {
+      double x1 = chips[k].x * 16.0, y1 = chips[k].y * 16.0, x2 = (chips[k].x + chips[k].w) * 16.0, y2 = (chips[k].y + chips[k].h) * 16.0;
+      if (x2 > im_width) {
+        x2 = im_width;
+        x1 = fmax(fmin(x1, x2 - ms * 16.0), 0.0);
+      }
+      if (y2 > im_height) {
+        y2 = im_height;
+        y1 = fmax(fmin(y1, y2 - ms * 16.0), 0.0);
+      }
+      chips_xyxy[4 * k + 0] = x1 / cscale; chips_xyxy[4 * k + 1] = y1 / cscale;
+      chips_xyxy[4 * k + 2] = x2 / cscale; chips_xyxy[4 * k + 3] = y2 / cscale;
+    }
+    *n_chips = nc;
+  }
+  SN_REQUIRE(status == SN_OK, "sn_focus_chips_host: more contours / chips than the caller's capacity");
+  return SN_OK;
+}

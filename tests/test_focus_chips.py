@@ -217,3 +217,42 @@ def test_bench_focus_maps_give_the_specified_c5_workload():
     assert chips[0] == [1] * 8 and all(1 <= n <= 4 for n in chips[1]) and 12 <= sum(chips[1]) <= 24
     assert sum(chips[1]) == 17                                      # the line profiles/r03_bench_v2.json reports
     assert 0.2 <= areas[1][0] / areas[1][1] <= 0.5                  # a third of the finest scale's pixels is run
+
+
+def test_native_focus_chips_equal_the_python_statement():
+    """sn_focus_chips_host (what gmask calls) against gmask_reference (the scipy.ndimage statement of lib/chips/chips_inference.py
+    :12-89) on random maps: blobs, rings and frames (holes), noise, empty maps; every dilation size, threshold and minimum side of
+    the configs and a few more; crops that end inside the last cell.  Same chips, same order, same float64 values."""
+    from sniper_amd.chips_inference import gmask, gmask_reference
+    rs = np.random.RandomState(4)
+    n_chips = 0
+    for trial in range(500):
+        H, W = int(rs.randint(3, 90)), int(rs.randint(3, 126))
+        m = np.full((H, W), 0.01, np.float32)
+        yy, xx = np.mgrid[0:H, 0:W]
+        kind = trial % 5
+        if kind == 0:
+            for _ in range(rs.randint(1, 6)):
+                cy, cx, r = rs.randint(0, H), rs.randint(0, W), rs.randint(1, 9)
+                m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0.9
+        elif kind == 1:
+            for _ in range(rs.randint(1, 4)):
+                cy, cx, r = rs.randint(0, H), rs.randint(0, W), rs.randint(3, 14)
+                d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+                m[(d2 <= r * r) & (d2 >= (r - 2) ** 2)] = 0.9
+        elif kind == 2:
+            m = rs.rand(H, W).astype(np.float32) ** int(rs.randint(1, 8))
+        elif kind == 3:
+            for _ in range(rs.randint(1, 4)):
+                y0, x0 = rs.randint(0, max(1, H - 2)), rs.randint(0, max(1, W - 2))
+                y1, x1 = rs.randint(y0, H), rs.randint(x0, W)
+                m[y0:y1 + 1, x0:x1 + 1] = 0.9
+                if y1 - y0 > 3 and x1 - x0 > 3:
+                    m[y0 + 2:y1 - 1, x0 + 2:x1 - 1] = 0.0
+        d, thr, ms = int(rs.choice([1, 2, 3, 4, 5])), float(rs.choice([0.02, 0.2, 0.5])), int(rs.choice([1, 4, 16, 20]))
+        cs = float(rs.choice([0.8, 1.6667, 2.9166]))
+        imw, imh = W * 16 - int(rs.randint(0, 16)), H * 16 - int(rs.randint(0, 16))
+        got, want = gmask(m, d, thr, ms, imw, imh, cs), gmask_reference(m, d, thr, ms, imw, imh, cs)
+        assert got == [[float(v) for v in c] for c in want], (trial, kind, (H, W), d, thr, ms)
+        n_chips += len(got)
+    assert n_chips > 500
