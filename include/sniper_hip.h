@@ -137,6 +137,14 @@ int sn_bbox_decode(const float *d_rois, const float *d_deltas, const float *d_im
  * chips_xyxy (max_chips,4) f64 host, n_chips host.  Restatement of the cv2 calls: parity unpinned (no OpenCV here). */
 int sn_focus_chips_host(const float *map_hw, int H, int W, int d, float thresh, int ms, double im_width, double im_height,
                         double cscale, double *chips_xyxy, int max_chips, int32_t *n_chips);
+/* The regrouping half of Tester.aggregate (lib/inference.py:166-190) on the HOST in one pass: parts = the chips of all scales as
+ * sn_det_compact returned them (part_rows[p] = address of float64 (n_p,5) rows grouped by class, lens (P,nc) rows per class), the
+ * parts of image i = part_of_image[i] .. part_of_image[i+1]-1 in (scale, chip) order, range2 (P,2) f32 = the scale's valid range
+ * squared (<= 0: no bound; areas and comparisons in float32, _valid_range_filter :176-186).  -> out_rows (total,5) f32: the rows of
+ * all (image, class) problems back to back in (image, class, scale, chip, row) order; out_sizes (num_images*nc) rows per problem. */
+int sn_aggregate_problems_host(const uint64_t *part_rows, const int64_t *lens, const int32_t *part_of_image, const float *range2,
+                               int P, int nc, int num_images, float *out_rows, long capacity_rows, int64_t *out_sizes,
+                               int64_t *total_rows);
 /* The per-class score threshold of Tester.get_detections (lib/inference.py:289-295: inds = where(scores[:, j] > thresh), rows
  * hstack(boxes[inds, 0:4], scores[inds, j])) and, when h_crops != NULL, the AutoFocus border pruning that follows it (:336-353,
  * check_valid :236-259: rows shifted by the chip origin, dropped within `delta` px of a chip border that is not an image

@@ -24,7 +24,7 @@ EXTRA = {
     "nms.hip": ["-ffp-contract=off"],
     "proposal.hip": ["-ffp-contract=off"],
     "infer.hip": ["-ffp-contract=off"],
-    "focus_chips_host.cpp": ["-ffp-contract=off"],
+    "host_inference.cpp": ["-ffp-contract=off"],
     "mask.hip": ["-ffp-contract=off"],
 }
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wno-unused-function",

@@ -1,4 +1,4 @@
-// focus_chips_host.cpp -- host-only code of the library (no kernels: a .cpp, so that the identity of the DEVICE sources that
+// host_inference.cpp -- host-only code of the library (no kernels: a .cpp, so that the identity of the DEVICE sources that
 // bench.py keys its counter reports on -- every .hip / .h of this directory -- does not move with it).
 #include "common.h"
 #include <math.h>
@@ -165,5 +165,55 @@ SN_EXPORT int sn_focus_chips_host(const float *map_hw, int H, int W, int d, floa
     *n_chips = nc;
   }
   SN_REQUIRE(status == SN_OK, "sn_focus_chips_host: more contours / chips than the caller's capacity");
+  return SN_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// aggregate_problems_host: the regrouping half of Tester.aggregate (lib/inference.py:166-190).  The reference walks
+// classes x images x scales x chips in Python, filters every chip's rows by the scale's valid range (areas in float32,
+// _valid_range_filter :176-186) and stacks what is left per (image, class) for the NMS pool.  Here the chips arrive as the GPU
+// returned them (rows of one chip grouped by class, float64, + rows per class: sn_det_compact) and ONE pass writes the float32
+// rows of all (image, class) problems back to back, in (image, class, scale, chip, row) order, plus the rows per problem --
+// exactly the array the batched soft-NMS launch uploads.  Tested equal to the numpy statement (sniper_amd/inference.py).
+// part_rows[p]: float64 (n_p, 5) rows of part p; lens (P, nc): rows per class of part p; parts of image i are
+// part_of_image[i] .. part_of_image[i + 1] - 1 in (scale, chip) order; range2 (P, 2): squared valid range as float32, <= 0: none.
+SN_EXPORT int sn_aggregate_problems_host(const uint64_t *part_rows, const int64_t *lens, const int32_t *part_of_image,
+                                         const float *range2, int P, int nc, int num_images, float *out_rows, long capacity_rows,
+                                         int64_t *out_sizes, int64_t *total_rows) {
+  SN_REQUIRE(part_rows && lens && part_of_image && range2 && out_rows && out_sizes && total_rows && P >= 0 && nc > 0 &&
+                 num_images >= 0 && capacity_rows >= 0,
+             "sn_aggregate_problems_host: bad arguments");
+  thread_local std::vector<int64_t> first;           // first row of class j inside part p
+  first.resize((size_t)P * nc);
+  for (int p = 0; p < P; ++p) {
+    int64_t at = 0;
+    for (int j = 0; j < nc; ++j) {
+      first[(size_t)p * nc + j] = at;
+      at += lens[(size_t)p * nc + j];
+    }
+  }
+  long n = 0;
+  for (int i = 0; i < num_images; ++i)
+    for (int j = 0; j < nc; ++j) {
+      const long before = n;
+      for (int p = part_of_image[i]; p < part_of_image[i + 1]; ++p) {
+        const double *src = reinterpret_cast<const double *>(part_rows[p]) + first[(size_t)p * nc + j] * 5;
+        const int64_t cnt = lens[(size_t)p * nc + j];
+        const float lo2 = range2[2 * p], hi2 = range2[2 * p + 1];
+        for (int64_t r = 0; r < cnt; ++r, src += 5) {
+          const float x1 = (float)src[0], y1 = (float)src[1], x2 = (float)src[2], y2 = (float)src[3];
+          const float area = (y2 - y1) * (x2 - x1);                  // float32 products, as _valid_range_filter
+          if (lo2 > 0.f && !(area > lo2)) continue;
+          if (hi2 > 0.f && !(area <= hi2)) continue;
+          SN_REQUIRE(n < capacity_rows, "sn_aggregate_problems_host: output capacity");
+          float *dst = out_rows + n * 5;
+          dst[0] = x1; dst[1] = y1; dst[2] = x2; dst[3] = y2; dst[4] = (float)src[4];
+          ++n;
+        }
+      }
+      out_sizes[(size_t)i * nc + j] = n - before;
+    }
+  *total_rows = n;
   return SN_OK;
 }

@@ -145,6 +145,10 @@ def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes, st
     per (part, class) counts -- no sort.  Returns the problems in (image, class) order, float32 (n, 5); stacked=True: the same
     rows as ONE (total, 5) array + the rows per problem (what the batched soft-NMS launch uploads)."""
     nc = num_classes - 1
+    if stacked:
+        native = _aggregate_stacked_native(scale_cls_dets, valid_ranges, num_images, nc)
+        if native is not None:
+            return native
     problems, sizes = [], []
     for i in range(num_images):
         parts, counts = [], []
@@ -188,6 +192,36 @@ def aggregate_problems(scale_cls_dets, valid_ranges, num_images, num_classes, st
         rows = np.concatenate(problems) if problems else np.zeros((0, 5), np.float32)
         return rows, (np.concatenate(sizes) if sizes else np.zeros(0, np.int64))
     return problems
+
+
+def _aggregate_stacked_native(scale_cls_dets, valid_ranges, num_images, nc):
+    """aggregate_problems(stacked=True) in one pass of sn_aggregate_problems_host, when EVERY chip's rows are at hand in the form
+    the GPU returned them (`compact`: rows grouped by class + rows per class).  None otherwise (the numpy statement runs)."""
+    parts, lens, ranges, part_of_image = [], [], [], [0]
+    for i in range(num_images):
+        for all_cls_dets, vr in zip(scale_cls_dets, valid_ranges):
+            ready = getattr(all_cls_dets, 'compact', None)
+            n_chips = len(all_cls_dets[1][i]) if len(all_cls_dets) > 1 else 0
+            for c in range(n_chips):
+                hit = ready.get((i, c)) if ready else None
+                if hit is None or hit[0].dtype != np.float64 or not hit[0].flags['C_CONTIGUOUS'] or len(hit[1]) != nc:
+                    return None
+                parts.append(hit[0])
+                lens.append(hit[1])
+                # `areas > vr * vr` against a float32 array compares in float32 (numpy's weak Python scalars)
+                ranges.append((np.float32(vr[0] * vr[0]) if vr[0] > 0 else np.float32(0), np.float32(vr[1] * vr[1]) if vr[1] > 0 else np.float32(0)))
+        part_of_image.append(len(parts))
+    P = len(parts)
+    sizes = np.zeros(num_images * nc, np.int64)
+    if P == 0:
+        return np.zeros((0, 5), np.float32), sizes
+    lens_a = np.ascontiguousarray(np.stack(lens), np.int64)
+    ptrs = np.fromiter((a.ctypes.data for a in parts), np.uint64, P)
+    cap = int(lens_a.sum())
+    rows, total = np.empty((cap, 5), np.float32), np.zeros(1, np.int64)
+    hip.call('sn_aggregate_problems_host', ptrs, lens_a, np.asarray(part_of_image, np.int32), np.asarray(ranges, np.float32).reshape(-1, 2),
+             P, nc, num_images, rows, cap, sizes, total)
+    return rows[:int(total[0])], sizes
 
 
 class _Detections(list):

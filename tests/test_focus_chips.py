@@ -256,3 +256,39 @@ def test_native_focus_chips_equal_the_python_statement():
         assert got == [[float(v) for v in c] for c in want], (trial, kind, (H, W), d, thr, ms)
         n_chips += len(got)
     assert n_chips > 500
+
+
+def test_native_aggregation_equals_the_numpy_statement():
+    """sn_aggregate_problems_host (one pass over the chips' rows as the GPU returns them) against the numpy statement of the
+    valid-range merge (itself held against the reference's loops above): random row counts incl. empty chips and classes, three
+    scales with 1 / 1 / 1-3 chips per image, open and two-sided valid ranges.  Same rows, same order, same float32 bits."""
+    from sniper_amd.inference import _Detections, _aggregate_stacked_native, aggregate_problems
+    rs = np.random.RandomState(9)
+    NC, n_img = 13, 5
+    nc = NC - 1
+
+    def scale(chips_per_image):
+        d = _Detections([[[None] * chips_per_image[i] for i in range(n_img)] for _ in range(NC)])
+        for i in range(n_img):
+            for c in range(chips_per_image[i]):
+                lens = rs.multinomial(int(rs.randint(0, 400)), np.ones(nc) / nc).astype(np.int64)
+                if rs.rand() < 0.2:
+                    lens[:] = 0
+                n = int(lens.sum())
+                xy, wh = rs.uniform(0, 600, (n, 2)), rs.uniform(1, 300, (n, 2))
+                big = np.hstack((xy, xy + wh, rs.uniform(0.001, 1, (n, 1)))).astype(np.float64)
+                ends = np.cumsum(lens)
+                for j in range(nc):
+                    d[j + 1][i][c] = big[ends[j] - lens[j]:ends[j]]
+                d.compact[(i, c)] = (big, lens)
+        return d
+    scales = [scale([1] * n_img), scale([1] * n_img), scale([1, 2, 3, 0, 2])]
+    for vr in (((-1, -1),) * 3, ((-1, 90), (32, 180), (75, -1)), ((40, -1), (-1, 60), (10, 400))):
+        got = _aggregate_stacked_native(scales, vr, n_img, nc)
+        assert got is not None
+        want_rows, want_sizes = aggregate_problems([list(s) for s in scales], vr, n_img, NC, stacked=True)     # (no `compact`: numpy)
+        assert got[0].dtype == np.float32 and np.array_equal(got[0], want_rows) and np.array_equal(got[1], want_sizes)
+        assert len(want_rows) > 100
+    # a chip without the compact form sends the whole call to the numpy statement
+    del scales[1].compact[(2, 0)]
+    assert _aggregate_stacked_native(scales, ((-1, -1),) * 3, n_img, nc) is None
