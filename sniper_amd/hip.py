@@ -46,6 +46,13 @@ def _conv(a):
 
 
 def call(name, *args):
+    # a numpy array is a HOST pointer: only where the header says so (an entry point named *_host, a parameter named h_*) --
+    # anywhere else it would hand a kernel a host address
+    if any(isinstance(a, np.ndarray) for a in args) and not name.endswith('_host'):
+        names = lib().protos[name][2]
+        for a, pname in zip(args, names):
+            if isinstance(a, np.ndarray) and not pname.startswith('h_'):
+                raise TypeError('%s: parameter %s is a device pointer, got a numpy array' % (name, pname))
     return lib().call(name, *[_conv(a) for a in args])
 
 

@@ -100,3 +100,18 @@ def test_conv_tile_plan_divides_the_baseline_shapes_over_the_cus():
     assert dgrad(20, 32, 32, 256, 256, 3, pad=1) == 128    # data gradient of stage-3 conv2, BatchNorm reduction fused
     assert fwd(20, 128, 128, 64, 256, 1) == 5120           # a single K-step: 64-row tiles (all epilogue)
     assert fwd(20, 128, 128, 64, 64, 1) == 0               # <= 64 output channels: register-staged kernel, no fused statistics
+
+
+def test_numpy_arguments_are_host_pointers_only_where_the_header_says_so():
+    """sniper_amd.hip.call hands a numpy array to the library as a HOST address: allowed for the *_host entry points and for
+    parameters named h_*; a numpy array in a device-pointer slot is a TypeError, not a kernel reading host memory."""
+    import numpy as np
+    from sniper_amd import hip
+    with pytest.raises(TypeError):
+        hip.call('sn_bbox_decode', np.zeros((4, 5), np.float32), None, None, None, 1, 4, None)
+    with pytest.raises(ValueError):            # host arrays must be contiguous
+        hip.call('sn_focus_chips_host', np.zeros((8, 8), np.float32)[:, ::2], 8, 4, 1, 0.5, 1, 64.0, 128.0, 1.0,
+                 np.zeros((4, 4), np.float64), 4, np.zeros(1, np.int32))
+    out, n = np.zeros((4, 4), np.float64), np.zeros(1, np.int32)
+    hip.call('sn_focus_chips_host', np.full((8, 8), 0.9, np.float32), 8, 8, 1, 0.5, 1, 128.0, 128.0, 1.0, out, 4, n)
+    assert n[0] == 1 and out[0].tolist() == [0.0, 0.0, 128.0, 128.0]
