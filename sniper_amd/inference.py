@@ -27,8 +27,10 @@ from .iterators.MNIteratorTestAutoFocus import MNIteratorTestAutoFocus
 from .iterators.PrefetchingIter import PrefetchingIter
 
 
-_PINNED = {}     # (thread, (lane, ping / pong, gpu, output), shape, dtype) -> pinned host tensor of Tester._launch
-_LANE_STREAMS = {}        # thread -> the side streams of Tester's lanes (created once: streams are not free to make)
+_PINNED = {}     # (job slot, (lane, ping / pong, gpu, output), shape, dtype) -> pinned host tensor of Tester._launch
+_LANE_STREAMS = {}        # job slot -> the side streams of Tester's lanes (created once: streams are not free to make)
+_SLOT = threading.local()       # .job: which concurrent job of imdb_detection_wrapper this thread runs (0 outside of it).  Buffers and
+                                # streams are keyed by the SLOT, not the thread: the job threads of every call are new ones
 
 
 class nms_wrapper(object):
@@ -302,7 +304,7 @@ class Tester(object):
         # process-wide and never released: a pinned block returned to torch's host allocator from a garbage-collected Tester
         # makes that allocator query events / free host memory at an arbitrary moment -- inside another executor's hipGraph
         # capture that is an illegal call and the process aborts (seen once, in the -m gpu suite).  One entry per output shape.
-        k = (threading.get_ident(), key, tuple(like.shape), dtype or like.dtype)
+        k = (getattr(_SLOT, 'job', 0), key, tuple(like.shape), dtype or like.dtype)
         t = _PINNED.get(k)
         if t is None:
             t = _PINNED[k] = torch.empty(tuple(like.shape), dtype=dtype or like.dtype, pin_memory=True)
@@ -313,7 +315,7 @@ class Tester(object):
         if len(self.modules) == 1 or not torch.cuda.is_available():
             return None
         if self._lane_streams is None:
-            self._lane_streams = _LANE_STREAMS.setdefault(threading.get_ident(), [])
+            self._lane_streams = _LANE_STREAMS.setdefault(getattr(_SLOT, 'job', 0), [])
             while len(self._lane_streams) < len(self.modules):
                 self._lane_streams.append(torch.cuda.Stream())
         return self._lane_streams[lane]
@@ -613,16 +615,20 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
     detections = []
     for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
         def job(j):
-            cache = None if module_cache is None else module_cache.setdefault(('__job__', j), {})
-            args = [scale, scale_i, nbatch, context, config, sym_def, parts[j], imdb, arg_params, aux_params, vis]
-            if streams is None:
-                return detect_scale_worker(args, cache, lanes)
-            main = torch.cuda.current_stream()
-            streams[j].wait_stream(main)
-            with torch.cuda.stream(streams[j]):
-                out = detect_scale_worker(args, cache, lanes)
-            streams[j].synchronize()
-            return out
+            was, _SLOT.job = getattr(_SLOT, 'job', 0), j
+            try:
+                cache = None if module_cache is None else module_cache.setdefault(('__job__', j), {})
+                args = [scale, scale_i, nbatch, context, config, sym_def, parts[j], imdb, arg_params, aux_params, vis]
+                if streams is None:
+                    return detect_scale_worker(args, cache, lanes)
+                main = torch.cuda.current_stream()
+                streams[j].wait_stream(main)
+                with torch.cuda.stream(streams[j]):
+                    out = detect_scale_worker(args, cache, lanes)
+                streams[j].synchronize()
+                return out
+            finally:
+                _SLOT.job = was
         if len(parts) == 1:
             dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis],
                                              module_cache, lanes)
