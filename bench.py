@@ -141,6 +141,58 @@ class ConvProfiler(object):
         return tot_ms, tot_fl, per
 
 
+def device_identity(index=0):
+    """Which physical card and at what clock: `unique_id` (the card's serial-like id: box-to-box spread of one build is 4-8 %, a
+    reader must be able to tell spread from regression) and the current shader / memory clock levels from sysfs.  Best effort:
+    empty fields where the node does not expose them."""
+    import glob
+    out = {'name': torch.cuda.get_device_name(index), 'unique_id': None, 'sclk_mhz': None, 'mclk_mhz': None}
+    try:
+        want = None
+        try:
+            props = torch.cuda.get_device_properties(index)
+            bus = getattr(props, 'pci_bus_id', None)
+            want = None if bus is None else '%02x:' % int(bus)
+        except Exception:      # noqa: BLE001
+            want = None
+        cards = []
+        for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+            if not os.path.exists(os.path.join(d, 'unique_id')) and not os.path.exists(os.path.join(d, 'pp_dpm_sclk')):
+                continue
+            slot = ''
+            try:
+                with open(os.path.join(d, 'uevent')) as fh:
+                    for ln in fh:
+                        if ln.startswith('PCI_SLOT_NAME='):
+                            slot = ln.strip().split('=', 1)[1]
+            except OSError:
+                pass
+            cards.append((d, slot))
+        pick = [c for c in cards if want and want in c[1]] or cards
+        if pick:
+            d = pick[0][0]
+            out['pci'] = pick[0][1]
+
+            def level(fname):
+                try:
+                    with open(os.path.join(d, fname)) as fh:
+                        for ln in fh:
+                            if '*' in ln:
+                                return int(''.join(ch for ch in ln.split(':', 1)[1] if ch.isdigit()))
+                except (OSError, ValueError, IndexError):
+                    return None
+                return None
+            try:
+                with open(os.path.join(d, 'unique_id')) as fh:
+                    out['unique_id'] = '0x' + fh.read().strip().lower().replace('0x', '')
+            except OSError:
+                pass
+            out['sclk_mhz'], out['mclk_mhz'] = level('pp_dpm_sclk'), level('pp_dpm_mclk')
+    except Exception as e:      # noqa: BLE001 -- identity is a report
+        out['error'] = repr(e)
+    return out
+
+
 def conv_sources_hash():
     """Identity of the convolution kernels a PMC profile was collected on (the GPU box has no .git)."""
     import hashlib
@@ -168,7 +220,7 @@ def library_sources_hash():
 HBM_KERNELS = ('dpsroi_fwd_roi_kernel', 'dpsroi_bwd_data_mfma_kernel', 'dpsroi_bwd_trans_roi_kernel', 'deform_im2col_kernel',
                'deform_col2im_offset_kernel', 'deform_col2im_data_mfma_kernel', 'bn_apply_kernel', 'bn_bwd_dx_kernel',
                'bn_bwd_reduce_kernel', 'nms_lazy_kernel', 'topk_select_sort_kernel', 'anchor_finish_kernel', 'chips_generate_kernel',
-               'sgd_dev_kernel', 'maxpool_kernel')
+               'sgd_dev', 'maxpool_kernel')
 
 
 def roofline_hbm():
@@ -185,15 +237,22 @@ def roofline_hbm():
         return None
     out = []
     for name in HBM_KERNELS:
-        hit = [(k, v) for k, v in d.get('kernels', {}).items() if name in k]
-        for k, v in hit[:1]:
-            # bytes per launch from the counter passes; duration from the un-countered --stats run of the same command when the
-            # report has it (counter collection slows a streaming kernel by ~50 %), else from the counter pass itself
-            gbs = v.get('hbm_gb_per_s_stats', v.get('hbm_gb_per_s'))
-            out.append({'kernel': name, 'launches_profiled': v['launches'], 'avg_us': v.get('avg_us_stats', v['avg_us']),
-                        'duration_from': 'kernel statistics run' if 'avg_us_stats' in v else 'counter pass',
-                        'fetch_mb': round(v['fetch_bytes_per_launch'] / 1e6, 2), 'write_mb': round(v['write_bytes_per_launch'] / 1e6, 2),
-                        'achieved_gb_s': gbs, 'frac_of_8tb_s': round(gbs / HBM_PEAK_GBS, 3) if gbs else None})
+        # every kernel whose name contains `name` (the SGD update is a vec4 body kernel + a scalar head / tail kernel: one row,
+        # launch-weighted), durations from the un-countered --stats run of the same command when the report has them (counter
+        # collection slows a streaming kernel by ~50 %), else from the counter pass itself
+        hit = [v for k, v in d.get('kernels', {}).items() if name in k]
+        if not hit:
+            continue
+        n = sum(v['launches'] for v in hit)
+        from_stats = all('avg_us_stats' in v for v in hit)
+        us = sum(v['launches'] * (v['avg_us_stats'] if from_stats else v['avg_us']) for v in hit)
+        fetch = sum(v['launches'] * v['fetch_bytes_per_launch'] for v in hit)
+        write = sum(v['launches'] * v['write_bytes_per_launch'] for v in hit)
+        gbs = round((fetch + write) / (us * 1e-6) / 1e9, 1) if us > 0 else None
+        out.append({'kernel': name, 'kernels_matched': len(hit), 'launches_profiled': n, 'avg_us': round(us / n, 2),
+                    'duration_from': 'kernel statistics run' if from_stats else 'counter pass',
+                    'fetch_mb': round(fetch / n / 1e6, 2), 'write_mb': round(write / n / 1e6, 2),
+                    'achieved_gb_s': gbs, 'frac_of_8tb_s': round(gbs / HBM_PEAK_GBS, 3) if gbs else None})
     return out or None
 
 
@@ -500,6 +559,7 @@ def main():
     for i in range(args.steps):
         step(i)
     host_dt = time.perf_counter() - t0     # host enqueue time: all launches issued, nothing waited for yet
+    device = device_identity(local % torch.cuda.device_count())      # clocks sampled while the queued steps still run
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -578,8 +638,21 @@ def main():
                                    'assignment and image decode+resize are outside the step); f16 MFMA operands, f32 accumulation / losses / '
                                    'master weights' % args.batch,
                        'chips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+            'device': dict(device, sampled='sysfs levels read after the timed steps were enqueued, before the closing synchronise '
+                                           '(the device is still executing them)'),
+            'library_sources_hash': library_sources_hash(),
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        # the committed rocprofv3 --kernel-trace --stats cross-check of this same command ON THIS BUILD (tools/roofline_check.py,
+        # same session as a bench line of that card): lets a reader tell card-to-card spread from a regression
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'roofline_check.json')) as fh:
+                rc = json.load(fh)
+            if rc.get('library_sources_hash') == out['library_sources_hash']:
+                roof['rocprof_cross_check'] = {k: rc.get(k) for k in ('frac_rocprof', 'tflops_rocprof', 'bench_frac', 'ratio_bench_over_rocprof',
+                                                                       'conv_family_ms_per_step_rocprof', 'device')}
+        except (OSError, ValueError):
+            pass
         if not args.no_inference and world == 1:
             out['inference'] = bench_inference()
         print(json.dumps(out), flush=True)

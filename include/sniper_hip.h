@@ -4,8 +4,12 @@
  *
  * Conventions ("Inner boundary"):
  *   - every pointer named d_* / documented "device" is a HIP device pointer owned by the caller;
- *   - no allocation, no synchronisation and no global state inside any call: kernels are enqueued on
- *     `stream` (a hipStream_t passed as void*; NULL = default stream) and the call returns;
+ *   - no allocation and no synchronisation inside any call: kernels are enqueued on `stream` (a hipStream_t passed
+ *     as void*; NULL = default stream) and the call returns; the calls are re-entrant per stream and per device;
+ *   - process-wide state is limited to the explicit test / tuning hooks sn_debug_option, sn_conv_tune,
+ *     sn_conv_wgrad_impl, sn_conv_trace and sn_conv_wgrad_trace (atomics, defaults = production behaviour; their
+ *     environment-variable spellings are read ONCE at load time) -- no hot call reads the environment or mutates a
+ *     global; the per-device "large LDS" opt-in of two kernels is applied once per (kernel, device) under a mutex;
  *   - scratch memory comes from the caller: sn_*_workspace_bytes() tells how much;
  *   - return value: 0 = ok, SN_ERR_* otherwise (argument errors are detected before any launch).
  * The only native ABI the reference itself defines is
@@ -31,6 +35,10 @@ enum { SN_OK = 0, SN_ERR_ARG = 1, SN_ERR_HIP = 2, SN_ERR_WORKSPACE = 3, SN_ERR_U
 /* Library / device sanity. */
 int sn_version(void);
 const char *sn_last_error(void); /* thread-local text of the last failure */
+/* Test / A-B switch (process-wide, atomic; no reference counterpart): "proposal_full_sort" = 1 orders the proposals with the
+ * general global-memory bitonic sort instead of radix select + LDS sort, "nms_full_mask" = 1 runs the full bitmask + scan
+ * instead of the lazy kernel.  Results are identical either way (that is what the tests use it for). */
+int sn_debug_option(const char *name, int value);
 
 /* ------------------------------------------------------------------ box geometry ------------- */
 /* bbox_overlaps_cython / ignore_overlaps_cython (lib/bbox/bbox.pyx:17-57, 59-95).
@@ -112,12 +120,15 @@ int sn_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_
                 float nms_overlap_thresh, int device_id);
 
 /* Soft-NMS (cpu_soft_nms, lib/nms/cpu_nms.pyx:17-110; method 1 linear, 2 gaussian, else hard) for P independent
- * problems: d_boxes (total,5) f32 [x1,y1,x2,y2,score], problem p owns rows [d_off[p], d_off[p+1]) (at most
- * sn_soft_nms_max_boxes() each, max_n = the largest).  In place, like the reference: on return rows
- * [d_off[p], d_off[p] + d_count[p]) are the surviving boxes in the reference's order with their decayed scores. */
+ * problems: d_boxes (total_rows,5) f32 [x1,y1,x2,y2,score], problem p owns rows [d_off[p], d_off[p+1]), max_n = the
+ * largest problem.  No size cap, like the reference: problems of at most sn_soft_nms_max_boxes() boxes run out of one
+ * workgroup's LDS; larger ones run the same phases in global memory and need d_ws =
+ * sn_soft_nms_workspace_bytes(total_rows) of scratch (NULL is accepted when max_n fits).  In place, like the reference: on
+ * return rows [d_off[p], d_off[p] + d_count[p]) are the surviving boxes in the reference's order with their decayed scores. */
 size_t sn_soft_nms_max_boxes(void);
-int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, float sigma, float Nt, float threshold, int method,
-                      int32_t *d_count, sn_stream_t stream);
+size_t sn_soft_nms_workspace_bytes(size_t total_rows);
+int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, size_t total_rows, float sigma, float Nt,
+                      float threshold, int method, void *d_ws, int32_t *d_count, sn_stream_t stream);
 
 /* ------------------------------------------------------------------ test-time host loops ----- */
 /* im_worker.worker / worker_autofocus after the decode (lib/data_utils/data_workers.py:49-121): d_src_bgr (H,W,3) u8,
@@ -230,6 +241,9 @@ int sn_conv_wgrad_batch(const sn_wgrad_desc *descs, int n, void *ws, size_t ws_b
 int sn_conv_wgrad_impl(int impl, int job_steps);
 /* diagnostics (tools/wgrad_batch_bench.py --trace): per-job phase cycles [jobs][8] x uint64 into buf; NULL = off */
 int sn_conv_wgrad_trace(void *buf);
+/* diagnostics (tools/conv_trace.py): per-workgroup phase cycles [grid][8] x uint64 of the LDS-DMA forward / data-gradient
+ * launches that follow into buf; NULL = off (default) */
+int sn_conv_trace(void *buf);
 /* bias gradient: db[c] += sum_rows dy[r][c].  Row blocks leave partial sums in `ws` (sn_bias_grad_workspace_bytes) and are added in
  * block order -- deterministic, no atomics; without scratch one block per 64 channels walks all rows. */
 size_t sn_bias_grad_workspace_bytes(long rows, int C);

@@ -23,6 +23,8 @@
 //
 // The weight gradient needs both operands transposed (the contraction index is the pixel, which is
 // the slow dimension of both dY and X); see conv_wgrad_kernel below.
+#include <atomic>
+
 #include "conv_common.h"
 
 #include <stdlib.h>
@@ -185,10 +187,10 @@ static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
-static int g_conv_cfg = env_int("SNIPER_CONV_CFG", -1);   // whole-program A/B (tools/conv_ab.sh) without code changes
+static std::atomic<int> g_conv_cfg{env_int("SNIPER_CONV_CFG", -1)};   // whole-program A/B (tools/conv_ab.sh) without code changes
 SN_EXPORT int sn_conv_tune(int cfg) {
   SN_REQUIRE(cfg == -1 || cfg == 0 || conv_dma_config(cfg).bm > 0, "sn_conv_tune: no configuration %d", cfg);
-  g_conv_cfg = cfg;
+  g_conv_cfg.store(cfg, std::memory_order_relaxed);
   return SN_OK;
 }
 
@@ -224,7 +226,8 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {
   if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul) {
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
-    const int cfg = g_conv_cfg >= 0 ? g_conv_cfg : conv_dma_choice(p.M, p.Nout, p.KH * p.KW * (p.Cin / 64), dgrad);
+    const int forced = g_conv_cfg.load(std::memory_order_relaxed);
+    const int cfg = forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, p.KH * p.KW * (p.Cin / 64), dgrad);
     if (cfg > 0) {
       const ConvDmaConfig c = conv_dma_config(cfg);
       q.dma = cfg;
@@ -563,14 +566,20 @@ static int wgrad_legacy(const void *dy, const void *x, float *dw, int N, int H, 
 }
 
 // ---- entry points: one layer, or a table of layers in one launch (conv_wgrad_ps.hip) ----
-static int g_wgrad_na = 0;     // 0 = by layer width (Cout > 128: 256 x 128 tiles), 1 / 2 = forced (sn_conv_wgrad_impl's job_steps >= 100000)
-static int g_wgrad_impl = 1;   // 1 = wave-specialised batched kernel, 0 = the gather kernel (sn_conv_wgrad_impl: tests, A/B)
+static std::atomic<int> g_wgrad_na{0};     // 0 = by layer width (Cout > 128: 256 x 128 tiles), 1 / 2 = forced (sn_conv_wgrad_impl's job_steps >= 100000)
+static std::atomic<int> g_wgrad_impl{1};   // 1 = wave-specialised batched kernel, 0 = the gather kernel (sn_conv_wgrad_impl: tests, A/B)
 SN_EXPORT int sn_conv_wgrad_impl(int impl, int job_steps) {
   SN_REQUIRE((impl == 0 || impl == 1) && job_steps >= 0, "sn_conv_wgrad_impl: impl in {0, 1}, job_steps >= 0");
-  g_wgrad_impl = impl;
-  g_wgrad_na = job_steps / 100000;                 // tuning only: 100000 / 200000 + steps forces 128- / 256-row tiles for every layer
-  SN_REQUIRE(g_wgrad_na >= 0 && g_wgrad_na <= 2, "sn_conv_wgrad_impl: bad tile selector");
+  SN_REQUIRE(job_steps / 100000 <= 2, "sn_conv_wgrad_impl: bad tile selector");
+  g_wgrad_impl.store(impl, std::memory_order_relaxed);
+  g_wgrad_na.store(job_steps / 100000, std::memory_order_relaxed);   // tuning only: 100000 / 200000 + steps forces 128- / 256-row tiles
   wgrad_ps_set_job_steps(job_steps % 100000);
+  return SN_OK;
+}
+
+// diagnostics: phase timeline of the LDS-DMA forward / data-gradient workgroups into buf (tools/conv_trace.py); NULL = off
+SN_EXPORT int sn_conv_trace(void *buf) {
+  conv_dma_set_trace(static_cast<unsigned long long *>(buf));
   return SN_OK;
 }
 
@@ -628,8 +637,9 @@ static int wgrad_batch_run(const sn_wgrad_desc *descs, int n, void *ws, size_t w
       const sn_wgrad_desc &d = descs[i];
       WgradParams p;
       wgrad_desc_params(d, p);
-      if (!(g_wgrad_impl == 1 && wgrad_ps_ok(p))) continue;
-      const int want = g_wgrad_na ? g_wgrad_na : (p.Cout > 128 ? 2 : 1);
+      if (!(g_wgrad_impl.load(std::memory_order_relaxed) == 1 && wgrad_ps_ok(p))) continue;
+      const int na_forced = g_wgrad_na.load(std::memory_order_relaxed);
+      const int want = na_forced ? na_forced : (p.Cout > 128 ? 2 : 1);
       if (want != pass) continue;
       const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
       const long steps = flat ? sn_div_up(sn_div_up(p.N * p.H * p.W, 32), 2) : sn_div_up(p.N * p.Ho * sn_div_up(p.Wo, 32), 2);
@@ -651,7 +661,7 @@ static int wgrad_batch_run(const sn_wgrad_desc *descs, int n, void *ws, size_t w
     const sn_wgrad_desc &d = descs[i];
     WgradParams p;
     wgrad_desc_params(d, p);
-    if (g_wgrad_impl == 1 && wgrad_ps_ok(p)) continue;
+    if (g_wgrad_impl.load(std::memory_order_relaxed) == 1 && wgrad_ps_ok(p)) continue;
     const size_t bytes = wgrad_legacy_workspace_bytes(d.N, d.H, d.W, d.Cin, d.x_pix_stride, d.Cout, d.dy_pix_stride, d.KH, d.KW, d.stride, d.pad, d.dil);
     if (launch) {
       char *base = ws ? static_cast<char *>(ws) + off : nullptr;

@@ -1,6 +1,7 @@
 // conv_common.h -- types shared by the convolution translation units (conv.hip: register-staged kernels, weight gradient,
 // C-ABI entry points; conv_dma.hip: LDS-DMA pipelined implicit GEMM).  Internal, not part of the C ABI.
 #pragma once
+#include <atomic>
 #include "common.h"
 
 typedef _Float16 half_t;
@@ -38,6 +39,7 @@ struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };
 constexpr int kConvDmaConfigs = 18;    // highest configuration number (the table has holes: conv_dma_config(c).bm == 0)
 ConvDmaConfig conv_dma_config(int cfg);
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
+void conv_dma_set_trace(unsigned long long *buf);
 
 // ---- weight gradient (conv.hip: gather kernel for unaligned operands and the packed stem; conv_wgrad_ps.hip: everything else)
 struct WgradParams {

@@ -598,17 +598,16 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
   return SN_OK;
 }
 
+// diagnostics: phase timeline of the next launches' workgroups into buf (>= 8 x grid 64-bit words; tools/conv_trace.py), NULL = off
+static std::atomic<unsigned long long *> g_conv_trace{nullptr};
+void conv_dma_set_trace(unsigned long long *buf) { g_conv_trace.store(buf, std::memory_order_relaxed); }
+
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s) {
-  // SNIPER_CONV_TRACE=1 at load time arms the timeline probe; SNIPER_CONV_TRACE_PTR (hex device address of >= 8 x grid
-  // 64-bit words, set by tools/conv_trace.py around one launch) is read per launch
-  static const bool armed = getenv("SNIPER_CONV_TRACE") != nullptr;
-  if (armed) {
-    const char *e = getenv("SNIPER_CONV_TRACE_PTR");
-    if (e && *e) {
-      ConvParams q = p;
-      q.trace = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 16));
-      return dgrad ? launch_cfg<true>(q, cfg, s) : launch_cfg<false>(q, cfg, s);
-    }
+  unsigned long long *trace = g_conv_trace.load(std::memory_order_relaxed);
+  if (trace) {
+    ConvParams q = p;
+    q.trace = trace;
+    return dgrad ? launch_cfg<true>(q, cfg, s) : launch_cfg<false>(q, cfg, s);
   }
   return dgrad ? launch_cfg<true>(p, cfg, s) : launch_cfg<false>(p, cfg, s);
 }

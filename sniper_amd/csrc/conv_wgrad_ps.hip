@@ -364,10 +364,10 @@ bool wgrad_ps_ok(const WgradParams &p) {
          (size_t)p.Cout * p.KH * p.KW * p.Cin < (1ull << 31);
 }
 
-static unsigned long long *g_wgrad_trace = nullptr;   // phase timeline buffer [jobs][8] (tools/wgrad_batch_bench.py --trace), normally null
-void wgrad_ps_set_trace(unsigned long long *buf) { g_wgrad_trace = buf; }
-static int g_wgrad_job_steps = 0;   // tuning override of the longest job (K-steps); 0 = built-in
-void wgrad_ps_set_job_steps(int steps) { g_wgrad_job_steps = steps; }
+static std::atomic<unsigned long long *> g_wgrad_trace{nullptr};   // phase timeline buffer [jobs][8] (tools/wgrad_batch_bench.py --trace), normally null
+void wgrad_ps_set_trace(unsigned long long *buf) { g_wgrad_trace.store(buf, std::memory_order_relaxed); }
+static std::atomic<int> g_wgrad_job_steps{0};   // tuning override of the longest job (K-steps); 0 = built-in
+void wgrad_ps_set_job_steps(int steps) { g_wgrad_job_steps.store(steps, std::memory_order_relaxed); }
 
 // Fill tab (geometry, splits, item ranges) from n problems; slab pointers are offsets into `ws` (nullptr = size query).
 // Returns the scratch bytes the split problems need.
@@ -393,7 +393,7 @@ size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bo
   // rounds(cap) * cap with rounds = ceil(jobs(cap) / 256): dividing the longest problem's K by s = 1, 2, ... the cheapest s wins
   // (126 whole-K jobs of 320 steps: s = 2 -> 252 jobs of 160, one round; s = 3 -> 378 jobs of 107, TWO rounds = 214).  A split
   // costs its slabs and a reduce launch (weighted 5 %), jobs under 16 steps are all fill and drain.
-  long cap = g_wgrad_job_steps;
+  long cap = g_wgrad_job_steps.load(std::memory_order_relaxed);
   if (cap <= 0) {
     long longest = 1;
     for (int i = 0; i < n; ++i) { const long st = sn_div_up(tab.p[i].nunits, 2); longest = st > longest ? st : longest; }
@@ -452,7 +452,7 @@ size_t wgrad_ps_plan(const WgradParams *ps, int n, WgradBatch &tab, void *ws, bo
     for (x = 0; x < 8; ++x) longest = tab.xcd_start[x + 1] - tab.xcd_start[x] > longest ? tab.xcd_start[x + 1] - tab.xcd_start[x] : longest;
     tab.per_xcd = longest;
   }
-  tab.trace = g_wgrad_trace;
+  tab.trace = g_wgrad_trace.load(std::memory_order_relaxed);
   return off;
 }
 

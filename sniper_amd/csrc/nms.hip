@@ -222,7 +222,7 @@ SN_EXPORT int sn_nms_batch(const float *d_boxes, const int32_t *d_n, int B, int 
     return SN_OK;
   }
   SN_REQUIRE(d_boxes && d_keep, "sn_nms_batch: null pointer");
-  if (max_keep <= kLazyMaxKeep && max_keep * 4 <= N && !getenv("SNIPER_NMS_FULL")) {
+  if (max_keep <= kLazyMaxKeep && max_keep * 4 <= N && !sn_debug_get(SN_OPT_NMS_FULL_MASK)) {
     hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(256), 0, s, d_boxes, d_n, N, dim, thresh, max_keep, d_keep, d_nkeep);
     SN_CHECK_LAUNCH();
     return SN_OK;
@@ -291,26 +291,20 @@ SN_EXPORT int sn_nms_host(int *keep_out, int *num_out, const float *boxes_host, 
 //   3. the removals: "overwrite the dead box with the last one, shrink, re-examine" fills the dead slots below the
 //      new N in INCREASING position order with the surviving tail boxes in DECREASING position order -> ranks from
 //      a block-wide prefix sum of the keep flags, one parallel move.
-// LDS: 25 bytes per box (array + flags + tail list): n <= 4096 per problem.
+// LDS: 25 bytes per box (array + flags + tail list): problems of n <= 4096 boxes run out of LDS; larger ones (the reference has
+// no cap) run the same phases on their rows in global memory with the flags / tail list in a caller-provided workspace.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSoftThreads = 256;
+constexpr int kSoftLdsBoxes = 4096;
 
-__global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(float *__restrict__ boxes, const int32_t *__restrict__ off,
-                                                                float sigma, float Nt, float threshold, int method,
-                                                                int32_t *__restrict__ count, int max_n) {
-  extern __shared__ __attribute__((aligned(16))) float soft_smem[];
-  float *bx = soft_smem;                                           // [max_n][5]
-  int *tail = reinterpret_cast<int *>(bx + (size_t)max_n * 5);     // [max_n]
-  unsigned char *keepf = reinterpret_cast<unsigned char *>(tail + max_n);   // [max_n]
-  __shared__ float r_score[kSoftThreads];
-  __shared__ int r_pos[kSoftThreads];
-  __shared__ int cnt[kSoftThreads + 1];
-  const int p = blockIdx.x, t = threadIdx.x;
-  const int base = off[p];
-  int N = off[p + 1] - base;
-  float *g = boxes + (size_t)base * 5;
-  for (int k = t; k < N * 5; k += kSoftThreads) bx[k] = g[k];
-  __syncthreads();
+// One problem.  IN_LDS: `bx` / `tail` / `keepf` are the workgroup's LDS image of the problem (copied in and out by the caller);
+// otherwise they are global memory -- the problem's own rows, updated in place, and its slice of the caller's workspace -- for
+// problems beyond the LDS capacity.  Same phases, same arithmetic: a workgroup barrier orders the workgroup's global accesses too.
+template <bool IN_LDS>
+__device__ __forceinline__ int soft_nms_problem(float *__restrict__ bx, int *__restrict__ tail, unsigned char *__restrict__ keepf,
+                                                int N, float sigma, float Nt, float threshold, int method, float *r_score,
+                                                int *r_pos, int *cnt) {
+  const int t = threadIdx.x;
   for (int i = 0; i < N; ++i) {
     // ---- 1. arg-max over [i, N), smallest position among equals
     const int len = N - i, per = (len + kSoftThreads - 1) / kSoftThreads;
@@ -411,25 +405,53 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(float *__restric
       N = Nn;
     }
   }
-  for (int k = t; k < N * 5; k += kSoftThreads) g[k] = bx[k];
+  return N;
+}
+
+__global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(float *__restrict__ boxes, const int32_t *__restrict__ off,
+                                                                float sigma, float Nt, float threshold, int method,
+                                                                int32_t *__restrict__ count, int lds_n, unsigned char *__restrict__ ws,
+                                                                long long total_rows) {
+  extern __shared__ __attribute__((aligned(16))) float soft_smem[];
+  __shared__ float r_score[kSoftThreads];
+  __shared__ int r_pos[kSoftThreads];
+  __shared__ int cnt[kSoftThreads + 1];
+  const int p = blockIdx.x, t = threadIdx.x;
+  const int base = off[p];
+  int N = off[p + 1] - base;
+  float *g = boxes + (size_t)base * 5;
+  if (N <= lds_n) {
+    float *bx = soft_smem;                                           // [lds_n][5]
+    int *tail = reinterpret_cast<int *>(bx + (size_t)lds_n * 5);     // [lds_n]
+    unsigned char *keepf = reinterpret_cast<unsigned char *>(tail + lds_n);   // [lds_n]
+    for (int k = t; k < N * 5; k += kSoftThreads) bx[k] = g[k];
+    __syncthreads();
+    N = soft_nms_problem<true>(bx, tail, keepf, N, sigma, Nt, threshold, method, r_score, r_pos, cnt);
+    for (int k = t; k < N * 5; k += kSoftThreads) g[k] = bx[k];
+  } else {
+    // (the host wrapper refuses such a problem without a workspace)
+    int *tail = reinterpret_cast<int *>(ws) + base;
+    unsigned char *keepf = ws + (size_t)total_rows * sizeof(int) + base;
+    N = soft_nms_problem<false>(g, tail, keepf, N, sigma, Nt, threshold, method, r_score, r_pos, cnt);
+  }
   if (t == 0) count[p] = N;
 }
 
-SN_EXPORT size_t sn_soft_nms_max_boxes(void) { return 4096; }
+SN_EXPORT size_t sn_soft_nms_max_boxes(void) { return kSoftLdsBoxes; }
 
-SN_EXPORT int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, float sigma, float Nt, float threshold,
-                                int method, int32_t *d_count, sn_stream_t stream) {
+SN_EXPORT size_t sn_soft_nms_workspace_bytes(size_t total_rows) { return (total_rows * 5 + 15) / 16 * 16; }
+
+SN_EXPORT int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, size_t total_rows, float sigma, float Nt,
+                                float threshold, int method, void *d_ws, int32_t *d_count, sn_stream_t stream) {
   SN_REQUIRE(d_boxes && d_off && d_count && P > 0 && max_n > 0, "sn_soft_nms_batch: bad arguments");
-  SN_REQUIRE(max_n <= 4096, "sn_soft_nms_batch: at most 4096 boxes per problem (got %d)", max_n);
-  const int mn = (max_n + 3) / 4 * 4;
+  SN_REQUIRE(max_n <= kSoftLdsBoxes || d_ws,
+             "sn_soft_nms_batch: a problem of %d boxes (more than the %d one workgroup holds in LDS) needs "
+             "sn_soft_nms_workspace_bytes(total_rows) of scratch", max_n, kSoftLdsBoxes);
+  const int mn = (std::min(max_n, kSoftLdsBoxes) + 3) / 4 * 4;
   const size_t smem = (size_t)mn * 5 * sizeof(float) + (size_t)mn * sizeof(int) + (size_t)mn;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(soft_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
-    attr_set = true;
-  }
+  SN_HIP(sn_once_per_device_max_lds(reinterpret_cast<const void *>(soft_nms_kernel), 110 * 1024));
   hipLaunchKernelGGL(soft_nms_kernel, dim3(P), dim3(kSoftThreads), smem, sn_stream(stream), d_boxes, d_off, sigma, Nt, threshold,
-                     method, d_count, mn);
+                     method, d_count, mn, static_cast<unsigned char *>(d_ws), (long long)total_rows);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -294,13 +294,9 @@ static int proposal_common(const float *cls_prob, const float *bbox_pred, const 
                      base_anchors, A, Fh, Fw, stride, min_size, L.total, L.sort_n, boxes_all, keys);
   SN_CHECK_LAUNCH();
   const int P2 = next_pow2(L.pre);
-  if (P2 <= 16384 && L.pre < L.sort_n && !getenv("SNIPER_FULL_SORT")) {
-    static bool attr_done = false;       // > 64 KB of dynamic LDS needs the opt-in once per process
-    if (!attr_done) {
-      SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 16384 * 8));
-      attr_done = true;
-    }
+  if (P2 <= 16384 && L.pre < L.sort_n && !sn_debug_get(SN_OPT_PROPOSAL_FULL_SORT)) {
+    // > 64 KB of dynamic LDS needs the opt-in once per (kernel, device)
+    SN_HIP(sn_once_per_device_max_lds(reinterpret_cast<const void *>(topk_select_sort_kernel), 16384 * 8));
     hipLaunchKernelGGL(topk_select_sort_kernel, dim3(B), dim3(kSelThreads), (size_t)P2 * 8, s, keys, L.sort_n, L.pre, P2);
   } else {
     hipLaunchKernelGGL(bitonic_sort_kernel, dim3(B), dim3(1024), 0, s, keys, L.sort_n);

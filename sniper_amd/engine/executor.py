@@ -255,6 +255,10 @@ class Executor(object):
 
     def queue_wgrad(self, *problem):
         """problem = the arguments of sn_conv_wgrad up to `dil` (tensors dy, x, dw first)."""
+        # two layers sharing one weight tensor must not sit in one table: unsplit jobs do a plain `dw += tile`, so the two
+        # problems' tiles would race on that gradient (the reference's symbols share no weights; a custom graph may)
+        if any(q[2].data_ptr() == problem[2].data_ptr() for q in self._pending_wgrads):
+            self.flush_wgrads()
         self._pending_wgrads.append(problem)
         for t in problem[:2]:
             self._pending_reads.add(t.untyped_storage().data_ptr())

@@ -5,8 +5,9 @@ size; MXNet's executor group then splits each batch over the GPUs of the one pro
 the same script, so every rank's iterator would crop, resize and anchor-label all W * B chips of a batch and the Module would keep
 1 / W of them.  `patch_iterator_class` wraps `get_batch` of the iterator class: rank r assembles the chips
 [cur_i + r * B, cur_i + (r + 1) * B) of every global batch and the cursor advances by the global batch, so the ranks' slices are
-disjoint, together they are exactly the batch the unsliced iterator would have built, and `len(iter)`, the epoch length and the
-learning-rate schedule stay those of the global batch.  (All ranks must hold the same chip database: `Module._sync_epoch` seeds
+disjoint, together they are exactly the batch the unsliced iterator would have built (including the per-image chip cursor
+`crop_idx`, which every rank advances for the WHOLE global batch), and `len(iter)`, the epoch length and the learning-rate schedule
+stay those of the global batch.  (All ranks must hold the same chip database: `Module._sync_epoch` seeds
 numpy from rank 0 and resets the iterator at every epoch.)  `install_import_hook` applies the wrapper to the reference's own class
 the moment `iterators.MNIteratorE2E` is imported -- the file itself is untouched."""
 import importlib.abc
@@ -44,6 +45,15 @@ def patch_iterator_class(cls):
             self.batch = self._get_batch()
         finally:
             self.batch_size, self.cur_i = gb, base + gb
+        # Per-image chip cursor (MNIteratorE2E.py:118-129): `_get_batch` picks chip `chip_order[crop_idx[image] % n]` for every
+        # entry of the batch from the cursor values AT THE START of the batch and then advances the cursor of every entry's
+        # image.  The sliced call advanced it for this rank's entries only; the entries the other ranks assembled advance it
+        # here, so that every rank's cursors equal the unsliced iterator's after each global batch -- otherwise an image whose
+        # chips fall into two ranks' slices would train its first chip twice and the next one never.
+        crop_idx, inds = getattr(self, 'crop_idx', None), getattr(self, 'inds', None)
+        if crop_idx is not None and inds is not None:
+            for i in list(range(base, base + rank * lb)) + list(range(base + (rank + 1) * lb, base + gb)):
+                crop_idx[inds[i]] = crop_idx[inds[i]] + 1
         self.rank_sliced = True            # Module.fit reads this: the batches are rank-local already
         return True
     cls.get_batch = get_batch

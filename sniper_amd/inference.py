@@ -52,16 +52,12 @@ class nms_wrapper(object):
                 keep = _gpu_nms.gpu_nms(d, self.thresh) if d.shape[0] else []
                 out.append(d[keep, :] if len(keep) else np.zeros((0, 5), np.float32))
             return out
-        cap = int(hip.query('sn_soft_nms_max_boxes'))
-        big = [i for i, d in enumerate(problems) if d.shape[0] > cap]
-        for i in big:       # keep the best-scoring `cap` boxes of an oversized problem (the rest could only lose score)
-            problems[i] = problems[i][np.argsort(-problems[i][:, 4], kind='stable')[:cap]]
         return _cpu_nms.soft_nms_batch(problems, sigma=self.sigma, Nt=0.3, threshold=0.001, method=2)
 
 
     def process_stacked(self, rows, sizes):
         """process_many for problems given as one (total, 5) float32 array + rows per problem."""
-        if self.thresh <= 0 and (len(sizes) == 0 or int(np.max(sizes)) <= int(hip.query('sn_soft_nms_max_boxes'))):
+        if self.thresh <= 0:
             return _cpu_nms.soft_nms_stacked(rows, sizes, sigma=self.sigma, Nt=0.3, threshold=0.001, method=2)
         return self.process_many(_split_rows(rows, sizes))
 
@@ -565,8 +561,12 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1):
                                         pad_rois_to=400, crop_size=None, test_scale=scale)
     n_batches = max(1, test_iter.size // max(1, nGPUs * nbatch))
     lanes = max(1, min(int(lanes), n_batches))
-    mods = module_cache.get((tuple(scale), nbatch)) if module_cache is not None else None
-    mods = list(mods) if isinstance(mods, (list, tuple)) else ([mods] if mods is not None else [])
+    # module_cache[(scale, nbatch)] stays ONE Module (what a caller reading the cache expects); further lanes live under
+    # their own key
+    mods = []
+    if module_cache is not None:
+        first = module_cache.get((tuple(scale), nbatch))
+        mods = ([first] if first is not None else []) + list(module_cache.get(('__lanes__', tuple(scale), nbatch), []))
     while len(mods) < lanes:
         sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
         sym = sym_inst.get_symbol_rcnn(config, is_train=False)
@@ -579,14 +579,15 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1):
             mod.init_params(arg_params=arg_params, aux_params=aux_params, allow_missing=arg_params is None)
         mods.append(mod)
     if module_cache is not None:
-        module_cache[(tuple(scale), nbatch)] = mods
+        module_cache[(tuple(scale), nbatch)] = mods[0]
+        module_cache[('__lanes__', tuple(scale), nbatch)] = mods[1:]
     tester = Tester(mods[:lanes], imdb, roidb, test_iter, cfg=config, batch_size=nbatch)
     return tester.get_detections(vis=False, evaluate=False, cache_name='dets_scale_{}x{}'.format(scale[0], scale[1]),
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
 def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
-                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=3):
+                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=1):
     """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
     AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips); detections of all scales
     are aggregated under TEST.VALID_RANGES with per-class NMS.
@@ -595,7 +596,9 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
     Module and its own HIP stream on this process's GPU (a batch of two FocusChips at the finest scale leaves most of the 256
     CUs idle; two streams fill them).  Results are merged in part order, as the reference does (:494-500).
     lanes: batches of one scale in flight at once, each on its own bound Module and HIP stream, driven by ONE host thread
-    (detect_scale_worker / Tester.get_detections) -- the form of concurrency that measured faster here than threads.
+    (detect_scale_worker / Tester.get_detections) -- the form of concurrency that measured faster here than threads.  Every
+    lane is a full bound Module (its own activations at every scale, 1400 x 2000 included), so the default is 1; a throughput
+    run on a 288 GB card asks for 3 (bench.py, tools/infer_profile.py).
     focus_map_fn(scale_i, image, chip, net_map) -> map (benchmarks only): replaces the network's FocusPixel map before the
     FocusChips are cut -- a random-init network's maps select whole images, a trained one's ~10 % of the pixels in blobs
     (SURVEY 8(d)); return_scale_dets: also hand back the per-scale detections (what the CPU baseline of the aggregation reads)."""

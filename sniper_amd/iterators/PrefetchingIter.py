@@ -65,12 +65,22 @@ class PrefetchingIter(mx.io.DataIter):
                         self._queue.append((batch, error))
                         self._exhausted = batch is None
                     self._cv.notify_all()
-        self.prefetch_thread = threading.Thread(target=prefetch_func, daemon=True)
+        self._prefetch_func = prefetch_func
+        self._start()
+
+    def _start(self):
+        self.started = True
+        self.prefetch_thread = threading.Thread(target=self._prefetch_func, daemon=True)
         self.prefetch_thread.start()
 
     def close(self):
-        """End the worker thread (it otherwise waits for a reset() for as long as the process lives)."""
+        """End the worker thread (it otherwise waits for a reset() for as long as the process lives).  Not final: reset()
+        starts a new worker, so an iterator a Tester closed after one scale serves the next `set_scale` (demo.py reuses one
+        Tester across scales)."""
         self.__del__()
+        t = getattr(self, 'prefetch_thread', None)
+        if t is not None and t is not threading.current_thread():
+            t.join(timeout=30)
 
     def __del__(self):
         self.started = False
@@ -119,6 +129,8 @@ class PrefetchingIter(mx.io.DataIter):
             self.iters[0].reset()
             self._exhausted = False
             self._cv.notify_all()
+        if not self.started or not self.prefetch_thread.is_alive():          # closed earlier: a fresh worker for the new epoch
+            self._start()
 
     def iter_next(self):
         with self._cv:

@@ -56,3 +56,37 @@ def anchor_case(k):
 
 def ref_cfg():
     return cfgmod.res101_e2e()
+
+
+# ---- large soft-NMS problems (tests/golden/nms_big_v1.npz, made by tests/golden/make_nms_big_golden.py) ---------------------
+# The inputs are regenerated from a seed (numpy's legacy RandomState stream is frozen); the fixture holds the reference's
+# output compactly: for every surviving row the index of the input row it is a copy of + its decayed float32 score.
+NMS_BIG_CASES = [   # (n, method, threshold, score quantisation or None, seed)
+    (4097, 2, 0.001, None, 501),      # one box beyond the LDS capacity of a workgroup
+    (6000, 2, 0.001, 40, 502),        # quantised scores: ties broken by position; exact duplicates
+    (6000, 1, 0.05, None, 503),       # linear method, many removals ("overwrite with the last box")
+    (12000, 2, 0.001, None, 504),
+]
+
+
+def nms_big_problem(n, quant, seed):
+    """n detection-like boxes: overlapping clusters inside a 2000 x 1400 image, scores in (0, 1]."""
+    rs = np.random.RandomState(seed)
+    k = max(1, n // 40)
+    centres = np.stack((rs.uniform(40, 1960, k), rs.uniform(40, 1360, k)), 1)
+    which = rs.randint(0, k, n)
+    c = centres[which] + rs.normal(0, 12, (n, 2))
+    wh = np.exp(rs.normal(np.log(70), 0.4, (n, 2)))
+    s = rs.uniform(0.002, 1.0, (n, 1))
+    if quant:
+        s = np.ceil(s * quant) / quant
+    d = np.hstack((c - wh / 2, c + wh / 2, s)).astype(np.float32)
+    if quant:
+        d[1:40:3, :4] = d[0, :4]          # exact duplicates: IoU 1
+    return d
+
+
+def nms_big_expected(z, i, d):
+    """Rebuild the reference's output rows of case i from the fixture and the regenerated input d."""
+    idx, sc = z['idx_%d' % i], z['score_%d' % i]
+    return np.concatenate((d[idx, :4], sc[:, None]), 1).astype(np.float32)

@@ -145,6 +145,83 @@ def test_two_rank_gradient_exchange_gloo():
     assert dict(out) == {0: 127, 1: 127}, dict(out)
 
 
+def test_rank_sliced_iterator_walks_the_chips_of_the_unsliced_one(monkeypatch):
+    """An iterator with MNIteratorE2E's per-image chip cursor (lib/iterators/MNIteratorE2E.py:118-129: chip
+    `chip_order[crop_idx[image] % n]` for every entry, cursors read at the start of the batch and advanced for every entry):
+    images occur several times per epoch (one entry per chip), so the chips of one image land in different ranks' slices.
+    The ranks' slices together must be exactly the (image, chip) sequence of the unsliced iterator, over two epochs, and every
+    rank's cursors must end equal to the unsliced iterator's (each rank used to advance only its own entries)."""
+    from sniper_amd.ext import rank_slice
+
+    class ChipCursorIter(object):
+        def __init__(self, n_images, batch_size, seed):
+            rs = np.random.RandomState(seed)
+            self.n_chips = rs.randint(1, 6, n_images)
+            self.roidb = [dict(chip_order=rs.permutation(int(k))) for k in self.n_chips]
+            self.batch_size, self.seed, self.epoch = batch_size, seed, 0
+            self.reset()
+
+        def reset(self):
+            rs = np.random.RandomState(self.seed + self.epoch)
+            self.epoch += 1
+            inds = np.repeat(np.arange(len(self.roidb)), self.n_chips)       # one entry per chip of every image
+            self.inds = inds[rs.permutation(len(inds))]
+            self.size = len(self.inds) // self.batch_size * self.batch_size
+            self.crop_idx = [0] * len(self.roidb)
+            self.cur_i = 0
+
+        def get_batch(self):
+            if self.cur_i >= self.size:
+                return False
+            self.batch = self._get_batch()
+            self.cur_i += self.batch_size
+            return True
+
+        def _get_batch(self):
+            rng = range(self.cur_i, self.cur_i + self.batch_size)
+            cropids = [self.roidb[self.inds[i]]['chip_order'][self.crop_idx[self.inds[i]] % len(self.roidb[self.inds[i]]['chip_order'])]
+                       for i in rng]
+            for i in rng:
+                self.crop_idx[self.inds[i]] = self.crop_idx[self.inds[i]] + 1
+            return [(int(self.inds[i]), int(c)) for i, c in zip(rng, cropids)]
+
+    class Sliced(ChipCursorIter):
+        pass
+    rank_slice.patch_iterator_class(Sliced)
+    world, B = 4, 3
+    monkeypatch.delenv('SNIPER_RANK_SLICE', raising=False)
+    ref = ChipCursorIter(40, world * B, seed=3)
+    monkeypatch.setenv('WORLD_SIZE', str(world))
+    its = []
+    for r in range(world):
+        its.append(Sliced(40, world * B, seed=3))
+    for epoch in range(2):
+        steps = 0
+        while ref.get_batch():
+            steps += 1
+            merged = []
+            for r, it in enumerate(its):
+                monkeypatch.setenv('RANK', str(r))
+                assert it.get_batch() and len(it.batch) == B
+                merged += it.batch
+            assert merged == ref.batch, (epoch, steps)
+            for it in its:
+                assert it.crop_idx == ref.crop_idx and it.cur_i == ref.cur_i
+        assert steps == ref.size // (world * B) and steps > 5
+        for r, it in enumerate(its):
+            monkeypatch.setenv('RANK', str(r))
+            assert not it.get_batch()
+            it.reset()
+        ref.reset()
+    # an image with several chips did cross slices (otherwise the test would not see the defect it is here for)
+    seen = {}
+    ref.reset()
+    while ref.get_batch():
+        for k, (im, _) in enumerate(ref.batch):
+            seen.setdefault(im, set()).add(k // B)
+    assert any(len(v) > 1 for v in seen.values())
+
+
 def test_single_process_is_a_no_op():
     from sniper_amd import parallel
     g = torch.ones(10)

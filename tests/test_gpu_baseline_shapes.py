@@ -88,3 +88,116 @@ def test_deformable_psroi_pooling_at_6000_rois(with_trans):
     assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, 1e-2, 1e-2 * np.abs(wd).max(), 'dpsroi d_data R=6000')
     if with_trans:
         assert_close(d_trans.cpu().numpy(), wtr, 1e-2, 1e-2 * np.abs(wtr).max(), 'dpsroi d_trans R=6000')
+
+
+def _fused_case(name):
+    N, C, H, W, O, K, s, p, d, hb, hr, relu = C2_CONV_SHAPES[name]
+    Ho = (H + 2 * p - d * (K - 1) - 1) // s + 1
+    return N, C, H, W, O, K, s, p, d, hb, hr, relu, Ho, Ho
+
+
+@pytest.mark.parametrize('name', list(C2_CONV_SHAPES))
+def test_conv_fwd_stats_at_c2_launch_shapes_vs_oracle(name):
+    """sn_conv_fwd_stats (87 of the step's 115 forward launches) at the C2 launch shapes against the fp32 oracle DIRECTLY:
+    the output tensor (1e-2) and the BatchNorm batch statistics its epilogue emits -- mean and biased variance per channel
+    from the per-row-tile partials against mean / variance of the oracle's tensor (mean to 1e-2 of the channel's standard
+    deviation, variance to 1e-2 relative)."""
+    from sniper_amd import hip
+    from gpu_util import from_nhwc, to_nhwc_f16, w_to_otI
+    N, C, H, W, O, K, s, p, d, hb, hr, relu, Ho, Wo = _fused_case(name)
+    args = (N, H, W, C, C, O, O, O if hr else 0, K, K, s, p, d)
+    nblk = hip.query('sn_conv_fwd_stats_blocks', *args)
+    if nblk <= 0:
+        # the engine asks the same query and falls back to sn_conv_fwd + sn_bn_stats for such a layer (Cout = 72: narrow)
+        assert O < 128
+        pytest.skip('%s does not qualify for the statistics epilogue (Cout = %d)' % (name, O))
+    rs = np.random.RandomState(len(name) * 11 + O)
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rs.standard_normal((O, C, K, K)) / np.sqrt(C * K * K)).astype(np.float32)
+    b = rs.standard_normal(O).astype(np.float32) if hb else None
+    res = rs.standard_normal((N, O, Ho, Wo)).astype(np.float32) if hr else None
+    want = _ref_conv(x, w, b, res, s, p, d, relu)
+    xd = to_nhwc_f16(x)
+    wd = torch.from_numpy(w_to_otI(w)).to(dev()).half().contiguous()
+    bd = torch.from_numpy(b).to(dev()) if hb else None
+    rd = to_nhwc_f16(res) if hr else None
+    y = torch.full((N, Ho, Wo, O), 7.0, dtype=torch.float16, device=dev())
+    part = torch.full((nblk, 2, O), 7.0, dtype=torch.float32, device=dev())
+    hip.call('sn_conv_fwd_stats', xd, wd, bd, rd, y, *args, relu, part, hip.stream())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(y), want, 1e-2, 1e-2 * np.abs(want).max(), 'conv fwd (+stats) %s' % name)
+    M = N * Ho * Wo
+    sm, sq = part[:, 0].double().sum(0).cpu().numpy(), part[:, 1].double().sum(0).cpu().numpy()
+    mean, var = sm / M, sq / M - (sm / M) ** 2
+    w64 = want.astype(np.float64).transpose(1, 0, 2, 3).reshape(O, -1)
+    wmean, wvar = w64.mean(1), w64.var(1)
+    assert np.all(np.abs(mean - wmean) <= 1e-2 * np.sqrt(wvar)), float(np.max(np.abs(mean - wmean) / np.sqrt(wvar)))
+    assert np.all(np.abs(var - wvar) <= 1e-2 * wvar), float(np.max(np.abs(var - wvar) / wvar))
+
+
+@pytest.mark.parametrize('act', [1, 0])
+@pytest.mark.parametrize('name', list(C2_CONV_SHAPES))
+def test_conv_dgrad_bn_at_c2_launch_shapes_vs_oracle(name, act):
+    """sn_conv_dgrad_bn (84 of the step's data-gradient launches) + sn_bn_backward_blocks at the C2 launch shapes against the
+    fp32 oracle DIRECTLY: the data gradient (torch-CPU autograd of the fp32 convolution), and -- from the partial sums its
+    epilogue emits -- dgamma, dbeta and the input gradient of the BatchNorm(+ReLU) below it against the numpy statement of the
+    BatchNorm backward on the ORACLE's data gradient.  1e-2 of each tensor's scale."""
+    import torch.nn.functional as Fnn
+    from sniper_amd import hip
+    from gpu_util import from_nhwc, to_nhwc_f16, w_to_otI
+    N, C, H, W, O, K, s, p, d, hb, hr, relu, Ho, Wo = _fused_case(name)
+    Op = (O + 7) // 8 * 8
+    args = (N, H, W, C, C, Op, Op, 0, K, K, s, p, d)
+    nblk = hip.query('sn_conv_dgrad_bn_blocks', *args)
+    if nblk <= 0:
+        pytest.skip('%s does not qualify for the BatchNorm-backward epilogue' % name)
+    rs = np.random.RandomState(len(name) * 13 + C + act)
+    w = (rs.standard_normal((O, C, K, K)) / np.sqrt(C * K * K)).astype(np.float32)
+    dy = rs.standard_normal((N, O, Ho, Wo)).astype(np.float32)
+    bnx = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    gamma, beta = rs.uniform(0.5, 1.5, C), rs.uniform(-0.3, 0.6, C)
+    # the saved statistics are inputs of the entry (any values: the backward formula is algebra in them); float32-exact
+    mean = (rs.standard_normal(C) * 0.1).astype(np.float32).astype(np.float64)
+    invstd = rs.uniform(0.7, 1.6, C).astype(np.float32).astype(np.float64)
+    scale = (gamma * invstd).astype(np.float32).astype(np.float64)
+    shift = (beta - mean * gamma * invstd).astype(np.float32).astype(np.float64)
+    bc = lambda v: v.reshape(1, C, 1, 1)
+    # keep every pre-activation away from the ReLU threshold: a mask decided by the last bit of x * scale + shift is not an
+    # arithmetic difference this test is about (the end-to-end runs teacher-force it for the same reason)
+    bnx = f16r(bnx)
+    near = np.abs(bnx.astype(np.float64) * bc(scale) + bc(shift)) < 1e-2
+    bnx = f16r(bnx + 0.125 * near)
+    x16 = bnx.astype(np.float64)
+    assert not (np.abs(x16 * bc(scale) + bc(shift)) < 1e-3).any()
+    # oracle: dL/d(conv input) by autograd of the fp32 convolution (its input value does not matter: the op is linear)
+    xt = torch.zeros((N, C, H, W), requires_grad=True)
+    Fnn.conv2d(xt, torch.from_numpy(f16r(w)), None, s, p, d).backward(torch.from_numpy(f16r(dy)))
+    want_dx = xt.grad.numpy().astype(np.float64)
+    z = x16 * bc(scale) + bc(shift)
+    g = want_dx * (z > 0) if act == 1 else want_dx
+    M = N * H * W
+    want_dbeta = g.sum((0, 2, 3))
+    gx = (g * (x16 - bc(mean))).sum((0, 2, 3))
+    want_dgamma = gx * invstd
+    want_dbn = bc(scale) * (g - bc(want_dbeta) / M - (x16 - bc(mean)) * bc(invstd ** 2 * gx) / M)
+    d_dy = torch.zeros((N, Ho, Wo, Op), dtype=torch.float16, device=dev())
+    d_dy[..., :O] = to_nhwc_f16(dy)
+    wT = torch.empty((C, K * K, Op), dtype=torch.float16, device=dev())
+    hip.call('sn_weight_transpose', torch.from_numpy(w_to_otI(w)).to(dev()), wT, O, K * K, C, Op, hip.stream())
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev())
+    dsc, dsh, dmean, dinv = f(scale), f(shift), f(mean), f(invstd)
+    bnxd = to_nhwc_f16(bnx)
+    dx = torch.full((N, H, W, C), 7.0, dtype=torch.float16, device=dev())
+    part = torch.full((nblk, 2, C), 7.0, dtype=torch.float32, device=dev())
+    hip.call('sn_conv_dgrad_bn', d_dy, wT, None, dx, *args, bnxd, C, dsc, dsh, dmean, act, part, hip.stream())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(dx), want_dx, 1e-2, 1e-2 * np.abs(want_dx).max(), 'dgrad (+bn reduction) %s' % name)
+    ws = torch.empty(hip.query('sn_bn_workspace_bytes', M, C), dtype=torch.uint8, device=dev())
+    dg, db = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    out = torch.full((N, H, W, C), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_bn_backward_blocks', part, nblk, dx, bnxd, None, out, M, C, C, C, C, C, dsc, dsh, dmean, dinv, act, ws, dg, db,
+             hip.stream())
+    torch.cuda.synchronize()
+    assert_close(db.cpu().numpy(), want_dbeta, 1e-2, 1e-2 * np.abs(want_dbeta).max(), 'dbeta %s' % name)
+    assert_close(dg.cpu().numpy(), want_dgamma, 1e-2, 1e-2 * np.abs(want_dgamma).max(), 'dgamma %s' % name)
+    assert_close(from_nhwc(out), want_dbn, 1e-2, 1e-2 * np.abs(want_dbn).max(), 'BatchNorm input gradient %s' % name)

@@ -113,7 +113,7 @@ def test_nms_survivor_sets_bit_exact():
 
 
 def test_nms_lazy_kernel_equals_full_mask_and_oracle(monkeypatch):
-    """nms_lazy_kernel (max_keep << N: the proposal op's 6000 -> 300) against the full bitmask + scan pair (SNIPER_NMS_FULL=1)
+    """nms_lazy_kernel (max_keep << N: the proposal op's 6000 -> 300) against the full bitmask + scan pair (sn_debug_option nms_full_mask)
     and the oracle: identical survivor lists on sparse boxes (300 reached within a few chunks), on dense clusters (fewer
     than max_keep survivors: every chunk is walked), with ragged per-image counts, and at the max_keep boundary."""
     import torch
@@ -121,10 +121,7 @@ def test_nms_lazy_kernel_equals_full_mask_and_oracle(monkeypatch):
     rs = np.random.RandomState(17)
 
     def run(ds, n_per, th, mk, full):
-        if full:
-            monkeypatch.setenv('SNIPER_NMS_FULL', '1')
-        else:
-            monkeypatch.delenv('SNIPER_NMS_FULL', raising=False)
+        hip.call('sn_debug_option', b'nms_full_mask', 1 if full else 0)
         B, N, _ = ds.shape
         d = hip.dev(ds)
         keep = torch.full((B, mk), -1, dtype=torch.int32, device=d.device)
@@ -278,6 +275,47 @@ def test_soft_and_hard_nms_reference_golden_bit_exact():
     for i in range(int(z['hard_n'])):
         keep = cpu_nms.cpu_nms(z['hard_in_%d' % i], float(z['hard_thr_%d' % i]))
         assert list(keep) == z['hard_keep_%d' % i].tolist(), i
+
+
+def test_soft_nms_beyond_the_lds_capacity_reference_golden_bit_exact():
+    """cpu_soft_nms has no size cap (lib/nms/cpu_nms.pyx:17-110).  Problems of 4097 ... 12 000 boxes (more than one workgroup
+    holds in LDS: the kernel runs the same phases on the rows in global memory) against the outputs of the REFERENCE's compiled
+    module (tests/golden/nms_big_v1.npz): identical rows, order and float32 scores -- alone, mixed with small problems in one
+    launch, through nms_wrapper (lib/nms/nms.py:15-23: no truncation) and through the drop-in `cpu_nms.cpu_soft_nms` (no raise)."""
+    import os
+    import oracle
+    from golden_util import NMS_BIG_CASES, nms_big_expected, nms_big_problem
+    from sniper_amd import hip
+    from sniper_amd.ext import cpu_nms
+    from sniper_amd.inference import nms_wrapper
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms_big_v1.npz'))
+    cap = hip.query('sn_soft_nms_max_boxes')
+    rs = np.random.RandomState(3)
+    groups = {}
+    for i, (n, method, thr, quant, seed) in enumerate(NMS_BIG_CASES):
+        assert n > cap
+        groups.setdefault((method, thr), []).append(i)
+    for (method, thr), ids in groups.items():
+        big = [nms_big_problem(*[NMS_BIG_CASES[i][k] for k in (0, 3, 4)]) for i in ids]
+        small = [nms_big_problem(int(m), None, 900 + int(m)) for m in rs.randint(1, 700, 5)]
+        probs = [small[0]] + [p for pair in zip(big, small[1:]) for p in pair] + [np.zeros((0, 5), np.float32)]
+        got = cpu_nms.soft_nms_batch([p.copy() for p in probs], sigma=0.55, Nt=0.3, threshold=thr, method=method)
+        k = 1
+        for i, d in zip(ids, big):
+            want = nms_big_expected(z, i, d)
+            assert got[k].shape == want.shape and np.array_equal(got[k], want), (i, got[k].shape, want.shape)
+            k += 2
+        for p, g in zip(probs, got):
+            if 0 < p.shape[0] <= cap:
+                assert np.array_equal(g, oracle.soft_nms(p.copy(), 0.55, 0.3, thr, method))
+    d = nms_big_problem(*[NMS_BIG_CASES[3][k] for k in (0, 3, 4)])
+    want = nms_big_expected(z, 3, d)
+    assert np.array_equal(nms_wrapper(-1, 0.55).process(d.copy()), want)
+    stacked = nms_wrapper(-1, 0.55).process_stacked(np.concatenate((d[:50], d)), [50, len(d)])
+    assert np.array_equal(stacked[1], want) and np.array_equal(stacked[0], oracle.soft_nms(d[:50].copy(), 0.55, 0.3, 0.001, 2))
+    inplace = d.copy()
+    res = cpu_nms.cpu_soft_nms(inplace, 0.55, 0.3, 0.001, 2)
+    assert np.array_equal(res, want) and np.array_equal(inplace[:len(want)], want)
 
 
 def test_focus_mask_golden_bit_exact():

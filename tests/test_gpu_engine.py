@@ -489,11 +489,46 @@ def _train_inputs(rs, B, A, F, extra=()):
     return inp
 
 
+def _check_proposal_steps_vs_oracle(ex):
+    """The teacher-forced run below hands the DEVICE's RoIs to the CPU graph (a proposal set cannot be teacher-forced through
+    a gradient).  So that a wrong RoI set cannot hide behind that override, every MultiProposal(Target) step of the executor is
+    re-evaluated here by oracle/nn.py on exactly the tensors the kernel received: the survivor sequence must be the oracle's
+    (scores are copies: compared through the coordinates, <= 1 float32 ulp), labels / weights bit-equal on the device's RoIs."""
+    from oracle import nn as onn
+    n_checked = 0
+    for st in ex.steps:
+        kind = type(st).__name__
+        if kind not in ('MultiProposalTargetStep', 'MultiProposalStep', 'MultiProposalTargetMaskStep'):
+            continue
+        f = lambda v: ex.as_f32(v).detach().cpu().numpy()
+        cls, box, info = f(st.cls), f(st.bbox), f(st.info)
+        box = box.reshape(st.bbox.shape)
+        cls = cls.reshape(box.shape[0], 2, -1, box.shape[-1])
+        info = info.reshape(-1, 3)
+        from sniper_amd.engine.ops import _anchor_attrs
+        scales, ratios = _anchor_attrs(st.a)
+        want_rois, _, dbg = onn.proposals(cls, box, info, st.stride, scales, ratios, st.pre, st.post, st.thresh, st.min_size)
+        got_rois = (st.rois if kind == 'MultiProposalStep' else st.outs[0]).t.cpu().numpy().reshape(-1, 5)
+        err = np.abs(got_rois.astype(np.float64) - want_rois)
+        ulp = np.spacing(np.maximum(np.abs(got_rois), np.abs(want_rois)).astype(np.float32)).astype(np.float64)
+        bad = np.where((err > ulp).any(1))[0]
+        assert len(bad) == 0, '%s: %d of %d RoIs differ from the oracle (first rows %s)' % (st.node.name, len(bad), len(err), bad[:8])
+        if kind != 'MultiProposalStep':
+            wl, wt, ww = onn.proposal_targets(got_rois, f(st.gt), f(st.vr), st.post, st.fg, tuple(st.stds))
+            assert np.array_equal(st.outs[1].t.cpu().numpy().reshape(-1), wl), st.node.name
+            assert np.array_equal(st.outs[3].t.cpu().numpy().reshape(-1, 4), ww), st.node.name
+            assert_close(st.outs[2].t.cpu().numpy().reshape(-1, 4), wt, 1e-5, 1e-5, 'bbox targets of ' + st.node.name)
+        n_checked += 1
+    assert n_checked >= 1
+    return n_checked
+
+
 def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
     """One training step of the HIP engine against the whole graph evaluated by oracle/graph_cpu.py with TEACHER
     FORCING: every operator of the CPU evaluation receives the device's input activations (so each node is compared
     on identical inputs, and every ReLU / clip / max-pool / proposal decision is the device's), while gradients flow
-    through the CPU operators.  Without it a random-init 50-100 layer BatchNorm network amplifies the first fp16
+    through the CPU operators.  The proposal operators' outputs, which the CPU graph takes over from the device, are compared
+    with oracle/nn.py on the device's inputs first (_check_proposal_steps_vs_oracle): a wrong RoI set fails here.  Without it a random-init 50-100 layer BatchNorm network amplifies the first fp16
     rounding disagreement exponentially (measured: 1e-4 -> 1.5e-2 relative over MobileNetV2) and the flipped
     activation masks put ~sqrt(noise) into every gradient -- the comparison would say nothing about the kernels.
     Asserts: per-node forward mismatch <= tol_fwd (relative L2), every parameter gradient <= tol_grad (relative L2)."""
@@ -516,6 +551,7 @@ def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
         if int(np.prod(y.shape)) != t.numel():
             continue
         dev_vals[st.node.name] = t.reshape(y.shape).cpu().numpy()
+    _check_proposal_steps_vs_oracle(ex)
     ex.backward()
     torch.cuda.synchronize()
     got = [o.cpu().numpy() for o in outs]

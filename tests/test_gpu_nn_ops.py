@@ -618,6 +618,106 @@ def test_multi_proposal_target_vs_oracle(Fh, Fw):
     assert_close(sc.cpu().numpy(), want_scores, 1e-6, 1e-6, 'roi scores')
 
 
+def _ulp_close(got, want, ulps=1):
+    """every element within `ulps` float32 units in the last place"""
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    return np.abs(got.astype(np.float64) - want.astype(np.float64)) <= ulps * np.spacing(np.maximum(np.abs(got), np.abs(want)))
+
+
+def c2_proposal_inputs(seed=5):
+    """MultiProposalTarget / MultiProposal inputs at the BASELINE C2 launch shape (symbols/faster/resnet_mx_101_e2e.py:283-284,
+    347-355: B = 20 chips, A = 21 anchors, 32 x 32 map, 6000 -> 300, 100 x 5 ground truth), every chip a different regime:
+      0-7   continuous scores, moderate deltas (the usual case: 300 survivors, some decoded coordinates clipped)
+      8-11  scores quantised to 1/64 (hundreds of exact ties at the 6000 boundary and inside it: order = anchor index)
+      12    every box decodes to the whole chip (one NMS survivor, repeated cyclically 300 times)
+      13-14 large boxes around few centres (fewer than 300 survivors: cyclic padding with a remainder)
+      15-17 small boxes + rpn_min_size 16 at scale 1 / 1.667 / 2.917 (rejections get score -1 and sort last)
+      18    no ground truth at all, 19: 100 ground-truth boxes (full table), duplicated boxes (arg-max = first)
+    valid ranges are the three SNIPER scales' (MNIteratorE2E.py:158-162 applied to yml:98-101), so fg / ignore / bg all occur."""
+    rs = np.random.RandomState(seed)
+    B, A, F, G = 20, 21, 32, 100
+    p1 = rs.uniform(0, 1, (B, 1, A * F, F))
+    p1[8:12] = np.round(p1[8:12] * 64) / 64
+    cls_prob = np.concatenate((1 - p1, p1), 1).astype(np.float32)
+    bbox_pred = (rs.standard_normal((B, 4 * A, F, F)) * 0.4).astype(np.float32)
+    d = bbox_pred.reshape(B, A, 4, F, F)
+    d[12, :, 2:] = 6.0
+    d[13:15, :, 2:] = 2.6 + 0.3 * rs.standard_normal((2, A, 2, F, F)).astype(np.float32)
+    d[13:15, :, :2] *= 0.05
+    d[15:18, :, 2:] -= 1.2
+    scales = np.array([1.0] * 15 + [1.0, 1.667, 2.917] + [1.0, 1.0], np.float32)
+    im_info = np.stack((np.full(B, 512.0), np.full(B, 512.0), scales), 1).astype(np.float32)
+    gt = -np.ones((B, G, 5), np.float32)
+    for b in range(B):
+        n = 0 if b == 18 else (100 if b == 19 else int(rs.randint(1, 60)))
+        c = rs.uniform(20, 490, (n, 2))
+        wh = np.exp(rs.uniform(np.log(8), np.log(400), (n, 2)))
+        gt[b, :n, :4] = np.round(np.clip(np.concatenate((c - wh / 2, c + wh / 2), 1), 0, 511))
+        gt[b, :n, 4] = rs.randint(1, 81, n)
+    gt[19, 50:60, :4] = gt[19, 40:50, :4]          # equal IoU with two rows: the first one is the match
+    ranges = [(0.0, 80.0), (32.0 * 1.667, 150.0 * 1.667), (120.0 * 2.917, 512.0)]
+    vr = np.array([ranges[b % 3] for b in range(B)], np.float32)
+    vr[15], vr[16], vr[17] = ranges[0], ranges[1], ranges[2]
+    return cls_prob, bbox_pred, im_info, gt, vr
+
+
+@pytest.mark.parametrize('min_size', [0.0, 16.0])
+def test_multi_proposal_target_at_the_c2_launch_shape_vs_oracle(min_size):
+    """sn_multi_proposal_target and sn_multi_proposal against oracle/nn.py at the BASELINE C2 launch shape (B = 20, 21 504
+    anchors per chip, 6000 -> 300, G = 100): the RoI INDEX SETS must be those of the oracle -- same survivors in the same order,
+    i.e. every output row is the oracle's row (scores are copied, so bit-equal; a decoded coordinate may differ in its last
+    float32 bit: device exp vs libm) -- and labels / weights bit-equal, targets to 1e-5 (log of the device)."""
+    hip = _hip()
+    cls_prob, bbox_pred, im_info, gt, vr = c2_proposal_inputs()
+    B, A, F, G, stride, pre, post = 20, 21, 32, 100, 16, 6000, 300
+    from sniper_amd.data.anchors import generate_anchors
+    scales, ratios = (2, 4, 7, 10, 13, 16, 24), (0.5, 1, 2)
+    base = generate_anchors(stride, list(ratios), np.array(scales, np.float32)).astype(np.float32)
+    td = lambda z: torch.from_numpy(np.ascontiguousarray(z)).to(dev())
+    ws = torch.empty(hip.query('sn_proposal_workspace_bytes', B, A, F, F, pre, post), dtype=torch.uint8, device=dev())
+    rois = torch.full((B * post, 5), 7.0, device=dev())
+    label = torch.full((B * post,), 7.0, device=dev())
+    tgt, wgt = torch.full((B * post, 4), 7.0, device=dev()), torch.full((B * post, 4), 7.0, device=dev())
+    stds = np.array([0.1, 0.1, 0.2, 0.2], np.float32)
+    hip.call('sn_multi_proposal_target', td(cls_prob), td(bbox_pred), td(im_info), td(gt), td(vr), td(base), B, A, F, F, stride, G,
+             pre, post, 0.7, min_size, 0.5, stds.ctypes.data, ws, rois, label, tgt, wgt, hip.stream())
+    rois2, sc = torch.full((B * post, 5), 7.0, device=dev()), torch.full((B * post,), 7.0, device=dev())
+    hip.call('sn_multi_proposal', td(cls_prob), td(bbox_pred), td(im_info), td(base), B, A, F, F, stride, pre, post, 0.7, min_size, ws,
+             rois2, sc, hip.stream())
+    torch.cuda.synchronize()
+    want_rois, want_scores, dbg = onn.proposals(cls_prob, bbox_pred, im_info, stride, scales, ratios, pre, post, 0.7, min_size)
+    got_rois, got_sc = rois.cpu().numpy(), sc.cpu().numpy()
+    assert torch.equal(rois2, rois)
+    # scores are the input probabilities (or the -1 of a min_size rejection) of the selected anchors: bit-equal, row for row
+    assert np.array_equal(got_sc, want_scores)
+    assert np.array_equal(got_rois[:, 0], want_rois[:, 0])
+    ok = _ulp_close(got_rois[:, 1:], want_rois[:, 1:], 1)
+    assert ok.all(), 'RoI rows differ from the oracle beyond 1 ulp: rows %s' % np.where(~ok.all(1))[0][:10]
+    assert (got_rois == want_rois).all(1).mean() > 0.98
+    # the regimes the inputs were built for did occur
+    nkeep = np.array([len(k) for _, _, k in dbg])
+    assert nkeep[12] == 1 and (nkeep[13:15] < post).all() and (nkeep[13:15] > 1).all() and (nkeep[:8] >= post).all(), nkeep
+    for b in (12, 13, 14):          # cyclic repetition of the survivors
+        r = got_rois[b * post:(b + 1) * post]
+        assert np.array_equal(r, r[np.arange(post) % nkeep[b]])
+    for b in range(8, 12):          # ties at and inside the cut: the 6000 selected are the stable-sort prefix
+        sb = dbg[b][1]
+        assert (np.diff(sb[:, 4]) == 0).sum() > 1000
+    if min_size > 0:
+        rej = [int((dbg[b][1][:, 4] == -1).sum()) for b in (15, 16, 17)]
+        assert min(rej) >= 0 and max(rej) > 0, rej
+    # labels / targets: against the oracle on the DEVICE's rois (identical inputs) and on the oracle's own rois (whole op)
+    wl, wt, ww = onn.proposal_targets(got_rois, gt, vr, post)
+    gl = label.cpu().numpy()
+    assert np.array_equal(gl, wl) and np.array_equal(wgt.cpu().numpy(), ww)
+    assert_close(tgt.cpu().numpy(), wt, 1e-5, 1e-5, 'bbox targets')
+    wl2, wt2, ww2 = onn.proposal_targets(want_rois, gt, vr, post)
+    assert (gl != wl2).mean() < 1e-3          # a 1-ulp coordinate can move an IoU across 0.5 for a handful of RoIs at most
+    assert (gl > 0).sum() > 30 and (gl == -1).sum() > 20 and (gl == 0).sum() > 1000
+    assert (gl[18 * post:19 * post] == 0).all()          # no ground truth: background only
+    assert (gl[19 * post:] > 0).any()
+
+
 @pytest.mark.parametrize('A,Fh,Fw,pre,quant', [(21, 32, 32, 6000, 0), (21, 32, 32, 6000, 64), (15, 16, 16, 6000, 8), (21, 40, 56, 6000, 0),
                                                 (3, 4, 5, 20, 4)])
 def test_proposal_topk_select_equals_full_sort(A, Fh, Fw, pre, quant, monkeypatch):
@@ -641,10 +741,7 @@ def test_proposal_topk_select_equals_full_sort(A, Fh, Fw, pre, quant, monkeypatc
     ws = torch.empty(hip.query('sn_proposal_workspace_bytes', B, A, Fh, Fw, pre, post), dtype=torch.uint8, device=dev())
     outs = []
     for full in ('1', None):
-        if full:
-            monkeypatch.setenv('SNIPER_FULL_SORT', full)
-        else:
-            monkeypatch.delenv('SNIPER_FULL_SORT', raising=False)
+        hip.call('sn_debug_option', b'proposal_full_sort', 1 if full else 0)
         rois, sc = torch.empty((B * post, 5), device=dev()), torch.empty((B * post,), device=dev())
         hip.call('sn_multi_proposal', td(cls_prob), td(bbox_pred), td(im_info), td(base), B, A, Fh, Fw, stride, pre, post, 0.7, 24.0, ws,
                  rois, sc, hip.stream())

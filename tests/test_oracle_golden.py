@@ -197,6 +197,22 @@ def test_soft_and_hard_nms_reference_golden():
         assert np.array_equal(oracle.cpu_nms(z['hard_in_%d' % i], float(z['hard_thr_%d' % i])), z['hard_keep_%d' % i]), i
 
 
+def test_soft_nms_large_problems_reference_golden():
+    """tests/golden/nms_big_v1.npz: the reference's compiled cpu_soft_nms on 4097 ... 12 000 boxes (it has no size cap,
+    cpu_nms.pyx:17-110).  Rows, order and float32 scores of the C restatement must be identical."""
+    import os
+    from golden_util import NMS_BIG_CASES, nms_big_expected, nms_big_problem
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms_big_v1.npz'))
+    assert int(z['n']) == len(NMS_BIG_CASES)
+    for i, (n, method, thr, quant, seed) in enumerate(NMS_BIG_CASES):
+        d = nms_big_problem(n, quant, seed)
+        sigma, Nt, thr_, method_ = z['par_%d' % i]
+        want = nms_big_expected(z, i, d)
+        got = oracle.soft_nms(d.copy(), sigma, Nt, thr_, int(method_))
+        assert got.shape == want.shape and np.array_equal(got, want), i
+        assert 0 < len(want) < n          # removals happened: the "overwrite with the last box" path is exercised
+
+
 def test_focus_mask_golden():
     """AutoFocus FocusPixel labels (gen_mask, data_workers.py:165-192): the oracle's restatement against masks produced by
     the reference's own anchor_worker with TRAIN.AUTO_FOCUS (tests/golden/make_focus_golden.py)."""

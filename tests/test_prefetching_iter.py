@@ -84,3 +84,20 @@ def test_worker_error_surfaces_in_the_consumer():
     assert it.next().k == 0
     it.close()
     assert threading.active_count() < 50
+
+
+def test_reset_after_close_starts_a_new_worker():
+    """Tester.get_detections closes the iterator it wrapped; the reference reuses one Tester across scales (demo.py:
+    `tester.set_scale(s)` -> `PrefetchingIter.reset()` -> next `get_detections`).  A reset after close must serve a full epoch
+    again instead of waiting on a queue nobody fills."""
+    src = _Counter(5)
+    it = PrefetchingIter(src, depth=2)
+    assert [b.k for b in it] == list(range(5))
+    it.close()
+    assert not it.prefetch_thread.is_alive()
+    assert not it.iter_next()                                  # closed and exhausted: still answers, does not hang
+    for _ in range(2):
+        it.reset()
+        assert [b.k for b in it] == list(range(5))
+        it.close()
+    assert _wait_for(lambda: not it.prefetch_thread.is_alive())

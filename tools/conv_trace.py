@@ -66,7 +66,7 @@ def main():
                     hip.call('sn_conv_dgrad', dy, wt, acc, dx, N, H, W, C, C, Op, Op, C, K, K, s, p, dl, 0, hip.stream())
             for c in cfgs:
                 hip.call('sn_conv_tune', c)
-                os.environ['SNIPER_CONV_TRACE_PTR'] = ''
+                hip.call('sn_conv_trace', None)
                 for _ in range(2):
                     run()
                 for warm in (True, False):
@@ -75,13 +75,13 @@ def main():
                             t.add_(1.0)
                     trace.zero_()
                     torch.cuda.synchronize()
-                    os.environ['SNIPER_CONV_TRACE_PTR'] = '%x' % trace.data_ptr()
+                    hip.call('sn_conv_trace', trace)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     run()
                     e1.record()
                     torch.cuda.synchronize()
-                    os.environ['SNIPER_CONV_TRACE_PTR'] = ''
+                    hip.call('sn_conv_trace', None)
                     t = trace.cpu().numpy().reshape(-1, 8)
                     t = t[t[:, 0] > 0][:, :5].astype(np.float64)
                     if not len(t):

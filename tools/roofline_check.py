@@ -31,6 +31,8 @@ def main():
     res = {'conv_family_ms_per_step_rocprof': round(ms, 3), 'tflops_rocprof': round(tf, 1), 'frac_rocprof': round(tf / 2500.0, 4),
            'bench_achieved': d['roofline']['achieved'], 'bench_frac': d['roofline']['frac'],
            'ratio_bench_over_rocprof': round(d['roofline']['achieved'] / tf, 3), 'steps_profiled': steps,
+           'device': d.get('device'), 'library_sources_hash': d.get('library_sources_hash'),
+           'bench_ms_per_step_under_profiler': d.get('ms_per_step'),
            'by_kernel_ms_per_step': {k: round(v[1] / steps / 1e6, 3) for k, v in rows.items()},
            'launches_per_step': {k: round(v[0] / steps, 1) for k, v in rows.items()}}
     print(json.dumps(res))
