@@ -626,6 +626,18 @@ def main():
             cpu['c1'] = cpu_c1_step()
         except Exception as e:   # noqa: BLE001
             cpu['c1'] = {'value': None, 'sample': 'failed: %r' % (e,)}
+        # the SAME epoch chip database built through the reference's unchanged MNIteratorE2E.reset over the extension mirrors
+        # (its Pool = the drop-in pool that batches chip_worker maps into ragged GPU launches): tools/chipdb_bench.py, own process
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'chipdb_bench.py'), '5000', '400'], cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                               env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            cpu['chip_db_through_shim'] = json.loads(lines[-1]) if r.returncode == 0 and lines else \
+                {'value': None, 'sample': 'failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
+        except Exception as e:   # noqa: BLE001
+            cpu['chip_db_through_shim'] = {'value': None, 'sample': 'failed: %r' % (e,)}
     if rank == 0:
         out = {
             'metric': 'train chips/sec (512x512, R101)', 'value': round(value, 2), 'unit': 'chips/s', 'n_gpus': world,

@@ -113,10 +113,17 @@ class BatchNormStep(Step):
         # Test-time graphs: a BatchNorm that is the only reader of a convolution's output is a per-channel affine map (+ ReLU) of
         # it -- the convolution applies it itself (weights scaled by `scale`, bias = `shift`, ReLU in its epilogue) and this
         # step's output IS the convolution's output tensor: no separate pass over the activation (12 % of the AutoFocus pass).
+        # Training graphs: the same holds for a FROZEN moving-statistics layer behind a frozen convolution (conv0 -> bn0 and
+        # conv1 -> bn2, conv2 -> bn3 of the frozen stage-1 units, network.FIXED_PARAMS): constant affine map, no gradient on
+        # either side, so the pass over the 128 x 128 / 256 x 256 maps (the largest tensors of the step) disappears.
         self.folded_into = None
         prod = None if self.is_stem else self.x.producer
-        if (not ex.for_training and prod is not None and type(prod).__name__ == 'ConvolutionStep' and self.x.fmt == 'act'
-                and self.act in (0, 1) and not prod.is_stem and not prod.depthwise and not prod.out_f32
+        is_conv = prod is not None and type(prod).__name__ == 'ConvolutionStep' and self.x.fmt == 'act'
+        frozen_pair = (ex.for_training and is_conv and self.global_stats and not prod.w.trainable
+                       and (prod.b is None or not prod.b.trainable) and not prod.x.needs_grad
+                       and os.environ.get('SNIPER_TRAIN_FOLD_BN', '1') != '0')
+        if (is_conv and (not ex.for_training or frozen_pair) and self.act in (0, 1)
+                and not prod.depthwise and not prod.out_f32
                 and len(ex.consumers.get((id(prod.node), 0), [])) == 1 and (id(prod.node), 0) not in ex.head_keys
                 and os.environ.get('SNIPER_INFER_FOLD_BN', '1') != '0'):
             self.folded_into = prod
@@ -164,8 +171,8 @@ class BatchNormStep(Step):
                 hip.call('sn_bn_global_scale_shift', g, self.beta.master, self.mean, self.var, self.C, self.eps, self.scale,
                          self.shift, hip.stream())
                 self._global_ready = True
-        if self.folded_into is not None:
-            self.folded_into.refold(self.scale, self.shift)
+                if self.folded_into is not None:
+                    self.folded_into.refold(self.scale, self.shift)
 
     def _use_batch_stats(self):
         return self.ex.is_train and not self.global_stats
@@ -479,6 +486,13 @@ class ConvolutionStep(_GemmLike):
             src, scale, shift = (self.x.stem if self.x.stem is not None else (self.x, None, None))
             hip.call('sn_pack_stem_input', src.t, self.xp, self.N, self.C, self.H, self.W, self.Hp, self.Wp, self.p[0], self.p[1],
                      scale, shift, hip.stream())
+            fold = getattr(self, 'fold_bn', None)
+            if fold is not None:     # frozen conv0 -> bn0 (-> relu0): the affine map rides in the weights / bias / epilogue (refold)
+                if getattr(self, 'wf', None) is None:
+                    raise RuntimeError('%s: folded BatchNorm weights missing (parameters were never set)' % self.node.name)
+                hip.call('sn_conv_stem_fwd', self.xp, self.wf, self.bf, dst, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O,
+                         self.O, self.k[0], self.KWP, self.s[0], 1 if fold.act == 1 else 0, 0, hip.stream())
+                return
             hip.call('sn_conv_stem_fwd', self.xp, self.w.w16, bias, dst, self.N, self.Hp, self.Wp, self.Ho, self.Wo, self.O,
                      self.O, self.k[0], self.KWP, self.s[0], 0, 1 if self.out_f32 else 0, hip.stream())
             return

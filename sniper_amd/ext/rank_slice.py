@@ -61,15 +61,32 @@ def patch_iterator_class(cls):
     return cls
 
 
+def _patch_iterator_module(module, base):
+    cls = getattr(module, base, None)
+    if isinstance(cls, type) and hasattr(cls, 'get_batch') and hasattr(cls, '_get_batch'):
+        patch_iterator_class(cls)
+
+
+# module base name -> callbacks(module, base name) run right after a module of that name (any package prefix, outside sniper_amd)
+# was executed: the reference's files are patched in memory, never on disk.  ext/pool.py registers `inference` and adds a second
+# callback for `MNIteratorE2E` (their `Pool` name).
+POST_IMPORT = {'MNIteratorE2E': [_patch_iterator_module]}
+
+
+def register_post_import(base, fn):
+    hooks = POST_IMPORT.setdefault(base, [])
+    if fn not in hooks:
+        hooks.append(fn)
+
+
 class _Finder(importlib.abc.MetaPathFinder):
-    """Post-import patch of the reference's iterator module (any package prefix: `iterators.MNIteratorE2E`, `lib.iterators...`)."""
-    NAMES = ('MNIteratorE2E',)
+    """Post-import patch of the reference's modules (any package prefix: `iterators.MNIteratorE2E`, `lib.iterators...`)."""
 
     def __init__(self):
         self._busy = False
 
     def find_spec(self, name, path, target=None):
-        if self._busy or name.rsplit('.', 1)[-1] not in self.NAMES or name.startswith('sniper_amd.'):
+        if self._busy or name.rsplit('.', 1)[-1] not in POST_IMPORT or name.startswith('sniper_amd.'):
             return None
         self._busy = True
         try:
@@ -88,9 +105,9 @@ class _Finder(importlib.abc.MetaPathFinder):
 
             def exec_module(self, module):
                 inner.exec_module(module)
-                cls = getattr(module, name.rsplit('.', 1)[-1], None)
-                if isinstance(cls, type) and hasattr(cls, 'get_batch') and hasattr(cls, '_get_batch'):
-                    patch_iterator_class(cls)
+                base = name.rsplit('.', 1)[-1]
+                for fn in POST_IMPORT.get(base, []):
+                    fn(module, base)
         spec.loader = Loader()
         return spec
 
@@ -99,10 +116,10 @@ def install_import_hook():
     if not any(isinstance(f, _Finder) for f in sys.meta_path):
         sys.meta_path.insert(0, _Finder())
     for name, mod in list(sys.modules.items()):            # already imported: patch in place
-        if name.rsplit('.', 1)[-1] in _Finder.NAMES and not name.startswith('sniper_amd.'):
-            cls = getattr(mod, name.rsplit('.', 1)[-1], None)
-            if isinstance(cls, type) and hasattr(cls, '_get_batch'):
-                patch_iterator_class(cls)
+        base = name.rsplit('.', 1)[-1]
+        if base in POST_IMPORT and not name.startswith('sniper_amd.') and mod is not None:
+            for fn in POST_IMPORT[base]:
+                fn(mod, base)
 
 
 def is_rank_sliced(it):

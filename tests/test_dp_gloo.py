@@ -3,6 +3,7 @@ global batch, the bucketed gradient-arena all-reduce (sum, in place), and bench.
 The kernels need a GPU; what is exercised here is everything that differs between N = 1 and N > 1."""
 import os
 import socket
+import sys
 
 import numpy as np
 import torch
@@ -228,19 +229,34 @@ def test_single_process_is_a_no_op():
     assert parallel.allreduce_gradients(g, None) == 0 and torch.equal(g, torch.ones(10))
 
 
-def test_ext_install_hands_out_a_thread_backed_pool(monkeypatch):
-    """sniper_amd.ext.pool: `from multiprocessing import Pool` after install() is the thread-backed pool with Pool's interface (the
-    reference's forked workers would call GPU-backed extension modules from a copy of the parent's HIP context); the work items
-    run in THIS process, map() keeps order, initializer / initargs are honoured."""
+def test_ext_install_scopes_the_pool_to_the_reference_modules(tmp_path, monkeypatch):
+    """sniper_amd.ext.pool: after install(), a module named like the reference's `iterators/MNIteratorE2E.py` or `inference.py`
+    that does `from multiprocessing import Pool` sees the drop-in pool under that name (post-import hook, file untouched), while
+    `multiprocessing.Pool` itself and every other module keep the real process pool (lib/dataset/imdb.py:81-118 forks numpy-only
+    workers).  The drop-in has Pool's interface; unrecognised work items run on threads of THIS process, map() keeps order,
+    initializer / initargs are honoured; the reference's chip_worker / nms_worker bound methods are recognised for batching."""
+    import importlib
     import multiprocessing
     import threading
     from sniper_amd.ext import pool
-    monkeypatch.setattr(multiprocessing, 'Pool', multiprocessing.Pool)       # restore after the test
+    real = multiprocessing.Pool
+    pkg = tmp_path / 'refpkg'
+    (pkg / 'iterators').mkdir(parents=True)
+    (pkg / 'iterators' / '__init__.py').write_text('')
+    src = 'from multiprocessing import Pool\n\n\nclass MNIteratorE2E(object):\n    def get_batch(self):\n        return True\n\n    def _get_batch(self):\n        return None\n'
+    (pkg / 'iterators' / 'MNIteratorE2E.py').write_text(src)
+    (pkg / 'inference.py').write_text('from multiprocessing import Pool\n\n\nclass Tester(object):\n    pass\n')
+    (pkg / 'imdb_like.py').write_text('from multiprocessing import Pool\n')
+    monkeypatch.syspath_prepend(str(pkg))
+    for name in ('iterators', 'iterators.MNIteratorE2E', 'inference', 'imdb_like'):
+        monkeypatch.delitem(sys.modules, name, raising=False)
     pool.install()
-    from multiprocessing import Pool
-    assert Pool is pool.Pool
+    pool.install()                                                            # idempotent
+    assert multiprocessing.Pool is real
+    m_it, m_inf, m_other = (importlib.import_module(n) for n in ('iterators.MNIteratorE2E', 'inference', 'imdb_like'))
+    assert m_it.Pool is pool.Pool and m_inf.Pool is pool.Pool and m_other.Pool is real
     seen = []
-    p = Pool(4, initializer=seen.append, initargs=('init',))
+    p = m_it.Pool(4, initializer=seen.append, initargs=('init',))
     pid = os.getpid()
     import time
     res = p.map(lambda i: (time.sleep(0.02), i * i, os.getpid(), threading.current_thread().name)[1:], range(32))
@@ -249,6 +265,36 @@ def test_ext_install_hands_out_a_thread_backed_pool(monkeypatch):
     p.join()
     assert [r[0] for r in res] == [i * i for i in range(32)] and r2 == [1, 2, 3, 4, 5]
     assert all(r[1] == pid for r in res) and len(set(r[2] for r in res)) > 1
-    assert seen == ['init'] * 4
-    pool.install()                                                            # idempotent
-    assert multiprocessing.Pool is pool.Pool
+    assert seen == ['init'] * 4 and p.routed_maps == 0
+
+    # recognition of the reference's work items (the batched calls themselves need the GPU: tests/test_gpu_acceptance.py)
+    class chip_worker(object):                      # lib/data_utils/data_workers.py:374-392
+        valid_ranges, scales, chip_size, use_neg_chips, chip_stride = ((-1, 80), (32, 150), (120, -1)), ((1400, 2000), (800, 1280), (-1, 512)), 512, False, 57
+
+        def chip_extractor(self, r):
+            raise AssertionError('per-item path')
+
+        def box_assigner(self, r):
+            raise AssertionError('per-item path')
+
+        def other(self, r):
+            return r
+
+    class nms_wrapper(object):
+        thresh, sigma = -1, 0.55
+
+    class nms_worker(object):                       # lib/data_utils/data_workers.py:124-129
+        def __init__(self):
+            self.nms_wrapper = nms_wrapper()
+
+        def worker(self, data):
+            raise AssertionError('per-item path')
+    cw = chip_worker()
+    f = pool.route(cw.chip_extractor)
+    assert f is not None and f.__name__ == 'extract_batch' and f.__self__.chip_stride == 57 and f.__self__.res_based
+    cw.chip_stride = 58                             # chip_worker.reset() draws a new stride every epoch
+    assert pool.route(cw.box_assigner).__self__.chip_stride == 58 and pool.route(cw.box_assigner).__name__ == 'assign_batch'
+    assert pool.route(cw.other) is None and pool.route(lambda r: r) is None and pool.route(len) is None
+    assert pool.route(nms_worker().worker).__name__ == 'process_many'
+    monkeypatch.setenv('SNIPER_POOL_ROUTE', '0')
+    assert pool.route(cw.chip_extractor) is None

@@ -63,23 +63,32 @@ def test_test_graph_lowers():
     ex = Executor(sym, shapes, False, [], device=torch.device('cpu'))
     assert any(type(s).__name__ == 'MultiProposalStep' for s in ex.steps)
     assert ex.n_trainable == 0
-    # test-time BatchNorm folding: bn2 / bn3 of every bottleneck read a convolution nobody else reads -> folded into it; bn1 reads
-    # the residual sum (also the next shortcut's input), bn0 the packed stem convolution, bn_data the image: not folded
+    # test-time BatchNorm folding: bn2 / bn3 of every bottleneck and bn0 (the packed stem convolution) read a convolution nobody
+    # else reads -> folded into it; bn1 reads the residual sum (also the next shortcut's input), bn_data the image: not folded
     bns = [s for s in ex.steps if type(s).__name__ == 'BatchNormStep']
     folded = sorted(s.node.name for s in bns if s.folded_into is not None)
     # (the three stage-4 bn3 layers read a DeformableConvolution: sampling + GEMM, no epilogue to fold into)
-    assert len(folded) == 33 * 2 - 3 and all(n.endswith(('_bn2', '_bn3')) for n in folded), folded[:5]
+    assert len(folded) == 33 * 2 - 3 + 1 and all(n.endswith(('_bn2', '_bn3')) or n == 'bn0' for n in folded), folded[:5]
     assert not any(n.startswith('stage4') and n.endswith('_bn3') for n in folded)
     assert all(s.folded_into.fold_bn is s and s.y.t is s.x.t for s in bns if s.folded_into is not None)
     assert not any(type(s).__name__ == 'DeformableConvolutionStep' and getattr(s, 'fold_bn', None) is not None for s in ex.steps)
 
 
-def test_batchnorm_folding_is_test_time_only(monkeypatch):
+def test_batchnorm_folding_test_time_and_frozen_training_layers(monkeypatch):
     cfg = cfgmod.res101_e2e(batch_images=2)
     net = ours.resnet_mx_101_e2e(momentum=0.995)
     sym = net.get_symbol_rcnn(cfg)
     shapes = dict(data=(2, 3, 512, 512), valid_ranges=(2, 2), im_info=(2, 3), label=(2, 21 * 32 * 32),
                   bbox_target=(2, 84, 32, 32), bbox_weight=(2, 84, 32, 32), gt_boxes=(2, 100, 5))
+    ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
+    # a training graph folds ONLY frozen moving-statistics layers behind frozen convolutions (network.FIXED_PARAMS = conv0, bn0,
+    # stage1): conv0 -> bn0 and conv1 -> bn2, conv2 -> bn3 of the three stage-1 units; every batch-statistics layer keeps its pass
+    folded = sorted(s.node.name for s in ex.steps if getattr(s, 'folded_into', None) is not None)
+    assert folded == sorted(['bn0'] + ['stage1_unit%d_bn%d' % (u, b) for u in (1, 2, 3) for b in (2, 3)]), folded
+    for s in ex.steps:
+        if getattr(s, 'folded_into', None) is not None:
+            assert s.global_stats and not s.folded_into.w.trainable and not s.y.needs_grad
+    monkeypatch.setenv('SNIPER_TRAIN_FOLD_BN', '0')
     ex = Executor(sym, shapes, True, fixed_param_names(cfg, sym), device=torch.device('cpu'))
     assert not any(getattr(s, 'folded_into', None) is not None for s in ex.steps)
     monkeypatch.setenv('SNIPER_INFER_FOLD_BN', '0')

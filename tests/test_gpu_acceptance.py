@@ -187,3 +187,20 @@ def test_reference_operator_plugin_executes_in_a_graph():
         p = ex.params[name]
         got = p.to_reference(p.grad.detach().cpu().numpy())
         assert_close(got, want, 1e-2, 1e-2 * np.abs(want).max(), 'grad ' + name)
+
+
+def test_reference_epoch_chip_database_through_the_routed_pool():
+    """The reference's unchanged MNIteratorE2E.reset (lib/iterators/MNIteratorE2E.py:40-103) with its own chip_worker over the
+    extension mirrors: the drop-in pool (sniper_amd/ext/pool.py) runs each `pool.map(chip_worker.chip_extractor / box_assigner,
+    part)` as ONE ragged GPU launch instead of one launch + read-back per image on a pool thread.  Same numpy seed -> the routed
+    and the per-item build produce the SAME chip database (chips, scales, box assignment)."""
+    if not os.path.isfile(os.path.join(ROOT, 'oracle', '_ref', 'py3', 'main_train.py')):
+        pytest.skip('oracle/_ref/py3 not built (python -m oracle.build where the reference checkout exists)')
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'chipdb_bench.py'), '300', '120'], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert res['pool'] == 'sniper_amd.ext.pool.Pool', res
+    assert res['routed_maps'] == 2 and res['unrouted']['routed_maps'] == 0, res
+    assert res['routed_equals_unrouted'] and res['chips'] > 300, res

@@ -135,8 +135,7 @@ def test_conv_fwd_stats_at_c2_launch_shapes_vs_oracle(name):
     assert np.all(np.abs(var - wvar) <= 1e-2 * wvar), float(np.max(np.abs(var - wvar) / wvar))
 
 
-@pytest.mark.parametrize('act', [1, 0])
-@pytest.mark.parametrize('name', list(C2_CONV_SHAPES))
+@pytest.mark.parametrize('name,act', [(n, 1) for n in C2_CONV_SHAPES] + [('stage3 1x1 1024->256 @32', 0)])
 def test_conv_dgrad_bn_at_c2_launch_shapes_vs_oracle(name, act):
     """sn_conv_dgrad_bn (84 of the step's data-gradient launches) + sn_bn_backward_blocks at the C2 launch shapes against the
     fp32 oracle DIRECTLY: the data gradient (torch-CPU autograd of the fp32 convolution), and -- from the partial sums its

@@ -539,9 +539,12 @@ def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
     for st in ex.steps:
         y = getattr(st, 'y', None)
         if y is None or y.t is None or (type(st).__name__ == 'BatchNormStep' and getattr(st, 'act', 0)) or \
-                getattr(st, 'fused_residual', None) is not None:
+                getattr(st, 'fused_residual', None) is not None or getattr(st, 'fold_bn', None) is not None or \
+                (type(st).__name__ == 'BatchNormStep' and getattr(st, 'folded_into', None) is not None and not getattr(st, 'act', 0)):
             continue            # a BN fused with its activation holds the post-activation tensor (forced at the activation
-            #                     node); a convolution fused with the residual add writes the sum (forced at the add node)
+            #                     node); a convolution fused with the residual add writes the sum (forced at the add node); a
+            #                     frozen convolution that absorbed its frozen BatchNorm (+ ReLU) holds THAT output (forced at
+            #                     the BatchNorm / activation node)
         if getattr(st, 'fused', False) is False and type(st).__name__ in ('ActivationStep', 'ClipStep') or \
                 type(st).__name__ not in ('ActivationStep', 'ClipStep'):
             pass
