@@ -207,6 +207,11 @@ int sn_conv_stem_wgrad(const void *dy, const void *xp, float *dw, int N, int Hp,
 int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *dx, int N, int H, int W, int Cin,
                   int dx_pix_stride, int Cout, int dy_pix_stride, int acc_pix_stride, int KH, int KW, int stride, int pad, int dil,
                   int out_f32, sn_stream_t stream);
+/* Test / A-B switch (process-wide, atomic): 1 (default) = the data gradient of a stride-2, dilation-1 convolution with even
+ * destination dims walks its destination pixels parity class by parity class, each class only the taps that reach it (9 tap visits
+ * instead of 36 for a 3x3 kernel, 1 instead of 4 for a 1x1 shortcut; same sums in the same order per pixel); 0 = every tap for
+ * every pixel.  Affects the row-tile count sn_conv_dgrad_bn_blocks reports: set it before that query. */
+int sn_conv_dgrad_by_class(int on);
 /* sn_conv_dgrad that also emits the reduction of the BatchNorm(+activation) backward below it: dx is dL/dy of
  * y = act(BN(bn_x)) (bn_act: 0 none, 1 ReLU, 2 ReLU6), partials (blocks, 2, Cin) fp32 = per row tile sum g and sum g*(bn_x - mean)
  * with g = the stored dx masked by the activation; blocks = sn_conv_dgrad_bn_blocks(...) (0: the layer does not qualify).

@@ -164,6 +164,7 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
     # parameter gradients can be compared tightly instead of through the chaotic sensitivity of a random-init network.
     force = force or {}
     run.local_err = {}
+    run.kept = {}          # node name -> (oracle value, forced value) for the names in run.keep (diagnostics: tools/parity_nodes.py)
     probes = {}     # probe: list of node names -> run() additionally returns {name: (value, gradient)} as a third result
     t = {k: torch.from_numpy(np.asarray(v, np.float32).copy()).requires_grad_(want_grads) for k, v in params.items()}
     auxt = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in aux.items()}
@@ -303,6 +304,8 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
         if node.name in force and not isinstance(y, tuple):
             fv = torch.from_numpy(np.asarray(force[node.name], np.float32)).reshape(y.shape)
             run.local_err[node.name] = float((y.detach() - fv).norm() / (fv.norm() + 1e-20))
+            if node.name in getattr(run, 'keep', ()):
+                run.kept[node.name] = (y.detach().numpy().copy(), fv.numpy().copy())
             y = y + (fv - y.detach())
         if isinstance(y, tuple):
             for i, yi in enumerate(y):

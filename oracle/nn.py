@@ -426,8 +426,10 @@ def deform_im2col(data, offset, KH, KW, stride, pad, dil, DG):
                 for t in range(T):
                     kh, kw = divmod(t, KW)
                     for g in range(DG):
-                        py = oy * stride - pad + kh * dil + offset[n, g * 2 * T + 2 * t, oy, ox]
-                        px = ox * stride - pad + kw * dil + offset[n, g * 2 * T + 2 * t + 1, oy, ox]
+                        # the sampling position is a float32 sum (the operator's DType; the border test `p < dim` is a
+                        # discontinuity: 32 - 1e-6 is 32.0 in float32 and inside the map in double)
+                        py = float(np.float32(oy * stride - pad + kh * dil) + np.float32(offset[n, g * 2 * T + 2 * t, oy, ox]))
+                        px = float(np.float32(ox * stride - pad + kw * dil) + np.float32(offset[n, g * 2 * T + 2 * t + 1, oy, ox]))
                         ok, y0, y1, x0, x1, ly, lx = _deform_sample(py, px, H, W)
                         if not ok:
                             continue
@@ -449,8 +451,10 @@ def deform_col2im(dcol, data, offset, KH, KW, stride, pad, dil, DG):
                 for t in range(T):
                     kh, kw = divmod(t, KW)
                     for g in range(DG):
-                        py = oy * stride - pad + kh * dil + offset[n, g * 2 * T + 2 * t, oy, ox]
-                        px = ox * stride - pad + kw * dil + offset[n, g * 2 * T + 2 * t + 1, oy, ox]
+                        # the sampling position is a float32 sum (the operator's DType; the border test `p < dim` is a
+                        # discontinuity: 32 - 1e-6 is 32.0 in float32 and inside the map in double)
+                        py = float(np.float32(oy * stride - pad + kh * dil) + np.float32(offset[n, g * 2 * T + 2 * t, oy, ox]))
+                        px = float(np.float32(ox * stride - pad + kw * dil) + np.float32(offset[n, g * 2 * T + 2 * t + 1, oy, ox]))
                         ok, y0, y1, x0, x1, ly, lx = _deform_sample(py, px, H, W)
                         if not ok:
                             continue

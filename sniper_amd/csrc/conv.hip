@@ -23,6 +23,7 @@
 //
 // The weight gradient needs both operands transposed (the contraction index is the pixel, which is
 // the slow dimension of both dY and X); see conv_wgrad_kernel below.
+#include <algorithm>
 #include <atomic>
 
 #include "conv_common.h"
@@ -179,6 +180,7 @@ static int conv_check(const ConvParams &p, const char *who) {
 struct ConvPlan {
   int bm, mtiles, ntiles, dma;
   unsigned x_bytes, w_bytes;
+  int cls, cls_mc;       // stride-2 data gradient enumerated by parity class (ConvParams::cls): mtiles = 4 x tiles of cls_mc rows
 };
 // Tuning override (tools/conv_tune.py, tests): -1 = the built-in table, 0 = the register-staged kernel (conv_igemm_kernel) only,
 // else that LDS-DMA configuration (conv_dma_config) for every layer that qualifies.  Process-wide; not meant to change while
@@ -217,23 +219,39 @@ static int conv_dma_choice_balanced(int M, int Nout, int nk, bool dgrad) {
 
 static int conv_dma_choice(int M, int Nout, int nk, bool dgrad) { return conv_dma_choice_balanced(M, Nout, nk, dgrad); }
 
+// A/B and test switch: 0 = a stride-2 data gradient visits every tap for every destination pixel (three quarters of them
+// zero-filled), 1 (default) = by parity class (ConvParams::cls)
+static std::atomic<int> g_dgrad_by_class{env_int("SNIPER_DGRAD_BY_CLASS", 1)};
+SN_EXPORT int sn_conv_dgrad_by_class(int on) {
+  g_dgrad_by_class.store(on ? 1 : 0, std::memory_order_relaxed);
+  return SN_OK;
+}
+
 static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {
   // Layers whose taps are whole 64-channel K-steps and 16-byte addressable take a pipelined kernel; narrow outputs
   // (stage1 / RPN heads) and the packed stem stay on conv_igemm_kernel.
-  ConvPlan q = {0, 0, 0, 0, 0u, 0u};
+  ConvPlan q = {0, 0, 0, 0, 0u, 0u, 0, 0};
   const unsigned long x_bytes = ((unsigned long)p.N * p.H * p.W - 1) * p.in_ps * 2 + (unsigned long)p.Cin * 2;
   const unsigned long w_bytes = (unsigned long)p.Nout * p.KH * p.KW * p.Cin * 2;
   if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul) {
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
     const int forced = g_conv_cfg.load(std::memory_order_relaxed);
-    const int cfg = forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, p.KH * p.KW * (p.Cin / 64), dgrad);
+    // a stride-2 data gradient walks its destination pixels parity class by parity class (each class only its own taps)
+    const bool by_class = dgrad && p.stride == 2 && p.dil == 1 && p.Ho % 2 == 0 && p.Wo % 2 == 0 &&
+                          g_dgrad_by_class.load(std::memory_order_relaxed) != 0;
+    const int nk_full = p.KH * p.KW * (p.Cin / 64);
+    const int nk = by_class ? std::max(1, ((p.KH + 1) / 2) * ((p.KW + 1) / 2) * (p.Cin / 64)) : nk_full;    // the busiest class
+    const int cfg = forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, nk, dgrad);
     if (cfg > 0) {
       const ConvDmaConfig c = conv_dma_config(cfg);
       q.dma = cfg;
       q.bm = c.bm;
       q.ntiles = sn_div_up(p.Nout, c.bn);
-      q.mtiles = sn_div_up(p.M, c.bm);
+      const bool cls = by_class && c.bm * c.bn <= 160 * 128;      // (the 8-fragment-wide tiles are not instantiated for it)
+      q.cls = cls ? 1 : 0;
+      q.cls_mc = cls ? p.N * (p.Ho / 2) * (p.Wo / 2) : 0;
+      q.mtiles = cls ? 4 * sn_div_up(q.cls_mc, c.bm) : sn_div_up(p.M, c.bm);
       return q;
     }
   }
@@ -247,6 +265,9 @@ static int conv_launch(const ConvParams &p, hipStream_t s) {
     ConvParams q = p;
     q.x_bytes = pl.x_bytes;
     q.w_bytes = pl.w_bytes;
+    q.cls = pl.cls;
+    q.cls_mc = pl.cls_mc;
+    conv_fastdiv_fill(q);
     return conv_dma_launch(q, DGRAD, pl.dma, s);
   }
   SN_REQUIRE(!p.stats, "convolution statistics are emitted by the pipelined kernel only (query sn_conv_fwd_stats_blocks first)");

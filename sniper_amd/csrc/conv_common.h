@@ -28,11 +28,34 @@ struct ConvParams {
   const half_t *bn_x = nullptr;
   const float *bn_scale = nullptr, *bn_shift = nullptr, *bn_mean = nullptr;
   int bn_x_ps = 0, bn_act = 0;
+  // Row index -> (image, y, x) without integer division in the kernel (conv_dma.hip): q = (umulhi(n, mul) + n) >> sh for n < 2^31,
+  // by rows per image (fda) and by row length (fdb); filled by conv_launch (conv_fastdiv_fill).
+  unsigned fda_mul = 1, fda_sh = 0, fdb_mul = 1, fdb_sh = 0;
+  int rows_img = 1, row_len = 1;
+  // Data gradient of a stride-2 convolution by PARITY CLASS (cls = 1, conv_dma.hip): a destination pixel (y, x) only receives the
+  // taps with (y + pad - kh) and (x + pad - kw) even, so the rows of the GEMM are enumerated class by class ((y & 1, x & 1) =
+  // 00, 01, 10, 11; cls_mc = N * Ho/2 * Wo/2 rows each, row tiles never straddle classes) and every class walks only ITS taps:
+  // 9 tap visits over the four classes of a 3 x 3 kernel instead of 36, 1 instead of 4 for a 1 x 1 shortcut.
+  int cls = 0, cls_mc = 0;
   unsigned long long *trace = nullptr;   // phase timeline of every workgroup (tools/conv_trace.py; SNIPER_CONV_TRACE), normally null
   float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
                        // STORED fp16 values (what bn_stats_kernel would read back), or null
 };
 
+
+static inline void conv_fastdiv_make(unsigned d, unsigned &mul, unsigned &sh) {
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << s) - d)) / d + 1);
+  sh = s;
+}
+static inline void conv_fastdiv_fill(ConvParams &p) {
+  p.rows_img = p.cls ? (p.Ho / 2) * (p.Wo / 2) : p.Ho * p.Wo;
+  p.row_len = p.cls ? p.Wo / 2 : p.Wo;
+  conv_fastdiv_make((unsigned)p.rows_img, p.fda_mul, p.fda_sh);
+  conv_fastdiv_make((unsigned)p.row_len, p.fdb_mul, p.fdb_sh);
+}
+__device__ __forceinline__ int conv_fastdiv(int n, unsigned mul, unsigned sh) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> sh); }
 
 // LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: see conv_dma_config().
 struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };

@@ -79,6 +79,32 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
   const int nt = j % ntiles, mt = (j / ntiles) * 8 + xcd;
   if (mt >= mtiles) return;
+  // stride-2 data gradient by parity class (ConvParams::cls): row tile mt = (class, tile of the class's rows)
+  // (not instantiated for the 8-fragment-wide tiles: their epilogue has no register to spare, and no stride-2 layer takes them)
+  constexpr bool kClassOk = DGRAD && BM * BN <= 160 * 128;
+  const bool by_class = kClassOk && p.cls != 0;
+  int mt_l = mt, cls_ph = 0, cls_pw = 0;
+  if (by_class) {
+    const int mtc = mtiles >> 2, c = mt / mtc;
+    mt_l = mt - c * mtc;
+    cls_ph = c >> 1;
+    cls_pw = c & 1;
+  }
+  const int Mrows = by_class ? p.cls_mc : p.M;
+  // GEMM row -> destination (image, y, x) and flat pixel index, by multiplication (ConvParams::fda / fdb)
+  auto row_decompose = [&](int m, int &img, int &oy, int &ox) {
+    img = conv_fastdiv(m, p.fda_mul, p.fda_sh);
+    const int rem = m - img * p.rows_img;
+    oy = conv_fastdiv(rem, p.fdb_mul, p.fdb_sh);
+    ox = rem - oy * p.row_len;
+    if (by_class) { oy = 2 * oy + cls_ph; ox = 2 * ox + cls_pw; }
+  };
+  auto row_pixel = [&](int m) {
+    if (!by_class) return m;
+    int img, oy, ox;
+    row_decompose(m, img, oy, ox);
+    return (img * p.Ho + oy) * p.Wo + ox;
+  };
   // phase stamps (shader clock) of wave 0: [0] entry, [1] first stage landed, [2] K loop done, [3] stores drained, [4] exit
   auto stamp = [&](int k) {
     if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
@@ -90,13 +116,12 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   const int lw = PS ? (producer ? wave - NW : 0) : wave;   // index among the staging waves
   const int cw = producer ? 0 : wave;                      // index among the multiplying waves
   const int wm = cw / WNW, wn = cw % WNW;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt_l * BM, n0 = nt * BN;
   const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;   // row inside an 8-row group, global 16-byte chunk
 
   // ---- per-lane gather state: A rows m0 + 8 (wave + NW i) + lrow
   int a_base[AGW], a_h[AGW], a_w[AGW];
   bool a_ok[AGW];
-  const int HoWo = p.Ho * p.Wo;
   int a_grp[AGW], b_grp[BGW];          // wave-uniform group index of this wave's i-th piece
 #pragma unroll
   for (int i = 0; i < AGW; ++i) a_grp[i] = (lw + NL * i < PA) ? lw + NL * i : lw + NL * (i - 1);
@@ -105,17 +130,19 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
 #pragma unroll
   for (int i = 0; i < AGW; ++i) {
     const int m = m0 + 8 * a_grp[i] + lrow;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
-    const int img = mm / HoWo, rem = mm - img * HoWo;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    a_ok[i] = m < Mrows;
+    int img, oy, ox;
+    row_decompose(a_ok[i] ? m : 0, img, oy, ox);
     a_base[i] = img * p.H * p.W;
     if (DGRAD) { a_h[i] = oy + p.pad; a_w[i] = ox + p.pad; }
     else { a_h[i] = oy * p.stride - p.pad; a_w[i] = ox * p.stride - p.pad; }
   }
   const int taps = p.KH * p.KW;
   const int kpt = p.Cin / BK;          // host guarantees Cin % 64 == 0
-  const int nk = taps * kpt;
+  // taps this workgroup walks: all of them, or (by class, stride 2, dilation 1) those of its parity: kh = kh0, kh0 + 2, ...
+  const int kh0 = by_class ? ((cls_ph + p.pad) & 1) : 0, kw0 = by_class ? ((cls_pw + p.pad) & 1) : 0, kstep = by_class ? 2 : 1;
+  const int nkh = by_class ? (p.KH > kh0 ? (p.KH - kh0 + 1) >> 1 : 0) : p.KH, nkw = by_class ? (p.KW > kw0 ? (p.KW - kw0 + 1) >> 1 : 0) : p.KW;
+  const int nk = nkh * nkw * kpt;
   const unsigned wrow_bytes = (unsigned)(taps * p.Cin) * 2u;
   const char *xb = reinterpret_cast<const char *>(p.x), *wb = reinterpret_cast<const char *>(p.w);
   const unsigned in_ps_bytes = (unsigned)p.in_ps * 2u;
@@ -130,7 +157,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     const int n = n0 + (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
     w_voff[i] = n < p.Nout ? (unsigned)n * wrow_bytes + (unsigned)gchunk * 16u : kOob;
   }
-  int g_kh = 0, g_kw = 0, g_kc = 0, g_kt = 0;   // next stage to issue: tap (g_kh, g_kw), channel block g_kc, K-step g_kt
+  int g_kh = kh0, g_kw = kw0, g_kc = 0;   // next stage to issue: tap (g_kh, g_kw), channel block g_kc
   unsigned a_voff[AGW];
   auto tap_setup = [&]() {
 #pragma unroll
@@ -140,6 +167,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
       if (DGRAD) {
         const int ty = a_h[i] - g_kh * p.dil, tx = a_w[i] - g_kw * p.dil;
         if (p.stride == 1) { sy = ty; sx = tx; }
+        else if (p.stride == 2) { sy = ty >> 1; sx = tx >> 1; ok = ok && !((ty | tx) & 1); }     // (negative ty / tx fail the range test below)
         else { sy = ty / p.stride; sx = tx / p.stride; ok = ok && (sy * p.stride == ty) && (sx * p.stride == tx); }
         ok = ok && ty >= 0 && tx >= 0 && sy < p.H && sx < p.W;
       } else {
@@ -153,7 +181,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   // wave-uniform LDS destinations: stage base + group * 1 KB (the DMA adds 16 B per lane)
   half_t *const b_lds = lds + BM * BK;
   auto issue = [&](int buf) {
-    const unsigned cbo = (unsigned)g_kc * (BK * 2), wbo = (unsigned)g_kt * (BK * 2);   // uniform
+    const unsigned cbo = (unsigned)g_kc * (BK * 2), wbo = (unsigned)((g_kh * p.KW + g_kw) * p.Cin + g_kc * BK) * 2u;   // uniform
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb) + cbo, 0, (int)(p.x_bytes - cbo), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb) + wbo, 0, (int)(p.w_bytes - wbo), 0x00020000);
     half_t *const sa = lds + buf * STAGE, *const sb = b_lds + buf * STAGE;
@@ -163,10 +191,10 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
 #pragma unroll
     for (int i = 0; i < BGW; ++i)
       dma16(rw, sb + b_grp[i] * 512, w_voff[i]);
-    ++g_kt;
     if (++g_kc == kpt) {
       g_kc = 0;
-      if (++g_kw == p.KW) { g_kw = 0; ++g_kh; }
+      g_kw += kstep;
+      if (g_kw >= p.KW) { g_kw = kw0; g_kh += kstep; }
       tap_setup();
     }
   };
@@ -218,11 +246,12 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     const int src_ps = pre_res ? p.res_ps : p.bn_x_ps;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+      const int mr = m0 + wm * WTM + i * 16 + (lane & 15);
+      const int m = row_pixel(mr < Mrows ? mr : 0);
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         const int n = n0 + wn * WTN + jp * 32 + (lane >> 4) * 8;
-        rpre[i][jp] = (m < p.M && n < p.Nout) ? *reinterpret_cast<const half8 *>(src + (size_t)m * src_ps + n)
+        rpre[i][jp] = (mr < Mrows && n < p.Nout) ? *reinterpret_cast<const half8 *>(src + (size_t)m * src_ps + n)
                                               : half8{0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
@@ -402,8 +431,9 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     }
   #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + fr;
-      if (m >= p.M) continue;
+      const int mr = m0 + wm * WTM + i * 16 + fr;
+      if (mr >= Mrows) continue;
+      const int m = row_pixel(mr);        // flat destination pixel (the GEMM row itself unless the rows run class by class)
   #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         const int n = n0 + wn * WTN + jp * 32 + fq * 8;
@@ -577,7 +607,7 @@ ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConf
 
 template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false>
 static void launch_one(const ConvParams &p, hipStream_t s) {
-  const int mtiles = sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
+  const int mtiles = (DGRAD && p.cls && BM * BN <= 160 * 128) ? 4 * sn_div_up(p.cls_mc, BM) : sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
   const dim3 grid(sn_div_up(mtiles, 8) * 8 * ntiles);
   hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, p, mtiles, ntiles);
 }

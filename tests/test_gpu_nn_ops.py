@@ -541,6 +541,67 @@ def test_conv_dgrad_bn_epilogue(N, H, C, O, K, bm, act, monkeypatch, conv_tuning
     assert np.abs(g0).max() > 0
 
 
+@pytest.mark.parametrize('N,C,H,W,O,K,pad', [(2, 256, 32, 32, 128, 1, 0), (3, 128, 40, 72, 64, 3, 1), (20, 256, 64, 64, 256, 3, 1),
+                                             (20, 512, 64, 64, 1024, 1, 0), (2, 128, 24, 16, 192, 3, 1), (1, 64, 6, 10, 128, 5, 2)])
+def test_stride2_dgrad_by_parity_class_equals_every_tap_walk(N, C, H, W, O, K, pad, conv_tuning):
+    """The data gradient of a stride-2 convolution enumerated parity class by parity class (each class only the taps that reach it:
+    ConvParams::cls) against the walk over every tap for every pixel (sn_conv_dgrad_by_class(0)): dx BIT-equal (the skipped taps
+    contributed exact zeros), with an accumulate operand, through the fused BatchNorm-backward epilogue (per-channel sums of the
+    partials equal; the row tiles are grouped differently), for the 1x1 shortcut (three classes receive no tap at all), 3x3 and 5x5
+    kernels, the C2 launch shapes of stage3_unit1, and every tile configuration that takes such layers."""
+    hip = _hip()
+    rs = np.random.RandomState(N * C + K)
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    Op = (O + 7) // 8 * 8
+    dy = torch.zeros((N, Ho, Wo, Op), dtype=torch.float16, device=dev())
+    dy[..., :O] = torch.from_numpy(rs.standard_normal((N, Ho, Wo, O)).astype(np.float32)).to(dev()).half()
+    wt = torch.zeros((C, K * K, Op), dtype=torch.float16, device=dev())
+    wt[..., :O] = torch.from_numpy((rs.standard_normal((C, K * K, O)) / np.sqrt(K * K * O)).astype(np.float32)).to(dev()).half()
+    acc = torch.from_numpy(rs.standard_normal((N, H, W, C)).astype(np.float32)).to(dev()).half()
+    bnx = torch.from_numpy(rs.standard_normal((N, H, W, C)).astype(np.float32)).to(dev()).half()
+    f = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev())
+    scale, shift, mean = f(rs.uniform(0.5, 1.5, C)), f(rs.uniform(-0.5, 0.5, C)), f(rs.standard_normal(C) * 0.1)
+    geom = (N, H, W, C, C, Op, Op)
+    try:
+        for cfg in ((-1, 14, 16, 5) if N <= 3 else (-1,)):
+            hip.call('sn_conv_tune', cfg)
+            res = {}
+            for on in (0, 1):
+                hip.call('sn_conv_dgrad_by_class', on)
+                dx = torch.full((N, H, W, C), 7.0, dtype=torch.float16, device=dev())
+                hip.call('sn_conv_dgrad', dy, wt, None, dx, *geom, 0, K, K, 2, pad, 1, 0, hip.stream())
+                dxa = torch.full((N, H, W, C), 7.0, dtype=torch.float16, device=dev())
+                hip.call('sn_conv_dgrad', dy, wt, acc, dxa, *geom, C, K, K, 2, pad, 1, 0, hip.stream())
+                nblk = hip.query('sn_conv_dgrad_bn_blocks', *geom, 0, K, K, 2, pad, 1)
+                part, dxb = None, None
+                if nblk > 0:
+                    part = torch.full((nblk, 2, C), 7.0, dtype=torch.float32, device=dev())
+                    dxb = torch.full((N, H, W, C), 7.0, dtype=torch.float16, device=dev())
+                    hip.call('sn_conv_dgrad_bn', dy, wt, None, dxb, *geom, 0, K, K, 2, pad, 1, bnx, C, scale, shift, mean, 1, part,
+                             hip.stream())
+                torch.cuda.synchronize()
+                res[on] = (dx, dxa, dxb, part, nblk)
+            (dx0, dxa0, dxb0, p0, n0), (dx1, dxa1, dxb1, p1, n1) = res[0], res[1]
+            assert torch.equal(dx0, dx1) and torch.equal(dxa0, dxa1), (cfg, 'dx')
+            assert float(dx1.float().abs().max()) > 0
+            if cfg == -1 and H % 2 == 0 and W % 2 == 0:
+                assert (n0 > 0) == (n1 > 0)
+            if n0 > 0 and n1 > 0:
+                assert torch.equal(dxb0, dxb1) and torch.equal(dxb1, dx1), (cfg, 'dx of the fused entry')
+                assert n1 >= n0                                  # four classes, each with its own ragged last tile
+                s0, s1 = p0.double().sum(0).cpu().numpy(), p1.double().sum(0).cpu().numpy()
+                assert_close(s1, s0, 1e-5, 1e-4 * np.abs(s0).max(), 'BatchNorm-backward sums by class')
+    finally:
+        hip.call('sn_conv_dgrad_by_class', 1)
+    # the oracle on the smallest shapes (the every-tap walk has its own oracle tests: test_conv_dgrad_wgrad)
+    if N <= 3:
+        xt = torch.zeros((N, C, H, W), requires_grad=True)
+        w_oihw = wt[..., :O].float().cpu().permute(2, 0, 1).reshape(O, C, K, K)
+        Fnn.conv2d(xt, w_oihw, None, 2, pad).backward(dy[..., :O].float().cpu().permute(0, 3, 1, 2))
+        want = xt.grad.numpy()
+        assert_close(from_nhwc(dx1), want, 1e-2, 1e-2 * np.abs(want).max(), 'dgrad by class vs torch')
+
+
 def test_weight_transpose_batched_equals_single():
     """sn_weight_transpose_batched (one launch, LDS-tiled) against sn_weight_transpose per weight: ragged O / I, taps, O_pad."""
     hip = _hip()

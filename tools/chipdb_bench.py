@@ -37,7 +37,10 @@ def build(n_images, route, seed=7):
     it = ref_it.MNIteratorE2E.__new__(ref_it.MNIteratorE2E)
     it.roidb, it.cfg, it.batch_size, it.epiter = roidb, config, 20, 0
     np.random.seed(seed)
-    it.pool = ref_it.Pool(config.TRAIN.NUM_PROCESS)
+    # un-routed: ONE pool thread, so that the work items draw their candidate permutations from numpy's global generator in
+    # roidb order like the batched call does (with 64 threads -- or the reference's 64 forked processes, each with its own copy
+    # of the generator -- the order, hence the database, differs from run to run)
+    it.pool = ref_it.Pool(config.TRAIN.NUM_PROCESS if route else 1)
     it.chip_worker = dw.chip_worker(chip_size=512, cfg=config)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -80,7 +83,8 @@ def main():
                    'GPU launch',
            'unrouted': {'value': round(chips_p / dt_p, 1), 'images': n_plain, 'seconds': round(dt_p, 3), 'routed_maps': routed_p,
                         'routed_same_subset_chips_per_s': round(chips_s / dt_s, 1),
-                        'what': 'same call with SNIPER_POOL_ROUTE=0: every work item on a pool thread (the round-3 behaviour)'},
+                        'what': 'same call with SNIPER_POOL_ROUTE=0 on a pool of one thread: every work item its own kernel launch + read-back (the '
+                                'round-3 behaviour; its 64 threads ran one at a time under the interpreter lock anyway)'},
            'routed_equals_unrouted': bool(same)}
     print(json.dumps(out))
 
