@@ -81,6 +81,17 @@ def conv_flops(name, a):
     return 2.0 * N * Ho * Wo * Cout * Cin * KH * KW
 
 
+def conv_shape(name, a):
+    """(N, H, W, Cin, Cout, K, stride, dil) of a single-layer conv entry (forward: input dims; data gradient: dx dims), else None."""
+    if name in ('sn_conv_fwd', 'sn_conv_fwd_stats'):
+        N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[5:18]
+    elif name in ('sn_conv_dgrad', 'sn_conv_dgrad_bn'):
+        N, H, W, Cin, _, Cout, _, _, KH, KW, s, p, d = a[4:17]
+    else:
+        return None
+    return (int(N), int(H), int(W), int(Cin), int(Cout), int(KH), int(s), int(d))
+
+
 class ConvProfiler(object):
     """Wraps sniper_amd.hip.call: brackets every conv-family launch with HIP events recorded on the
     stream the kernel is launched on (torch's current stream)."""
@@ -99,7 +110,7 @@ class ConvProfiler(object):
                 e0.record()
                 r = self.orig(name, *args)
                 e1.record()
-                self.records.append((name, conv_flops(name, args), e0, e1))
+                self.records.append((name, conv_flops(name, args), e0, e1, conv_shape(name, args)))
                 return r
             return self.orig(name, *args)
         self.hip.call = call
@@ -130,7 +141,8 @@ class ConvProfiler(object):
         over = self.bracket_overhead_ms()
         self.overhead_ms = over
         tot_ms, tot_fl, per = 0.0, 0.0, {}
-        for name, fl, e0, e1 in self.records:
+        self.by_shape = {}
+        for name, fl, e0, e1, shape in self.records:
             ms = max(e0.elapsed_time(e1) - over, 0.0)
             tot_ms += ms
             tot_fl += fl
@@ -138,7 +150,19 @@ class ConvProfiler(object):
             d[0] += 1
             d[1] += ms
             d[2] += fl
+            if shape is not None:
+                b = self.by_shape.setdefault((name,) + shape, [0, 0.0, 0.0])
+                b[0] += 1
+                b[1] += ms
+                b[2] += fl
         return tot_ms, tot_fl, per
+
+    def shape_table(self, steps, top=28):
+        """In-situ time per (entry, layer shape), largest first: which layers the family's time is in and at what rate."""
+        rows = sorted(self.by_shape.items(), key=lambda kv: -kv[1][1])[:top]
+        return [{'entry': k[0], 'shape': 'N%d %dx%d C%d->%d k%d s%d d%d' % k[1:], 'launches_per_step': v[0] // steps,
+                 'us_per_launch': round(v[1] / v[0] * 1e3, 1), 'ms_per_step': round(v[1] / steps, 3),
+                 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in rows]
 
 
 def device_identity(index=0):
@@ -592,6 +616,7 @@ def main():
                 step(i)
             res = prof.summary()
             profile.overhead_us = prof.overhead_ms * 1e3
+            profile.by_shape = prof.shape_table(2)
             return res
     tot_ms, tot_fl, per = profile()                 # in situ: the kernels and the stream of the timed region, launched eagerly
     iso_ms, iso_fl, iso_per = tot_ms, tot_fl, per   # (one stream since round 3: a launch's duration is its own)
@@ -614,6 +639,7 @@ def main():
             'avg_launch_ms': round(tot_ms / max(1, n_launch), 4),
             'gflop_per_step': round(tot_fl / 2 / 1e9, 1), 'conv_ms_per_step': round(tot_ms / 2, 3),
             'conv_ms_per_step_isolated': round(iso_ms / 2, 3),
+            'by_shape': profile.by_shape,
             'by_entry': {k: {'launches': v[0] // 2, 'ms_per_step': round(v[1] / 2, 3),
                              'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in per.items()}}
     cpu = None

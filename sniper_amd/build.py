@@ -14,8 +14,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
-OBJ_DIR = os.path.join(OUT_DIR, "obj")
-LIB = os.path.join(OUT_DIR, "libsniper_hip.so")
+# A/B builds of the whole library (tools/ab.sh loads them through SNIPER_HIP_LIB): SNIPER_BUILD_SUFFIX=_x SNIPER_BUILD_DEFS="-DSN_X=1"
+# compiles into lib/obj_x and links lib/libsniper_hip_x.so; without them this is the one library the package loads.
+_SUFFIX = os.environ.get("SNIPER_BUILD_SUFFIX", "")
+_DEFS = os.environ.get("SNIPER_BUILD_DEFS", "").split()
+OBJ_DIR = os.path.join(OUT_DIR, "obj" + _SUFFIX)
+LIB = os.path.join(OUT_DIR, "libsniper_hip%s.so" % _SUFFIX)
 ARCH = "gfx950"
 
 # per-file extra flags: the bit-exact integer/box kernels must not contract a*b+c into FMA
@@ -70,7 +74,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ_DIR, os.path.splitext(f)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, src):
-            jobs.append([hipcc] + BASE + EXTRA.get(f, []) + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + BASE + _DEFS + EXTRA.get(f, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
             half8 o;
   #pragma unroll
             for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
+            // (non-temporal stores measured: no difference in the step, profiles/r04_ab_class_nt_fold.txt)
             *reinterpret_cast<half8 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + n) = o;
             if (p.stats) {
               bool done = false;

@@ -504,13 +504,12 @@ __device__ __forceinline__ unsigned hash_key(unsigned long long seed, unsigned b
 
 constexpr int kFinishThreads = 1024;
 
-// Block-wide: among anchors with label_pre == which, find the `keep`-th smallest 47-bit key
-// (key32 << 15 | idx).  Returns the threshold; entries with composite <= threshold are kept.
-// Requires keep >= 1 and keep < population.  MSB-first radix select, 8 bits per pass.
-__device__ unsigned long long radix_select_kth(const int8_t *__restrict__ label_pre, const uint32_t *__restrict__ keys,
-                                               unsigned long long seed, int b, int total, int which, int keep,
-                                               unsigned *hist /*256, shared*/, unsigned long long *sh_prefix,
-                                               int *sh_keep) {
+// Block-wide: among a population of 47-bit composites (key32 << 15 | idx), find the `keep`-th smallest.  Returns the threshold;
+// entries with composite <= threshold are kept.  Requires keep >= 1 and keep < population.  MSB-first radix select, 8 bits per
+// pass.  each(fn) calls fn(composite) for every member of the population this thread holds.
+template <typename Each>
+__device__ __forceinline__ unsigned long long radix_select_kth(Each each, int keep, unsigned *hist /*256, shared*/,
+                                                               unsigned long long *sh_prefix, int *sh_keep) {
   const int tid = threadIdx.x;
   unsigned long long prefix = 0;  // bits decided so far (left-aligned in the 48-bit field)
   int k = keep;                   // rank (1-based) inside the current bucket
@@ -518,12 +517,9 @@ __device__ unsigned long long radix_select_kth(const int8_t *__restrict__ label_
     for (int i = tid; i < 256; i += kFinishThreads) hist[i] = 0;
     __syncthreads();
     const unsigned long long hi_mask = shift == 40 ? 0ull : (~0ull << (shift + 8));
-    for (int idx = tid; idx < total; idx += kFinishThreads) {
-      if (label_pre[idx] != which) continue;
-      const unsigned kk = keys ? keys[(size_t)b * total + idx] : hash_key(seed, b, idx);
-      const unsigned long long comp = ((unsigned long long)kk << 15) | (unsigned)idx;
+    each([&](unsigned long long comp) {
       if ((comp & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(comp >> shift) & 0xffu], 1u);
-    }
+    });
     __syncthreads();
     // the bucket that holds rank k: first bin whose inclusive count reaches k.  One wave, four bins per lane, shuffle scan
     // (a single thread walking the 256 LDS bins took ~7 us per pass, 12 passes per chip: most of this kernel's 157 us)
@@ -555,6 +551,11 @@ __device__ unsigned long long radix_select_kth(const int8_t *__restrict__ label_
   return prefix;
 }
 
+// Round 4: the chip's (label, composite key) pairs are read / hashed ONCE into registers (21 per thread for the training map's
+// 21 504 anchors); the counting pass, the up to twelve radix passes of the two selections and the output pass run on them.
+// Each pass used to re-read the 1-byte labels with a dependent L2 load per iteration and re-hash every key (124 us per 20 chips).
+constexpr int kFinishReg = 24;       // anchors per thread held in registers (x 1024 threads); larger maps stream
+
 __global__ __launch_bounds__(kFinishThreads) void anchor_finish_kernel(
     const double *__restrict__ base, int A, int F, int stride, int rpn_batch, int num_fg,
     const uint32_t *__restrict__ keys, unsigned long long seed, char *__restrict__ ws, AnchorWsLayout L,
@@ -573,16 +574,55 @@ __global__ __launch_bounds__(kFinishThreads) void anchor_finish_kernel(
   __shared__ int cnt[3];
   if (tid < 3) cnt[tid] = 0;
   __syncthreads();
+  const bool in_regs = total <= kFinishReg * kFinishThreads;
+  // creg[u]: anchor idx = u * 1024 + tid: bits 0-46 the composite (key32 << 15 | idx), bits 60-61 the class (1 fg, 2 bg, 0 neither)
+  unsigned long long creg[kFinishReg];
+  auto composite = [&](int idx) {
+    const unsigned kk = keys ? keys[(size_t)b * total + idx] : hash_key(seed, b, idx);
+    return ((unsigned long long)kk << 15) | (unsigned)idx;
+  };
   int c_in = 0, c_fg = 0, c_bg = 0;
-  for (int idx = tid; idx < total; idx += kFinishThreads) {
-    const int l = lp[idx];
-    c_in += (l != -2);
-    c_fg += (l == 1);
-    c_bg += (l == 0);
-    if (label_pre_out) label_pre_out[(size_t)b * total + idx] = (int8_t)l;
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < kFinishReg; ++u) {
+      const int idx = u * kFinishThreads + tid;
+      creg[u] = 0ull;
+      if (idx < total) {
+        const int l = lp[idx];
+        c_in += (l != -2);
+        c_fg += (l == 1);
+        c_bg += (l == 0);
+        if (label_pre_out) label_pre_out[(size_t)b * total + idx] = (int8_t)l;
+        if (l == 1 || l == 0) creg[u] = composite(idx) | ((unsigned long long)(l == 1 ? 1 : 2) << 60);
+      }
+    }
+  } else {
+    for (int idx = tid; idx < total; idx += kFinishThreads) {
+      const int l = lp[idx];
+      c_in += (l != -2);
+      c_fg += (l == 1);
+      c_bg += (l == 0);
+      if (label_pre_out) label_pre_out[(size_t)b * total + idx] = (int8_t)l;
+    }
   }
   atomicAdd(&cnt[0], c_in); atomicAdd(&cnt[1], c_fg); atomicAdd(&cnt[2], c_bg);
   __syncthreads();
+  // the population of class `which` (1 = fg, 0 = bg) held by this thread
+  auto select = [&](int which, int keep) {
+    const unsigned long long tag = (unsigned long long)(which == 1 ? 1 : 2) << 60;
+    return radix_select_kth(
+        [&](auto fn) {
+          if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < kFinishReg; ++u)
+              if ((creg[u] >> 60) == (tag >> 60)) fn(creg[u] & ((1ull << 47) - 1ull));
+          } else {
+            for (int idx = tid; idx < total; idx += kFinishThreads)
+              if (lp[idx] == which) fn(composite(idx));
+          }
+        },
+        keep, hist, &sh_prefix, &sh_keep);
+  };
   const int n_fg = cnt[1], n_bg = cnt[2];
   if (tid == 0) {
     counts[4 * b + 0] = cnt[0]; counts[4 * b + 1] = n_fg; counts[4 * b + 2] = n_bg; counts[4 * b + 3] = hdr->nvalid;
@@ -590,7 +630,7 @@ __global__ __launch_bounds__(kFinishThreads) void anchor_finish_kernel(
   // data_workers.py:327-331 -- keep at most num_fg foreground anchors
   bool sub_fg = n_fg > num_fg;
   unsigned long long thr_fg = ~0ull, thr_bg = ~0ull;
-  if (sub_fg) thr_fg = radix_select_kth(lp, keys, seed, b, total, 1, num_fg, hist, &sh_prefix, &sh_keep);
+  if (sub_fg) thr_fg = select(1, num_fg);
   // :333-338 -- background fills the rest of the batch
   const int fg_after = sub_fg ? num_fg : n_fg;
   const int num_bg = rpn_batch - fg_after;
@@ -598,7 +638,7 @@ __global__ __launch_bounds__(kFinishThreads) void anchor_finish_kernel(
   bool drop_all_bg = false;
   if (sub_bg) {
     if (num_bg <= 0) drop_all_bg = true;
-    else thr_bg = radix_select_kth(lp, keys, seed, b, total, 0, num_bg, hist, &sh_prefix, &sh_keep);
+    else thr_bg = select(0, num_bg);
   }
   // dense outputs in the reference's batch layouts; o walks the (a, y, x) label order
   const int FF = F * F;

@@ -132,14 +132,19 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(const unsigned l
 // Same predicate (dev_iou(a, b) > thresh, symmetric bit for bit), same greedy order -> the same survivor list as the
 // mask + scan pair; work ~ (candidates examined) x (survivors) instead of N^2 / 2.
 constexpr int kLazyMaxKeep = 1024;
+// Round 4: 16 waves per image instead of 4 (one workgroup per image leaves 236 of 256 CUs idle whatever it does, so the only lever
+// is the latency of ONE workgroup: the survivor sweep of step 1 and the triangle of step 2 are split over four times the waves),
+// and step 3 visits only the candidates that are still alive (lowest set bit of `alive & ~suppressed`, one iteration per new
+// survivor) instead of all 64 rows: 259 us -> see profiles/r04_*.
+constexpr int kLazyThreads = 1024, kLazyWaves = kLazyThreads / 64, kLazyCols = 64 / kLazyWaves;
 
-__global__ __launch_bounds__(256) void nms_lazy_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ n_per, int N,
-                                                       int dim, float thresh, int max_keep, int32_t *__restrict__ keep,
-                                                       int32_t *__restrict__ nkeep) {
+__global__ __launch_bounds__(kLazyThreads) void nms_lazy_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ n_per,
+                                                                int N, int dim, float thresh, int max_keep,
+                                                                int32_t *__restrict__ keep, int32_t *__restrict__ nkeep) {
   __shared__ float kb[kLazyMaxKeep * 4];
   __shared__ float cand[64 * 4];
-  __shared__ unsigned long long dead_w[4];
-  __shared__ unsigned dpart[4][64];
+  __shared__ unsigned long long dead_w[kLazyWaves];
+  __shared__ unsigned dpart[kLazyWaves][64];
   __shared__ int nk_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = n_per ? min(n_per[b], N) : N;
@@ -160,38 +165,40 @@ __global__ __launch_bounds__(256) void nms_lazy_kernel(const float *__restrict__
     const bool in = lane < csize;
     float me[4] = {0.f, 0.f, 0.f, 0.f};
     if (in) { me[0] = cand[lane * 4]; me[1] = cand[lane * 4 + 1]; me[2] = cand[lane * 4 + 2]; me[3] = cand[lane * 4 + 3]; }
-    // 1. suppressed by an earlier survivor?
+    // 1. suppressed by an earlier survivor?  (wave w takes survivors w, w + 16, ...)
     bool dead = false;
-    for (int k = wave; k < nk; k += 4) dead = dead || (dev_iou(kb + k * 4, me) > thresh);
+    for (int k = wave; k < nk; k += kLazyWaves) dead = dead || (dev_iou(kb + k * 4, me) > thresh);
     const unsigned long long dw = __ballot(dead && in);
     if (lane == 0) dead_w[wave] = dw;
-    // 2. this wave's 16 columns of the chunk's upper triangle
+    // 2. this wave's columns of the chunk's upper triangle
     unsigned bits = 0u;
     if (in) {
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = wave * 16 + jj;
+#pragma unroll
+      for (int jj = 0; jj < kLazyCols; ++jj) {
+        const int j = wave * kLazyCols + jj;
         if (j > lane && j < csize && dev_iou(me, cand + j * 4) > thresh) bits |= 1u << jj;
       }
     }
     dpart[wave][lane] = bits;
     __syncthreads();
-    // 3. sequential resolution of the chunk (wave 0), as in nms_scan_kernel
+    // 3. sequential resolution of the chunk (wave 0), as in nms_scan_kernel: walk the candidates still alive in order
     if (wave == 0) {
-      const unsigned long long diag = (unsigned long long)dpart[0][lane] | ((unsigned long long)dpart[1][lane] << 16) |
-                                      ((unsigned long long)dpart[2][lane] << 32) | ((unsigned long long)dpart[3][lane] << 48);
-      const unsigned long long alive = __ballot(in) & ~(dead_w[0] | dead_w[1] | dead_w[2] | dead_w[3]);
-      unsigned long long sup = 0ull, kept = 0ull;
+      unsigned long long diag = 0ull, dead_all = 0ull;
+#pragma unroll
+      for (int w = 0; w < kLazyWaves; ++w) {
+        diag |= (unsigned long long)dpart[w][lane] << (w * kLazyCols);
+        dead_all |= dead_w[w];
+      }
+      unsigned long long avail = __ballot(in) & ~dead_all, kept = 0ull;
       int nk2 = nk;
-      for (int r = 0; r < 64; ++r) {  // wave-uniform loop
+      while (avail != 0ull && nk2 < max_keep) {      // wave-uniform loop: one iteration per new survivor
+        const int r = __ffsll((long long)avail) - 1;
         const unsigned long long d =
             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(diag >> 32), r) << 32) |
             (unsigned)__builtin_amdgcn_readlane((int)(diag & 0xffffffffu), r);
-        const bool take = ((alive >> r) & 1ull) && !((sup >> r) & 1ull) && nk2 < max_keep;
-        if (take) {
-          kept |= 1ull << r;
-          sup |= d;
-          ++nk2;
-        }
+        kept |= 1ull << r;
+        avail &= ~(d | (1ull << r));       // row r's bits are columns j > r: everything it suppresses leaves the list
+        ++nk2;
       }
       if ((kept >> lane) & 1ull) {
         const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
@@ -223,7 +230,7 @@ SN_EXPORT int sn_nms_batch(const float *d_boxes, const int32_t *d_n, int B, int 
   }
   SN_REQUIRE(d_boxes && d_keep, "sn_nms_batch: null pointer");
   if (max_keep <= kLazyMaxKeep && max_keep * 4 <= N && !sn_debug_get(SN_OPT_NMS_FULL_MASK)) {
-    hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(256), 0, s, d_boxes, d_n, N, dim, thresh, max_keep, d_keep, d_nkeep);
+    hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(kLazyThreads), 0, s, d_boxes, d_n, N, dim, thresh, max_keep, d_keep, d_nkeep);
     SN_CHECK_LAUNCH();
     return SN_OK;
   }

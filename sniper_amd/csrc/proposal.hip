@@ -107,7 +107,12 @@ __global__ __launch_bounds__(1024) void bitonic_sort_kernel(unsigned long long *
 //   2. compaction of the keys <= that key into LDS (any order), padded with ~0 to a power of two;
 //   3. bitonic sort of those <= 16 384 keys in LDS; the first K go back to keys[0..K).
 // One workgroup per image, every pass reads the image's keys (L2-resident, coalesced); 907 us -> see profiles/.
-constexpr int kSelThreads = 1024;
+// Round 4: REG = the image's keys are read from global memory ONCE into registers (n <= 32 keys per thread: the training map's
+// 21 504 anchors are 21) and every radix pass and the compaction run on them -- each pass used to re-read the 172 KB with one
+// dependent L2 load per iteration (the passes, not the sort, were most of the 147 us).  Larger maps (test images at the finest
+// scale: 231 k anchors) keep the streaming form.
+constexpr int kSelThreads = 1024, kSelRegKeys = 32;
+template <bool REG>
 __global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned long long *__restrict__ keys, int n, int K, int P2) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sel_buf[];   // [P2]
   __shared__ unsigned hist[256];
@@ -115,6 +120,15 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned 
   __shared__ int s_need, s_cnt, s_done;
   unsigned long long *k = keys + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x;
+  unsigned long long kreg[REG ? kSelRegKeys : 1];
+  if constexpr (REG) {
+#pragma unroll
+    for (int u = 0; u < kSelRegKeys; ++u) {
+      const int i = u * kSelThreads + tid;
+      kreg[u] = i < n ? k[i] : 0ull;
+    }
+  }
+  const int iters = REG ? (n + kSelThreads - 1) / kSelThreads : 0;
   if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_need = K; s_cnt = 0; s_done = 0; }
   __syncthreads();
   for (int shift = 56; shift >= 0; shift -= 8) {
@@ -122,7 +136,28 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned 
     __syncthreads();
     if (s_done) break;
     const unsigned long long prefix = s_prefix, mask = s_mask;
-    for (int i = tid; i < n; i += kSelThreads) {
+    auto count = [&](unsigned long long key, bool valid) {
+      const bool in = valid && (key & mask) == prefix;
+      const unsigned d = (unsigned)(key >> shift) & 255u;
+      // scores cluster in a few exponent buckets: when the whole wave agrees, one atomic instead of 64 serialised ones
+      const unsigned long long act = __ballot(in);
+      if (act) {
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned d0 = (unsigned)__shfl((int)d, leader, 64);
+        const bool same = __ballot(in && d == d0) == act;
+        if (same) {
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d0], (unsigned)__popcll(act));
+        } else if (in) {
+          atomicAdd(&hist[d], 1u);
+        }
+      }
+    };
+    if constexpr (REG) {
+#pragma unroll
+      for (int u = 0; u < kSelRegKeys; ++u)
+        if (u < iters) count(kreg[u], u * kSelThreads + tid < n);       // (u < iters is wave-uniform: the ballots see whole waves)
+    }
+    for (int i = tid; !REG && i < n; i += kSelThreads) {
       const unsigned long long key = k[i];
       const bool in = (key & mask) == prefix;
       const unsigned d = (unsigned)(key >> shift) & 255u;
@@ -162,7 +197,15 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned 
   const unsigned long long kth = s_prefix;     // keys <= kth are exactly the K smallest
   for (int i = tid; i < P2; i += kSelThreads) sel_buf[i] = ~0ull;
   __syncthreads();
-  for (int i = tid; i < n; i += kSelThreads) {
+  if constexpr (REG) {
+#pragma unroll
+    for (int u = 0; u < kSelRegKeys; ++u)
+      if (u * kSelThreads + tid < n && kreg[u] <= kth) {
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < P2) sel_buf[pos] = kreg[u];
+      }
+  }
+  for (int i = tid; !REG && i < n; i += kSelThreads) {
     const unsigned long long key = k[i];
     if (key <= kth) {
       const int pos = atomicAdd(&s_cnt, 1);
@@ -296,8 +339,13 @@ static int proposal_common(const float *cls_prob, const float *bbox_pred, const 
   const int P2 = next_pow2(L.pre);
   if (P2 <= 16384 && L.pre < L.sort_n && !sn_debug_get(SN_OPT_PROPOSAL_FULL_SORT)) {
     // > 64 KB of dynamic LDS needs the opt-in once per (kernel, device)
-    SN_HIP(sn_once_per_device_max_lds(reinterpret_cast<const void *>(topk_select_sort_kernel), 16384 * 8));
-    hipLaunchKernelGGL(topk_select_sort_kernel, dim3(B), dim3(kSelThreads), (size_t)P2 * 8, s, keys, L.sort_n, L.pre, P2);
+    if (L.sort_n <= kSelRegKeys * kSelThreads) {
+      SN_HIP(sn_once_per_device_max_lds(reinterpret_cast<const void *>(topk_select_sort_kernel<true>), 16384 * 8));
+      hipLaunchKernelGGL(topk_select_sort_kernel<true>, dim3(B), dim3(kSelThreads), (size_t)P2 * 8, s, keys, L.sort_n, L.pre, P2);
+    } else {
+      SN_HIP(sn_once_per_device_max_lds(reinterpret_cast<const void *>(topk_select_sort_kernel<false>), 16384 * 8));
+      hipLaunchKernelGGL(topk_select_sort_kernel<false>, dim3(B), dim3(kSelThreads), (size_t)P2 * 8, s, keys, L.sort_n, L.pre, P2);
+    }
   } else {
     hipLaunchKernelGGL(bitonic_sort_kernel, dim3(B), dim3(1024), 0, s, keys, L.sort_n);
   }
