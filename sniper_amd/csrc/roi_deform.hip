@@ -170,7 +170,7 @@ struct RoiStage {
 };
 // union of the bins' windows -> s (thread 0 publishes; called by every thread between two barriers)
 template <typename BW>
-__device__ __forceinline__ void roi_stage_plan(const BW *win, int nb, int C, int *s_mm, RoiStage *s) {
+__device__ __forceinline__ void roi_stage_plan(const BW *win, int nb, int C, int *s_mm, RoiStage *s, int stage_on) {
   // s_mm = {min x, min y, max x, max y, any slow bin}, reset by thread 0 before the barrier that precedes this call
   if ((int)threadIdx.x < nb) {
     const BW &b = win[threadIdx.x];
@@ -183,10 +183,12 @@ __device__ __forceinline__ void roi_stage_plan(const BW *win, int nb, int C, int
   __syncthreads();
   if (threadIdx.x == 0) {
     RoiStage t = {0, 0, 0, 0, 0};
-    if (!s_mm[4] && s_mm[2] >= s_mm[0] && s_mm[3] >= s_mm[1]) {
+    if (stage_on && !s_mm[4] && s_mm[2] >= s_mm[0] && s_mm[3] >= s_mm[1]) {
       t.x0 = s_mm[0]; t.y0 = s_mm[1]; t.nxw = s_mm[2] - s_mm[0] + 1; t.nyw = s_mm[3] - s_mm[1] + 1;
       const long cells = (long)t.nxw * t.nyw;
-      for (int sl = 1; sl <= 8 && !t.slices; sl <<= 1)
+      // at most two slices: a window that needs more (RoIs beyond ~11 cells a side) pays a copy, two barriers and a quarter-full
+      // item round per slice -- measured 2x SLOWER than the direct gathers with up to eight slices (profiles/r04_*)
+      for (int sl = 1; sl <= 2 && !t.slices; sl <<= 1)
         if (C % (8 * sl) == 0 && cells * (C / sl) * 2 <= kStageBytes) t.slices = sl;
     }
     *s = t;
@@ -197,9 +199,10 @@ __device__ __forceinline__ void roi_stage_plan(const BW *win, int nb, int C, int
 __device__ __forceinline__ void roi_stage_copy(const half_t *__restrict__ img0, half_t *lds, const RoiStage &st, int W, int C, int c0,
                                                int Cs) {
   const int cps = Cs >> 3, n = st.nxw * st.nyw * cps;
+  const float inv_cps = 1.f / (float)cps, inv_nxw = 1.f / (float)st.nxw;      // (exact for these small integers: + 0.5 guards the floor)
   for (int idx = threadIdx.x; idx < n; idx += 256) {
-    const int cell = idx / cps, chunk = idx - cell * cps;
-    const int cy = cell / st.nxw, cx = cell - cy * st.nxw;
+    const int cell = (int)(((float)idx + 0.5f) * inv_cps), chunk = idx - cell * cps;
+    const int cy = (int)(((float)cell + 0.5f) * inv_nxw), cx = cell - cy * st.nxw;
     *reinterpret_cast<half8 *>(lds + (size_t)cell * Cs + chunk * 8) =
         *reinterpret_cast<const half8 *>(img0 + ((size_t)(st.y0 + cy) * W + st.x0 + cx) * C + c0 + chunk * 8);
   }
@@ -207,7 +210,7 @@ __device__ __forceinline__ void roi_stage_copy(const half_t *__restrict__ img0, 
 
 __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
                                                              const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
-                                                             int W, int C, int P, int S, float scale, float trans_std) {
+                                                             int W, int C, int P, int S, float scale, float trans_std, int stage_on) {
   __shared__ BinWin win[kBinsMax];
   __shared__ int s_b;
   __shared__ int s_mm[5];
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
   half_t *orow = out + (size_t)r * nb * C;
-  roi_stage_plan(win, nb, C, s_mm, &s_stage);
+  roi_stage_plan(win, nb, C, s_mm, &s_stage, stage_on);
   const RoiStage st = s_stage;
   if (st.slices) {
     // ---- staged: a channel slice of the whole window in LDS, then every (bin, chunk) item of the slice from LDS
@@ -788,7 +791,7 @@ struct BinWinD {
 __global__ __launch_bounds__(256) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                    const float *__restrict__ rois, const float *__restrict__ trans,
                                                                    float *__restrict__ d_trans, int R, int H, int W, int C, int P,
-                                                                   int S, float scale, float trans_std) {
+                                                                   int S, float scale, float trans_std, int stage_on) {
   __shared__ BinWinD win[kBinsMax];
   __shared__ int s_b;
   __shared__ int s_mm[5];
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(256) void dpsroi_bwd_trans_roi_kernel(const half_t 
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
   const half_t *grow = dout + (size_t)r * nb * C;
-  roi_stage_plan(win, nb, C, s_mm, &s_stage);
+  roi_stage_plan(win, nb, C, s_mm, &s_stage, stage_on);
   const RoiStage st = s_stage;
   if (st.slices) {
     // ---- staged (see dpsroi_fwd_roi_kernel): a channel slice of the RoI's window in LDS; the slices' partial sums of a bin are
@@ -953,7 +956,7 @@ SN_EXPORT int sn_dpsroi_pool_fwd(const void *data, const float *rois, const floa
              "sn_dpsroi_pool_fwd: bad arguments (sample_per_part <= %d)", kMaxS);
   if (pooled * pooled <= kBinsMax)
     hipLaunchKernelGGL(dpsroi_fwd_roi_kernel, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
-                       (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+                       (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, sn_debug_get(SN_OPT_DPSROI_NO_STAGE) ? 0 : 1);
   else
     hipLaunchKernelGGL(dpsroi_fwd_kernel, dim3((unsigned)blocks_for((long)R * pooled * pooled * (C / 8))), dim3(256), 0,
                        sn_stream(stream), (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part,
@@ -993,7 +996,8 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
     const long total = (long)R * pooled * pooled * cpr;
     if (pooled * pooled <= kBinsMax)
       hipLaunchKernelGGL(dpsroi_bwd_trans_roi_kernel, dim3((unsigned)R), dim3(256), 0, s, (const half_t *)dout, (const half_t *)data,
-                         rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+                         rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std,
+                         sn_debug_get(SN_OPT_DPSROI_NO_STAGE) ? 0 : 1);
     else
       hipLaunchKernelGGL(dpsroi_bwd_trans_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t *)dout,
                          (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);

@@ -616,7 +616,14 @@ class Executor(object):
                     raise ValueError('input %s has shape %s, bound shape %s' % (node.name, tuple(src.shape), v.shape))
                 if v.t is None:
                     v.t = self.empty(v.shape, F32)
-                v.t.copy_(src, non_blocking=True)
+                n = v.t.numel()
+                if (isinstance(src, torch.Tensor) and src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
+                        and n % 8 == 0 and src.data_ptr() % 16 == 0 and v.t.data_ptr() % 16 == 0):
+                    # one 16-byte-per-lane kernel per tensor: torch's device-to-device copy_ runs the 80 MB of a 20-chip step as
+                    # ~60 blit launches at ~0.3 TB/s (0.29 ms per step in the kernel trace)
+                    hip.call('sn_copy2d', src, v.t, 1, n, n, n, 1, 1, hip.stream())
+                else:
+                    v.t.copy_(src, non_blocking=True)
 
     def _forward_body(self):
         for v in self.vals.values():

@@ -602,6 +602,23 @@ def test_stride2_dgrad_by_parity_class_equals_every_tap_walk(N, C, H, W, O, K, p
         assert_close(from_nhwc(dx1), want, 1e-2, 1e-2 * np.abs(want).max(), 'dgrad by class vs torch')
 
 
+@pytest.mark.parametrize('rows,cols,in_ld,out_ld', [(1, 15728640, 15728640, 15728640), (5000, 1024, 1024, 3072), (333, 72, 80, 72), (7, 30, 33, 40),
+                                                    (1, 1000, 1000, 1000), (64, 8, 24, 16)])
+def test_copy2d_vectorised_and_scalar_paths(rows, cols, in_ld, out_ld):
+    """sn_copy2d (Concat slices, Cast, the step's input copies): the 8-elements-per-thread path (row length and pitches multiples
+    of 8 on 16-byte aligned pointers; a single row is a flat copy) and the scalar path, all four dtype pairs, against torch."""
+    hip = _hip()
+    rs = np.random.RandomState(rows + cols)
+    for in_dt, out_dt in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        ti, to = (torch.float16, torch.float32)[in_dt], (torch.float16, torch.float32)[out_dt]
+        src = torch.from_numpy(rs.standard_normal((rows, in_ld)).astype(np.float32)).to(dev()).to(ti)
+        dst = torch.full((rows, out_ld), 7.0, dtype=to, device=dev())
+        hip.call('sn_copy2d', src, dst, rows, cols, in_ld, out_ld, in_dt, out_dt, hip.stream())
+        want = torch.full((rows, out_ld), 7.0, dtype=to, device=dev())
+        want[:, :cols] = src[:, :cols].to(to)
+        assert torch.equal(dst, want), (rows, cols, in_dt, out_dt)
+
+
 def test_weight_transpose_batched_equals_single():
     """sn_weight_transpose_batched (one launch, LDS-tiled) against sn_weight_transpose per weight: ragged O / I, taps, O_pad."""
     hip = _hip()
