@@ -679,7 +679,10 @@ struct BinWinD {
   int x_lo, nx, y_lo, ny, slow;
   float kx, ky;     // trans_std / count * roi_w, ... * roi_h
 };
-__global__ __launch_bounds__(256) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
+// Occupancy (round 4, profiles/r04_kab_roi_occupancy.txt): both per-RoI gather kernels compile to 110 - 120 VGPRs = 4 waves per
+// SIMD.  Capped at 64 VGPRs (8 waves, ~170 B of scratch per lane) this kernel runs 253 -> 211 us; the forward gets SLOWER
+// (154 -> 211 / 267 us at 6 / 8 waves: its 4 x 4 window of loads spills), so only this one carries the cap.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                    const float *__restrict__ rois, const float *__restrict__ trans,
                                                                    float *__restrict__ d_trans, int R, int H, int W, int C, int P,
                                                                    int S, float scale, float trans_std) {
