@@ -43,11 +43,16 @@ def test_hot_kernels_keep_their_accumulators_in_registers():
         # 8 consumers + 4 producers) has three waves per SIMD, i.e. at most 168 registers each
         wide = 'ELi3ELi2E' in name
         assert res['ScratchSize'] == 0 and res['VGPRs Spill'] == 0 and res['VGPRs'] <= (168 if wide else 256), (name, res)
-    for frag in ('dpsroi_bwd_data_mfma_kernel', 'deform_col2im_data_mfma_kernel', 'dpsroi_bwd_trans_roi_kernel', 'dpsroi_fwd_roi_kernel'):
+    for frag in ('dpsroi_bwd_data_mfma_kernel', 'deform_col2im_data_mfma_kernel', 'dpsroi_fwd_roi_kernel'):
         hits = {k: v for k, v in roi.items() if frag in k}
         assert hits, frag
         for name, res in hits.items():
             assert res['ScratchSize'] == 0 and res['VGPRs Spill'] == 0, (name, res)
+    # the offset gradient of the deformable PS-RoI pooling is DELIBERATELY capped at 64 VGPRs (8 waves per SIMD; the spilled values
+    # belong to the once-per-RoI geometry phase): 253 -> 211 us, profiles/r04_kab_roi_occupancy.txt
+    for name, res in roi.items():
+        if 'dpsroi_bwd_trans_roi_kernel' in name:
+            assert res['VGPRs'] <= 64 and res['Occupancy'] == 8 and res['ScratchSize'] <= 256, (name, res)
     # the matrix-core gathers are launched five workgroups deep per CU (1280 tile workgroups on 256 CUs): <= 96 VGPRs
     for name, res in roi.items():
         if 'dpsroi_bwd_data_mfma_kernel' in name:
