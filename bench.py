@@ -97,11 +97,13 @@ class ConvProfiler(object):
     stream the kernel is launched on (torch's current stream)."""
     NAMES = ('sn_conv_fwd', 'sn_conv_fwd_stats', 'sn_conv_dgrad', 'sn_conv_dgrad_bn', 'sn_conv_wgrad', 'sn_conv_wgrad_batch', 'sn_conv_stem_fwd')
 
-    def __init__(self):
+    def __init__(self, extra=()):
         from sniper_amd import hip
         self.hip = hip
         self.orig = hip.call
         self.records = []
+        self.extra = tuple(extra)           # further entry points to bracket (no FLOPs): name -> [calls, ms] in self.extra_ms
+        self.extra_records = []
 
     def __enter__(self):
         def call(name, *args):
@@ -111,6 +113,13 @@ class ConvProfiler(object):
                 r = self.orig(name, *args)
                 e1.record()
                 self.records.append((name, conv_flops(name, args), e0, e1, conv_shape(name, args)))
+                return r
+            if name in self.extra:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = self.orig(name, *args)
+                e1.record()
+                self.extra_records.append((name, e0, e1))
                 return r
             return self.orig(name, *args)
         self.hip.call = call
@@ -155,6 +164,11 @@ class ConvProfiler(object):
                 b[0] += 1
                 b[1] += ms
                 b[2] += fl
+        self.extra_ms = {}
+        for name, e0, e1 in self.extra_records:
+            d = self.extra_ms.setdefault(name, [0, 0.0])
+            d[0] += 1
+            d[1] += max(e0.elapsed_time(e1) - over, 0.0)
         return tot_ms, tot_fl, per
 
     def shape_table(self, steps, top=28):
@@ -502,6 +516,45 @@ def bench_inference(passes=5, jobs=None):
                        'injected: ~10 % positive pixels in 2-4 blobs per chip (SURVEY 8(d)) -> FocusChips per image at the finer '
                        'scales as listed; up to ' + str(lanes) + ' batches of a scale in flight on their own HIP streams (lanes), score '
                        'threshold + border pruning on the GPU, host slicing of batch b under the forwards of the following batches'}
+    # ---- roofline of the pass (untimed, after the measurement): one more pass on ONE lane with the executors running eagerly
+    # (a replayed hipGraph cannot be bracketed), every conv-family entry and the other device entries of the pass between HIP
+    # events on their stream.  FLOPs from the entries' arguments (as the training roofline), so it is what these chips cost.
+    try:
+        os.environ['SNIPER_HIP_GRAPHS'] = '0'
+        cache2 = {}
+        extra = ('sn_multi_proposal', 'sn_dpsroi_pool_fwd', 'sn_deform_im2col', 'sn_bn_apply', 'sn_bbox_decode', 'sn_det_compact',
+                 'sn_soft_nms_batch', 'sn_im_prepare', 'sn_maxpool_fwd', 'sn_softmax_fwd', 'sn_transpose_batched', 'sn_copy2d')
+        res = None
+        for rep in range(2):                 # the first pass binds (allocations, parameter packing), the second is measured
+            roidb = [dict(r) for r in base]
+            with ConvProfiler(extra=extra) as prof:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache2,
+                                       focus_map_fn=fmap, concurrent_jobs=1, lanes=1)
+                torch.cuda.synchronize()
+                eager_dt = time.perf_counter() - t0
+                res = prof.summary()
+                extra_ms, table = prof.extra_ms, prof.shape_table(1, top=12)
+        tot_ms, tot_fl, per = res
+        tf = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        out['roofline'] = {
+            'bound': 'mfma', 'kernel': 'conv_dma_kernel / conv_igemm_kernel through sn_conv_fwd (BatchNorm folded), sn_conv_stem_fwd',
+            'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_PEAK_TFLOPS, 4),
+            'gflop_per_pass': round(tot_fl / 1e9, 1), 'gflop_per_image': round(tot_fl / 1e9 / len(base), 1),
+            'conv_ms_per_pass': round(tot_ms, 2), 'conv_launches_per_pass': sum(v[0] for v in per.values()),
+            'pass_tflops': round(tot_fl / dt / 1e12, 1),      # conv FLOPs of a pass / the TIMED seconds per pass (end to end)
+            'mode': 'one extra pass, one lane, executors eager, HIP events around every entry on its stream (sum of launch '
+                    'durations; the timed passes replay hipGraphs on %d lanes)' % lanes,
+            'eager_seconds_per_pass': round(eager_dt, 3),
+            'other_entries_ms_per_pass': {k: {'calls': v[0], 'ms': round(v[1], 3)} for k, v in sorted(extra_ms.items(), key=lambda kv: -kv[1][1])},
+            'by_shape': table,
+            'note': 'the pass is 1 + 1 + 9 batches (8 / 8 / 2 chips): most launches are a small fraction of a wave of tiles, so the '
+                    'conv family runs far below the training step\'s rate; see DESIGN.md'}
+    except Exception as e:      # noqa: BLE001 -- a report
+        out['roofline'] = {'failed': repr(e)}
+    finally:
+        os.environ.pop('SNIPER_HIP_GRAPHS', None)
     try:
         from oracle import inference_ref
         P = min(os.cpu_count() or 1, 32)             # Pool(32): lib/inference.py:159
