@@ -11,7 +11,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, "..", "include", "sniper_hip.h")
-# SNIPER_HIP_LIB: another build of the same library (A/B runs of whole programs: tools/conv_ab.sh)
+# SNIPER_HIP_LIB: another build of the same library (A/B runs of whole programs: tools/ab.sh)
 LIB_PATH = os.environ.get("SNIPER_HIP_LIB") or os.path.join(_HERE, "lib", "libsniper_hip.so")
 
 _SCALARS = {

@@ -63,7 +63,7 @@ def _place(rect, ms, iw, ih):
 
 
 def gmask(mask, d, thresh_value=0.5, ms=16, im_width=0, im_height=0, cscale=1):
-    """The FocusChips of one FocusPixel map: sn_focus_chips_host (csrc/infer.hip), the native form of gmask_reference below
+    """The FocusChips of one FocusPixel map: sn_focus_chips_host (csrc/host_inference.cpp), the native form of gmask_reference below
     (same steps, same order of the chips; tests/test_focus_chips.py holds the two against each other).  250 us -> ~10 us per
     map: FocusChip generation sits between two scales of a test pass, where nothing overlaps it."""
     from . import hip

@@ -189,7 +189,7 @@ static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
-static std::atomic<int> g_conv_cfg{env_int("SNIPER_CONV_CFG", -1)};   // whole-program A/B (tools/conv_ab.sh) without code changes
+static std::atomic<int> g_conv_cfg{env_int("SNIPER_CONV_CFG", -1)};   // whole-program A/B (tools/ab.sh) without code changes
 SN_EXPORT int sn_conv_tune(int cfg) {
   SN_REQUIRE(cfg == -1 || cfg == 0 || conv_dma_config(cfg).bm > 0, "sn_conv_tune: no configuration %d", cfg);
   g_conv_cfg.store(cfg, std::memory_order_relaxed);
@@ -200,7 +200,7 @@ SN_EXPORT int sn_conv_tune(int cfg) {
 static int conv_dma_choice_balanced(int M, int Nout, int nk, bool dgrad) {
   // tools/conv_tune.py --insitu with the 160-row tiles in the candidate set (profiles/r02_conv_tune_insitu_v3.txt); round 2 also
   // carried an L2-warm and a cold table (profiles/r02_conv_tune*.txt) and eleven more tile configurations -- every whole-step A/B
-  // (tools/conv_ab.sh, profiles/r02_ab_balanced_tiles.txt) chose this one, so round 3 removed the others.
+  // (tools/ab.sh, profiles/r02_ab_balanced_tiles.txt) chose this one, so round 3 removed the others.
   // tools/conv_trace.py shows why they win at 20 chips: a K-step's operand delivery is an LDS-DMA issue cost per wave, so a
   // CU wants >= 8 waves in K loops (two 4-wave workgroups) and every CU the same number of tiles -- 20 480 pixels / 160 = 128
   // row tiles = 256 / 512 / 1024 / 2048 workgroups for 256 / 512 / 1024 / 2048 output channels, 81 920 / 160 = 512.
