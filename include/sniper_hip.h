@@ -180,6 +180,17 @@ int sn_det_compact(const float *d_scores, const double *d_boxes, const double *h
 int sn_conv_fwd(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
                 int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
                 int relu, int out_f32, sn_stream_t stream);
+/* sn_conv_fwd (fp16 output) with the contraction split over several copies of the tile grid, for launches with far fewer output
+ * tiles than CUs (test-time batches of two FocusChips: 82 tiles on 256 CUs, each a latency-bound chain of K-steps): fp32 partial
+ * tiles in `ws`, added in split order together with bias / residual / ReLU (deterministic).  The workspace query returns 0 when the
+ * layer would not be split (enough tiles, a short contraction, a layer the pipelined kernel does not take): call sn_conv_fwd then --
+ * sn_conv_fwd_splitk itself also falls back to it.  Same operator as sn_conv_fwd (symbols/faster/resnet_mx_101_e2e.py:43-66 at
+ * test time, BatchNorm folded); the sum is formed in fp32 across the splits and rounded once. */
+size_t sn_conv_fwd_splitk_workspace_bytes(int N, int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride,
+                                          int res_pix_stride, int KH, int KW, int stride, int pad, int dil);
+int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
+                       int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad,
+                       int dil, int relu, void *ws, size_t ws_bytes, sn_stream_t stream);
 /* Kernel-selection override for sn_conv_fwd / sn_conv_dgrad (tuning hook, tools/conv_tune.py; no reference counterpart):
  * -1 = built-in per-layer table (default), 0 = the register-staged kernel only, 4 / 5 / 6 / 7 / 14 / 16 / 18 = that LDS-DMA tile
  * configuration for every layer that qualifies (see conv_dma.hip; other numbers are rejected).  Results are identical up to fp32 summation order inside a tile's K loop

@@ -304,6 +304,98 @@ SN_EXPORT int sn_conv_fwd(const void *x, const void *w, const float *bias, const
   return conv_launch<false>(p, sn_stream(stream));
 }
 
+// ---- split-K forward for launches with few output tiles ------------------------------------------------------------------
+// A test-time batch of two FocusChips at the finest scale is M = 2 x 36 x 36 pixels: 82 tiles of 64 x 128 for a 256-channel layer,
+// one workgroup each on 256 CUs, and a lone workgroup needs ~0.5 us per K-step whatever the tile: 28 us for
+// the 36-step 3x3 at 108 TF/s.  With the contraction split over `ksplit` copies of the grid every CU has work and a workgroup's
+// serial chain is ksplit times shorter; the fp32 partial tiles are added by splitk_reduce_kernel in split order (deterministic)
+// together with the bias / residual / ReLU epilogue.
+struct SplitPlan { int ksplit; size_t slab_elems; };
+static SplitPlan conv_split_plan(const ConvParams &p) {
+  SplitPlan sp = {1, 0};
+  if (p.out_f32 || p.stats) return sp;
+  const ConvPlan pl = conv_plan(p, false);
+  if (!pl.dma) return sp;
+  const ConvDmaConfig c = conv_dma_config(pl.dma);
+  if (c.bm * c.bn > 160 * 128) return sp;      // (the 8-fragment-wide tiles are not instantiated for it)
+  const long tiles = (long)pl.mtiles * pl.ntiles;
+  const int nk = p.KH * p.KW * (p.Cin / 64);
+  if (tiles >= 160 || nk < 8) return sp;
+  int ks = (int)std::min<long>(std::min<long>(nk / 4, (448 + tiles - 1) / tiles), 8);
+  if (ks < 2) return sp;
+  sp.ksplit = ks;
+  sp.slab_elems = (size_t)p.M * p.Nout;
+  return sp;
+}
+
+// out[m][n] = act(sum_z slab[z][m][n] + bias[n] + res[m][n]) as fp16; 8 channels per thread (Nout % 8 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int ksplit, size_t stride, long M, int Nout,
+                                                            const float *__restrict__ bias, const half_t *__restrict__ res, int res_ps,
+                                                            half_t *__restrict__ out, int out_ps, int relu) {
+  const int cpr = Nout >> 3;
+  const long total = M * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / cpr;
+    const int n = (int)(i - m * cpr) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ksplit; ++z) {
+      const float *sp = slab + (size_t)z * stride + (size_t)m * Nout + n;
+      const float4 a = *reinterpret_cast<const float4 *>(sp), b = *reinterpret_cast<const float4 *>(sp + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bias[n + r];
+    }
+    if (res) {
+      const half8 rv = *reinterpret_cast<const half8 *>(res + (size_t)m * res_ps + n);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+    }
+    half8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = (half_t)((relu && v[r] < 0.f) ? 0.f : v[r]);
+    *reinterpret_cast<half8 *>(out + (size_t)m * out_ps + n) = o;
+  }
+}
+
+SN_EXPORT size_t sn_conv_fwd_splitk_workspace_bytes(int N, int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride,
+                                                    int res_pix_stride, int KH, int KW, int stride, int pad, int dil) {
+  ConvParams p;
+  conv_fwd_params(p, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH,
+                  KW, stride, pad, dil, 0, 0);
+  if (p.Ho <= 0 || p.Wo <= 0 || Cout % 8 != 0 || out_pix_stride % 8 != 0 || res_pix_stride % 8 != 0) return 0;
+  const SplitPlan sp = conv_split_plan(p);
+  return sp.ksplit > 1 ? sn_align((size_t)sp.ksplit * sp.slab_elems * sizeof(float)) : 0;
+}
+
+SN_EXPORT int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W,
+                                 int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW,
+                                 int stride, int pad, int dil, int relu, void *ws, size_t ws_bytes, sn_stream_t stream) {
+  ConvParams p;
+  conv_fwd_params(p, x, w, bias, residual, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH, KW, stride, pad,
+                  dil, relu, 0);
+  if (int rc = conv_check(p, "sn_conv_fwd_splitk")) return rc;
+  const SplitPlan sp = conv_split_plan(p);
+  if (sp.ksplit <= 1 || Cout % 8 != 0 || out_pix_stride % 8 != 0 || (residual && res_pix_stride % 8 != 0))
+    return conv_launch<false>(p, sn_stream(stream));          // nothing to split: the plain forward
+  SN_REQUIRE(ws && ws_bytes >= (size_t)sp.ksplit * sp.slab_elems * sizeof(float),
+             "sn_conv_fwd_splitk: %zu bytes of scratch needed (sn_conv_fwd_splitk_workspace_bytes), got %zu",
+             (size_t)sp.ksplit * sp.slab_elems * sizeof(float), ws_bytes);
+  ConvParams q = p;
+  q.y = ws; q.out_f32 = 1; q.out_ps = p.Nout; q.bias = nullptr; q.res = nullptr; q.res_ps = 0; q.relu = 0;
+  q.ksplit = sp.ksplit;
+  q.ksplit_stride = (long)sp.slab_elems;
+  if (int rc = conv_launch<false>(q, sn_stream(stream))) return rc;
+  const long total = (long)p.M * (p.Nout / 8);
+  long blocks = (total + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), (const float *)ws, sp.ksplit,
+                     sp.slab_elems, (long)p.M, p.Nout, bias, (const half_t *)residual, res_pix_stride, (half_t *)y, out_pix_stride, relu);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
 // Forward convolution that also emits the BatchNorm statistics of its (fp16) output: partials (blocks, 2, Cout) fp32 with
 // blocks = sn_conv_fwd_stats_blocks(...) row tiles, consumed by sn_bn_finalize_blocks -- the separate read pass of
 // sn_bn_stats over the tensor disappears.  sn_conv_fwd_stats_blocks returns 0 when the layer does not qualify (narrow or

@@ -37,6 +37,12 @@ struct ConvParams {
   // 00, 01, 10, 11; cls_mc = N * Ho/2 * Wo/2 rows each, row tiles never straddle classes) and every class walks only ITS taps:
   // 9 tap visits over the four classes of a 3 x 3 kernel instead of 36, 1 instead of 4 for a 1 x 1 shortcut.
   int cls = 0, cls_mc = 0;
+  // Split-K forward (sn_conv_fwd_splitk; launches with far fewer output tiles than CUs -- the 2-chip batches of the finest test
+  // scale are 82 tiles of a 36-step contraction, one latency-bound workgroup each): ksplit > 1 -> the grid is ksplit copies of the
+  // tile grid (ksplit_grid blocks each), copy z walks K-steps [z nk / ksplit, (z + 1) nk / ksplit) and writes its fp32 partial tile
+  // into slab z of `y` (ksplit_stride elements apart); splitk_reduce_kernel adds the slabs in order (+ bias, residual, ReLU).
+  int ksplit = 1, ksplit_grid = 0;
+  long ksplit_stride = 0;
   unsigned long long *trace = nullptr;   // phase timeline of every workgroup (tools/conv_trace.py; SNIPER_CONV_TRACE), normally null
   float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
                        // STORED fp16 values (what bn_stats_kernel would read back), or null

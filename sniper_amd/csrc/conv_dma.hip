@@ -76,9 +76,18 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   static_assert((S - 1) * L < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE];
 
-  const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
+  // split-K forward: grid copy z of the tile grid walks its own K range into its own fp32 slab (ConvParams::ksplit)
+  constexpr bool kSplitOk = !DGRAD && BM * BN <= 160 * 128;      // (few-tile launches never take the 8-fragment-wide tiles)
+  int kz = 0;
+  int lin = blockIdx.x;
+  if (kSplitOk && p.ksplit > 1) {
+    kz = lin / p.ksplit_grid;
+    lin -= kz * p.ksplit_grid;
+  }
+  const int xcd = lin & 7, j = lin >> 3;
   const int nt = j % ntiles, mt = (j / ntiles) * 8 + xcd;
   if (mt >= mtiles) return;
+  void *const ybase = (kSplitOk && p.ksplit > 1) ? (void *)(reinterpret_cast<float *>(p.y) + (size_t)kz * p.ksplit_stride) : p.y;
   // stride-2 data gradient by parity class (ConvParams::cls): row tile mt = (class, tile of the class's rows)
   // (not instantiated for the 8-fragment-wide tiles: their epilogue has no register to spare, and no stride-2 layer takes them)
   constexpr bool kClassOk = DGRAD && BM * BN <= 160 * 128;
@@ -142,7 +151,13 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   // taps this workgroup walks: all of them, or (by class, stride 2, dilation 1) those of its parity: kh = kh0, kh0 + 2, ...
   const int kh0 = by_class ? ((cls_ph + p.pad) & 1) : 0, kw0 = by_class ? ((cls_pw + p.pad) & 1) : 0, kstep = by_class ? 2 : 1;
   const int nkh = by_class ? (p.KH > kh0 ? (p.KH - kh0 + 1) >> 1 : 0) : p.KH, nkw = by_class ? (p.KW > kw0 ? (p.KW - kw0 + 1) >> 1 : 0) : p.KW;
-  const int nk = nkh * nkw * kpt;
+  const int nk_all = nkh * nkw * kpt;
+  // this workgroup's K-steps [t_begin, t_begin + nk): all of them, or its share of a split-K launch
+  int t_begin = 0, nk = nk_all;
+  if (kSplitOk && p.ksplit > 1) {
+    t_begin = (int)((long)kz * nk_all / p.ksplit);
+    nk = (int)((long)(kz + 1) * nk_all / p.ksplit) - t_begin;
+  }
   const unsigned wrow_bytes = (unsigned)(taps * p.Cin) * 2u;
   const char *xb = reinterpret_cast<const char *>(p.x), *wb = reinterpret_cast<const char *>(p.w);
   const unsigned in_ps_bytes = (unsigned)p.in_ps * 2u;
@@ -158,6 +173,12 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     w_voff[i] = n < p.Nout ? (unsigned)n * wrow_bytes + (unsigned)gchunk * 16u : kOob;
   }
   int g_kh = kh0, g_kw = kw0, g_kc = 0;   // next stage to issue: tap (g_kh, g_kw), channel block g_kc
+  if (kSplitOk && t_begin > 0) {            // (split-K: start in the middle of the walk; forward launches are never by class)
+    const int tap = t_begin / kpt;
+    g_kc = t_begin - tap * kpt;
+    g_kh = tap / p.KW;
+    g_kw = tap - g_kh * p.KW;
+  }
   unsigned a_voff[AGW];
   auto tap_setup = [&]() {
 #pragma unroll
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
             for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
           }
           if (p.out_f32) {
-            float *yo = reinterpret_cast<float *>(p.y) + (size_t)m * p.out_ps + n;
+            float *yo = reinterpret_cast<float *>(ybase) + (size_t)m * p.out_ps + n;
             *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
           } else {
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   #pragma unroll
             for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
             // (non-temporal stores measured: no difference in the step, profiles/r04_ab_class_nt_fold.txt)
-            *reinterpret_cast<half8 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + n) = o;
+            *reinterpret_cast<half8 *>(reinterpret_cast<half_t *>(ybase) + (size_t)m * p.out_ps + n) = o;
             if (p.stats) {
               bool done = false;
               if constexpr (kBnHoist) {
@@ -513,13 +534,13 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
               for (int r = 0; r < 4; ++r) v[4 * h + r] = v[4 * h + r] > 0.f ? v[4 * h + r] : 0.f;
             }
             if (p.out_f32) {
-              *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.y) + (size_t)m * p.out_ps + nh) =
+              *reinterpret_cast<float4 *>(reinterpret_cast<float *>(ybase) + (size_t)m * p.out_ps + nh) =
                   make_float4(v[4 * h + 0], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
             } else {
               half4 o;
   #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = (half_t)v[4 * h + r];
-              *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(p.y) + (size_t)m * p.out_ps + nh) = o;
+              *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(ybase) + (size_t)m * p.out_ps + nh) = o;
               if (p.stats) stats4(m, nh, o, jp, h);
             }
           }
@@ -531,8 +552,8 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
             if (p.bias) x += p.bias[n + r];
             if (p.res) x += (float)p.res[(size_t)m * p.res_ps + n + r];
             if (p.relu) x = x > 0.f ? x : 0.f;
-            if (p.out_f32) reinterpret_cast<float *>(p.y)[(size_t)m * p.out_ps + n + r] = x;
-            else reinterpret_cast<half_t *>(p.y)[(size_t)m * p.out_ps + n + r] = (half_t)x;
+            if (p.out_f32) reinterpret_cast<float *>(ybase)[(size_t)m * p.out_ps + n + r] = x;
+            else reinterpret_cast<half_t *>(ybase)[(size_t)m * p.out_ps + n + r] = (half_t)x;
           }
         }
       }
@@ -609,8 +630,11 @@ ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConf
 template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false>
 static void launch_one(const ConvParams &p, hipStream_t s) {
   const int mtiles = (DGRAD && p.cls && BM * BN <= 160 * 128) ? 4 * sn_div_up(p.cls_mc, BM) : sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
-  const dim3 grid(sn_div_up(mtiles, 8) * 8 * ntiles);
-  hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, p, mtiles, ntiles);
+  const int base = sn_div_up(mtiles, 8) * 8 * ntiles;
+  ConvParams q = p;
+  q.ksplit_grid = base;
+  const dim3 grid((unsigned)base * (unsigned)((!DGRAD && p.ksplit > 1 && BM * BN <= 160 * 128) ? p.ksplit : 1));
+  hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, q, mtiles, ntiles);
 }
 
 template <bool DGRAD>

@@ -514,15 +514,24 @@ class ConvolutionStep(_GemmLike):
                      self.stats_buf, hip.stream())
             return
         fold = getattr(self, 'fold_bn', None)
+        w, b, relu = self.w.w16, bias, 0
         if fold is not None:     # test-time: the BatchNorm (+ ReLU) reading this output is part of the epilogue (refold)
             if getattr(self, 'wf', None) is None:
                 raise RuntimeError('%s: folded BatchNorm weights missing (parameters were never set)' % self.node.name)
-            hip.call('sn_conv_fwd', x, self.wf, self.bf, None, dst, self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0,
-                     self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 1 if fold.act == 1 else 0, 0, hip.stream())
-            return
-        hip.call('sn_conv_fwd', x, self.w.w16, bias, None if res is None else res.t, dst, self.N, self.H, self.W, self.C, self.C,
-                 self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], 0,
-                 1 if self.out_f32 else 0, hip.stream())
+            w, b, relu = self.wf, self.bf, 1 if fold.act == 1 else 0
+        geom = (self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0 if res is None else self.O, self.k[0], self.k[1], self.s[0],
+                self.p[0], self.d[0])
+        if not ex.for_training and not self.out_f32:
+            # test-time launches with far fewer output tiles than CUs (batches of two FocusChips): contraction split over copies
+            # of the tile grid (sn_conv_fwd_splitk; the query is 0 for every layer that would not be split)
+            if getattr(self, '_splitk_bytes', None) is None:
+                self._splitk_bytes = 0 if os.environ.get('SNIPER_CONV_SPLITK', '1') == '0' else \
+                    int(hip.query('sn_conv_fwd_splitk_workspace_bytes', *geom))
+            if self._splitk_bytes:
+                hip.call('sn_conv_fwd_splitk', x, w, b, None if res is None else res.t, dst, *geom, relu, ex.ws.get(self._splitk_bytes),
+                         self._splitk_bytes, hip.stream())
+                return
+        hip.call('sn_conv_fwd', x, w, b, None if res is None else res.t, dst, *geom, relu, 1 if self.out_f32 else 0, hip.stream())
 
     def launch_dgrad(self, dy, Op, acc, dx):
         if self.depthwise:

@@ -619,6 +619,44 @@ def test_copy2d_vectorised_and_scalar_paths(rows, cols, in_ld, out_ld):
         assert torch.equal(dst, want), (rows, cols, in_dt, out_dt)
 
 
+@pytest.mark.parametrize('N,C,H,W,O,K,pad,dil,hb,hr,relu', [(2, 256, 36, 36, 256, 3, 1, 1, True, False, 1), (2, 1024, 36, 36, 256, 1, 0, 1, True, False, 1),
+                                                           (2, 256, 36, 36, 1024, 1, 0, 1, False, True, 0), (2, 512, 36, 40, 512, 3, 2, 2, True, False, 0),
+                                                           (1, 3072, 30, 44, 512, 3, 1, 1, True, False, 1), (8, 256, 32, 32, 256, 3, 1, 1, True, False, 1)])
+def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr, relu):
+    """sn_conv_fwd_splitk (test-time launches with far fewer output tiles than CUs: contraction split over copies of the tile grid,
+    fp32 partials reduced in order with the bias / residual / ReLU epilogue) against sn_conv_fwd and against torch-CPU fp32, at the
+    shapes of a 2-chip batch of the finest test scale; a launch with enough tiles (the last case) reports 0 bytes and runs the
+    plain kernel."""
+    hip = _hip()
+    rs = np.random.RandomState(N * C + O)
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rs.standard_normal((O, C, K, K)) / np.sqrt(C * K * K)).astype(np.float32)
+    b = rs.standard_normal(O).astype(np.float32) if hb else None
+    res = rs.standard_normal((N, O, H, W)).astype(np.float32) if hr else None
+    xd = to_nhwc_f16(x)
+    wd = torch.from_numpy(w_to_otI(w)).to(dev()).half().contiguous()
+    bd = torch.from_numpy(b).to(dev()) if hb else None
+    rd = to_nhwc_f16(res) if hr else None
+    geom = (N, H, W, C, C, O, O, O if hr else 0, K, K, 1, pad, dil)
+    need = hip.query('sn_conv_fwd_splitk_workspace_bytes', *geom)
+    assert (need > 0) == (N <= 2), need
+    y0 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_conv_fwd', xd, wd, bd, rd, y0, *geom, relu, 0, hip.stream())
+    ws = torch.full((max(need, 16),), 0x7f, dtype=torch.uint8, device=dev())
+    y1 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_conv_fwd_splitk', xd, wd, bd, rd, y1, *geom, relu, ws, need, hip.stream())
+    torch.cuda.synchronize()
+    want = _ref_conv(x, w, b, res, 1, pad, dil, relu)
+    assert_close(from_nhwc(y1), want, 1e-2, 1e-2 * np.abs(want).max(), 'split-K forward vs torch')
+    # same operands, fp32 accumulation on both sides, one fp16 rounding at the end: the two kernels differ by summation order only
+    assert_close(y1.float().cpu().numpy(), y0.float().cpu().numpy(), 2e-3, 2e-3 * float(y0.float().abs().max()), 'split-K vs plain')
+    if need == 0:
+        assert torch.equal(y0, y1)
+    y2 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_conv_fwd_splitk', xd, wd, bd, rd, y2, *geom, relu, ws, need, hip.stream())
+    assert torch.equal(y1, y2)          # deterministic
+
+
 def test_weight_transpose_batched_equals_single():
     """sn_weight_transpose_batched (one launch, LDS-tiled) against sn_weight_transpose per weight: ragged O / I, taps, O_pad."""
     hip = _hip()
