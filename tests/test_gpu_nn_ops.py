@@ -619,10 +619,13 @@ def test_copy2d_vectorised_and_scalar_paths(rows, cols, in_ld, out_ld):
         assert torch.equal(dst, want), (rows, cols, in_dt, out_dt)
 
 
-@pytest.mark.parametrize('N,C,H,W,O,K,pad,dil,hb,hr,relu', [(2, 256, 36, 36, 256, 3, 1, 1, True, False, 1), (2, 1024, 36, 36, 256, 1, 0, 1, True, False, 1),
-                                                           (2, 256, 36, 36, 1024, 1, 0, 1, False, True, 0), (2, 512, 36, 40, 512, 3, 2, 2, True, False, 0),
-                                                           (1, 3072, 30, 44, 512, 3, 1, 1, True, False, 1), (8, 256, 32, 32, 256, 3, 1, 1, True, False, 1)])
-def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr, relu):
+@pytest.mark.parametrize('N,C,H,W,O,K,pad,dil,hb,hr,relu,split', [
+    (2, 256, 36, 36, 256, 3, 1, 1, True, False, 1, True), (2, 1024, 36, 36, 256, 1, 0, 1, True, False, 1, True),
+    (2, 256, 36, 36, 1024, 1, 0, 1, False, True, 0, False),           # four K-steps: too short a contraction to split
+    (2, 512, 36, 40, 256, 3, 2, 2, True, True, 0, True),              # dilated, residual in the reduce
+    (1, 3072, 30, 44, 512, 3, 1, 1, True, False, 1, True),            # the RPN convolution of one test image
+    (20, 256, 32, 32, 256, 3, 1, 1, True, False, 1, False)])          # a training-size launch: enough tiles
+def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr, relu, split):
     """sn_conv_fwd_splitk (test-time launches with far fewer output tiles than CUs: contraction split over copies of the tile grid,
     fp32 partials reduced in order with the bias / residual / ReLU epilogue) against sn_conv_fwd and against torch-CPU fp32, at the
     shapes of a 2-chip batch of the finest test scale; a launch with enough tiles (the last case) reports 0 bytes and runs the
@@ -639,7 +642,7 @@ def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr
     rd = to_nhwc_f16(res) if hr else None
     geom = (N, H, W, C, C, O, O, O if hr else 0, K, K, 1, pad, dil)
     need = hip.query('sn_conv_fwd_splitk_workspace_bytes', *geom)
-    assert (need > 0) == (N <= 2), need
+    assert (need > 0) == split, need
     y0 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
     hip.call('sn_conv_fwd', xd, wd, bd, rd, y0, *geom, relu, 0, hip.stream())
     ws = torch.full((max(need, 16),), 0x7f, dtype=torch.uint8, device=dev())

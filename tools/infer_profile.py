@@ -1,7 +1,7 @@
 """Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
 cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
 
-    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2)]
+    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs]
 """
 import cProfile
 import os
@@ -29,8 +29,9 @@ def main():
              'gt_overlaps': np.zeros((1, 81), np.float32)} for _ in range(8)]
     cfg = cfgmod.res101_e2e_autofocus()
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    if len(sys.argv) > 3:
+    if len(sys.argv) > 3 and sys.argv[3] != '-':
         cfg.TEST.BATCH_IMAGES = tuple(int(b) for b in sys.argv[3].split(','))
+    jobs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     cache, blobs = {}, {}
 
     def fmap(scale_i, image, chip, net_map):        # (drawn once per (scale, image, chip), as bench.py does)
@@ -38,15 +39,15 @@ def main():
         if key not in blobs:
             blobs[key] = focus_map_blobs(scale_i, image, chip, net_map)
         return blobs[key]
-    for p in range(7):                      # bind, capture, four replays timed plainly, one under cProfile
+    for p in range(9 if jobs > 1 else 7):                      # bind, capture, four replays timed plainly, one under cProfile
         roidb = [dict(r) for r in base]
         torch.cuda.synchronize()
-        pr = cProfile.Profile() if p == 6 else None
+        pr = cProfile.Profile() if p == (8 if jobs > 1 else 6) else None
         t0 = time.perf_counter()
         if pr:
             pr.enable()
         imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache,
-                               focus_map_fn=fmap, lanes=lanes)
+                               focus_map_fn=fmap, lanes=lanes, concurrent_jobs=jobs)
         torch.cuda.synchronize()
         if pr:
             pr.disable()
