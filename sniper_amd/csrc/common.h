@@ -51,3 +51,23 @@ static inline int sn_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t sn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 constexpr int kWave = 64;  // CDNA wavefront width
+
+// Division by a launch-invariant divisor as multiply-high + shift (n < 2^31, d >= 1): q = (umulhi(n, mul) + n) >> sh.  An integer
+// division costs ~40 VALU instructions on gfx950 (64-bit: ~80); index decompositions of element-wise kernels use these instead.
+struct SnDiv { unsigned mul, sh, d; };
+static inline SnDiv sn_div_make(unsigned d) {
+  SnDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << s) - d)) / d + 1);
+  f.sh = s;
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ unsigned sn_div(unsigned n, const SnDiv f) { return (__umulhi(n, f.mul) + n) >> f.sh; }
+// n -> (n / d, n % d)
+__device__ __forceinline__ unsigned sn_divmod(unsigned n, const SnDiv f, unsigned &rem) {
+  const unsigned q = sn_div(n, f);
+  rem = n - q * f.d;
+  return q;
+}

@@ -1103,19 +1103,21 @@ __device__ __forceinline__ DeformSample deform_sample(float py, float px, int H,
 template <typename TO>
 __global__ __launch_bounds__(256) void deform_im2col_kernel(const half_t *__restrict__ data, const TO *__restrict__ offset,
                                                             half_t *__restrict__ col, int N, int H, int W, int C, int Ho, int Wo,
-                                                            int KH, int KW, int stride, int pad, int dil, int DG, int off_ps) {
-  const int cpr = C >> 3, T = KH * KW, cg = C / DG;
-  const long total = (long)N * Ho * Wo * T * cpr;
+                                                            int KH, int KW, int stride, int pad, int dil, int DG, int off_ps,
+                                                            SnDiv d_cpr, SnDiv d_T, SnDiv d_Wo, SnDiv d_Ho, SnDiv d_KW, SnDiv d_cg) {
+  const int cpr = C >> 3, T = KH * KW;
+  const long total = (long)N * Ho * Wo * T * cpr;      // (host: < 2^31)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cpr) * 8;
-    long t = i / cpr;
-    const int tap = (int)(t % T);
-    const long m = t / T;
-    const int ox = (int)(m % Wo);
-    const long t2 = m / Wo;
-    const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
-    const int g = ch / cg, kh = tap / KW, kw = tap - kh * KW;
-    const TO *op = offset + m * off_ps + g * 2 * T + 2 * tap;
+    // element -> (pixel m = (n, oy, ox), tap, 8-channel chunk) by multiply-high: the five 64-bit divisions this used to be were
+    // ~400 VALU instructions in front of four 16-byte gathers and one store (the kernel ran at 2.4 TB/s of its bytes)
+    unsigned chq, tapu, oxu, oyu;
+    const unsigned t = sn_divmod((unsigned)i, d_cpr, chq);
+    const unsigned m = sn_divmod(t, d_T, tapu);
+    const unsigned t2 = sn_divmod(m, d_Wo, oxu);
+    const int n = (int)sn_divmod(t2, d_Ho, oyu);
+    const int ch = (int)chq * 8, tap = (int)tapu, ox = (int)oxu, oy = (int)oyu;
+    const int g = (int)sn_div((unsigned)ch, d_cg), kh = (int)sn_div((unsigned)tap, d_KW), kw = tap - kh * KW;
+    const TO *op = offset + (size_t)m * off_ps + g * 2 * T + 2 * tap;
     const float py = (float)(oy * stride - pad + kh * dil) + (float)op[0], px = (float)(ox * stride - pad + kw * dil) + (float)op[1];
     const DeformSample s = deform_sample(py, px, H, W);
     half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1147,21 +1149,21 @@ template <typename TO>
 __global__ __launch_bounds__(256) void deform_col2im_offset_kernel(const half_t *__restrict__ dcol, const half_t *__restrict__ data,
                                                                    const TO *__restrict__ offset, TO *__restrict__ d_offset, int N,
                                                                    int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride,
-                                                                   int pad, int dil, int DG, int off_ps) {
+                                                                   int pad, int dil, int DG, int off_ps, SnDiv d_cpr, SnDiv d_T,
+                                                                   SnDiv d_Wo, SnDiv d_Ho, SnDiv d_KW, SnDiv d_cg) {
   const int cpr = C >> 3, T = KH * KW, cg = C / DG, lpg = cg >> 3;  // lanes per group (power of two <= 64)
-  const long total = (long)N * Ho * Wo * T * cpr;
+  const long total = (long)N * Ho * Wo * T * cpr;      // (host: < 2^31)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < total;
   const long ii = active ? i : total - 1;
-  const int ch = (int)(ii % cpr) * 8;
-  long t = ii / cpr;
-  const int tap = (int)(t % T);
-  const long m = t / T;
-  const int ox = (int)(m % Wo);
-  const long t2 = m / Wo;
-  const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
-  const int g = ch / cg, kh = tap / KW, kw = tap - kh * KW;
-  const TO *op = offset + m * off_ps + g * 2 * T + 2 * tap;
+  unsigned chq, tapu, oxu, oyu;        // (multiply-high index decomposition: see deform_im2col_kernel)
+  const unsigned t = sn_divmod((unsigned)ii, d_cpr, chq);
+  const unsigned m = sn_divmod(t, d_T, tapu);
+  const unsigned t2 = sn_divmod(m, d_Wo, oxu);
+  const int n = (int)sn_divmod(t2, d_Ho, oyu);
+  const int ch = (int)chq * 8, tap = (int)tapu, ox = (int)oxu, oy = (int)oyu;
+  const int g = (int)sn_div((unsigned)ch, d_cg), kh = (int)sn_div((unsigned)tap, d_KW), kw = tap - kh * KW;
+  const TO *op = offset + (size_t)m * off_ps + g * 2 * T + 2 * tap;
   const float py = (float)(oy * stride - pad + kh * dil) + (float)op[0], px = (float)(ox * stride - pad + kw * dil) + (float)op[1];
   const DeformSample s = deform_sample(py, px, H, W);
   float gy = 0.f, gx = 0.f;
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(256) void deform_col2im_offset_kernel(const half_t 
     gx += __shfl_xor(gx, off, 64);
   }
   if (active && ((ch >> 3) & (lpg - 1)) == 0) {
-    TO *dp = d_offset + m * off_ps + g * 2 * T + 2 * tap;
+    TO *dp = d_offset + (size_t)m * off_ps + g * 2 * T + 2 * tap;
     dp[0] = (TO)gy;
     dp[1] = (TO)gx;
   }
@@ -1343,14 +1345,17 @@ SN_EXPORT int sn_deform_im2col(const void *data, const void *offset, void *col, 
              "sn_deform_im2col: bad arguments");
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   const long total = (long)N * Ho * Wo * KH * KW * (C / 8);
+  SN_REQUIRE(total < 2147483647L, "sn_deform_im2col: too many column elements for 32-bit indexing");
+  const SnDiv d_cpr = sn_div_make(C / 8), d_T = sn_div_make(KH * KW), d_Wo = sn_div_make(Wo), d_Ho = sn_div_make(Ho),
+              d_KW = sn_div_make(KW), d_cg = sn_div_make(C / deformable_groups);
   if (offset_dtype == 0)
     hipLaunchKernelGGL((deform_im2col_kernel<half_t>), dim3((unsigned)blocks_for(total)), dim3(256), 0, sn_stream(stream),
                        (const half_t *)data, (const half_t *)offset, (half_t *)col, N, H, W, C, Ho, Wo, KH, KW, stride, pad, dil,
-                       deformable_groups, offset_pix_stride);
+                       deformable_groups, offset_pix_stride, d_cpr, d_T, d_Wo, d_Ho, d_KW, d_cg);
   else
     hipLaunchKernelGGL((deform_im2col_kernel<float>), dim3((unsigned)blocks_for(total)), dim3(256), 0, sn_stream(stream),
                        (const half_t *)data, (const float *)offset, (half_t *)col, N, H, W, C, Ho, Wo, KH, KW, stride, pad, dil,
-                       deformable_groups, offset_pix_stride);
+                       deformable_groups, offset_pix_stride, d_cpr, d_T, d_Wo, d_Ho, d_KW, d_cg);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
@@ -1392,14 +1397,17 @@ SN_EXPORT int sn_deform_col2im(const void *dcol, const void *data, const void *o
     SN_REQUIRE(lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0 && cg % 8 == 0,
                "sn_deform_col2im: channels per deformable group / 8 must be a power of two <= 64");
     const long total = (long)N * Ho * Wo * KH * KW * (C / 8);
+    SN_REQUIRE(total < 2147483647L - 256, "sn_deform_col2im: too many column elements for 32-bit indexing");
+    const SnDiv d_cpr = sn_div_make(C / 8), d_T = sn_div_make(KH * KW), d_Wo = sn_div_make(Wo), d_Ho = sn_div_make(Ho),
+                d_KW = sn_div_make(KW), d_cg = sn_div_make(cg);
     if (offset_dtype == 0)
       hipLaunchKernelGGL((deform_col2im_offset_kernel<half_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                          (const half_t *)dcol, (const half_t *)data, (const half_t *)offset, (half_t *)d_offset, N, H, W, C, Ho, Wo,
-                         KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride);
+                         KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, d_cpr, d_T, d_Wo, d_Ho, d_KW, d_cg);
     else
       hipLaunchKernelGGL((deform_col2im_offset_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                          (const half_t *)dcol, (const half_t *)data, (const float *)offset, (float *)d_offset, N, H, W, C, Ho, Wo,
-                         KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride);
+                         KH, KW, stride, pad, dil, deformable_groups, offset_pix_stride, d_cpr, d_T, d_Wo, d_Ho, d_KW, d_cg);
     SN_CHECK_LAUNCH();
   }
   if (d_data) {

@@ -278,6 +278,30 @@ def test_fc_as_conv_and_bias_grad():
     assert_close(dw.cpu().numpy(), want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'fc wgrad')
 
 
+@pytest.mark.parametrize('rows,C,ld', [(20480, 512, 512), (6000, 1024, 1024), (20480, 72, 72), (777, 256, 264), (20480, 48, 48), (5, 8, 8)])
+def test_bias_grad_fp16_paths(rows, C, ld):
+    """sn_bias_grad on fp16 gradients (the step's twelve bias gradients): the 16-byte-per-lane form (C and pitch multiples of 8)
+    and the 2-byte form, with and without scratch, against a float64 column sum; ordered partial sums -> the same bits every run;
+    `+=` semantics on a non-zero db."""
+    hip = _hip()
+    rs = np.random.RandomState(rows + C)
+    dy = rs.standard_normal((rows, ld)).astype(np.float32)
+    dyd = torch.from_numpy(dy).to(dev()).half()
+    want = dyd[:, :C].double().sum(0).cpu().numpy()
+    need = hip.query('sn_bias_grad_workspace_bytes', rows, C)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev())
+    runs = []
+    for rep in range(2):
+        db = torch.full((C,), 1.5, dtype=torch.float32, device=dev())
+        hip.call('sn_bias_grad', dyd, db, rows, C, ld, 0, ws, need, hip.stream())
+        runs.append(db.clone())
+    assert torch.equal(runs[0], runs[1])
+    assert_close(runs[0].cpu().numpy() - 1.5, want, 1e-4, 1e-3 * max(1.0, np.sqrt(rows) / 10), 'bias grad fp16')
+    db1 = torch.zeros(C, dtype=torch.float32, device=dev())
+    hip.call('sn_bias_grad', dyd, db1, rows, C, ld, 0, None, 0, hip.stream())
+    assert_close(db1.cpu().numpy(), want, 1e-4, 1e-3 * max(1.0, np.sqrt(rows) / 10), 'bias grad fp16 without scratch')
+
+
 def test_batchnorm_train_fwd_bwd():
     hip = _hip()
     rs = np.random.RandomState(3)
