@@ -1080,7 +1080,8 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dy
   }
 }
 
-// the same reduction with 16-byte loads: a thread owns 8 consecutive channels (fp16 dy, C and ld multiples of 8): a wave reads 1 KB
+// the same reduction with 16-byte loads: a thread owns 8 consecutive channels (fp16 dy, a pitch that is a multiple of 8 and covers the
+// last chunk -- the padded gradients of the narrow heads qualify): a wave reads 1 KB
 // of a row per instruction instead of 128 B, four rows in flight per thread (the 2-byte form ran at 1.2 TB/s: 17 us for the RPN's
 // 21 MB gradient)
 __global__ __launch_bounds__(256) void bias_grad_vec8_kernel(const half_t *__restrict__ dy, float *__restrict__ db, float *__restrict__ part,
@@ -1113,6 +1114,7 @@ __global__ __launch_bounds__(256) void bias_grad_vec8_kernel(const half_t *__res
   if (rl == 0 && c < C) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      if (c + j >= C) break;          // (a last chunk that reaches into the row's padding: C = 42 in a pitch of 48)
       const float t = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
       if (part) part[(size_t)blockIdx.y * C + c + j] = t;
       else db[c + j] += t;
@@ -1159,7 +1161,7 @@ SN_EXPORT int sn_bias_grad(const void *dy, float *db, long rows, int C, int ld, 
   SN_REQUIRE(dy && db && rows > 0 && C > 0, "sn_bias_grad: bad arguments");
   long rpb;
   int by = bias_grad_blocks(rows, &rpb);
-  const bool vec8 = dtype == 0 && C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)dy % 16) == 0;
+  const bool vec8 = dtype == 0 && ld % 8 == 0 && sn_div_up(C, 8) * 8 <= ld && ((uintptr_t)dy % 16) == 0;
   if (vec8 && by > 1 && sn_div_up(C, 512) * by < 256) {        // one block spans 512 channels: more row blocks to fill the CUs
     by = (int)std::min<long>(std::min<long>(256, (rows + 63) / 64), by * 4L);
     if (ws && ws_bytes < sizeof(float) * (size_t)by * C) by = bias_grad_blocks(rows, &rpb);

@@ -278,7 +278,8 @@ def test_fc_as_conv_and_bias_grad():
     assert_close(dw.cpu().numpy(), want_dw, 1e-2, 1e-2 * np.abs(want_dw).max(), 'fc wgrad')
 
 
-@pytest.mark.parametrize('rows,C,ld', [(20480, 512, 512), (6000, 1024, 1024), (20480, 72, 72), (777, 256, 264), (20480, 48, 48), (5, 8, 8)])
+@pytest.mark.parametrize('rows,C,ld', [(20480, 512, 512), (6000, 1024, 1024), (20480, 72, 72), (777, 256, 264), (20480, 42, 48), (6000, 81, 88),
+                                       (20480, 84, 88), (300, 30, 33), (5, 8, 8)])
 def test_bias_grad_fp16_paths(rows, C, ld):
     """sn_bias_grad on fp16 gradients (the step's twelve bias gradients): the 16-byte-per-lane form (C and pitch multiples of 8)
     and the 2-byte form, with and without scratch, against a float64 column sum; ordered partial sums -> the same bits every run;
