@@ -696,7 +696,7 @@ def main():
     n_launch = sum(v[0] for v in per.values())
     roof = {'bound': 'mfma',
             'kernel': 'conv_dma_kernel<DGRAD,BM,BN,...> / wgrad_ps_kernel (+ conv_igemm_kernel for narrow layers, '
-                      'wgrad_reduce2_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_dgrad_bn, sn_conv_wgrad_batch',
+                      'wgrad_reduce_batch_kernel): sn_conv_fwd, sn_conv_fwd_stats, sn_conv_dgrad, sn_conv_dgrad_bn, sn_conv_wgrad_batch',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
             'mode': 'in situ (eager replay of the timed step on its one stream); sum of launch durations as rocprofv3 --kernel-trace '
                     '--stats reports them',

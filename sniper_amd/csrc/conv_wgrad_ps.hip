@@ -327,10 +327,29 @@ __global__ __launch_bounds__(64 * (16 * NA / MI + 4)) void wgrad_ps_kernel(const
   }
 }
 
-// dw[e] += sum over splits of slab[s][e], eight slabs' loads in flight per thread, fixed summation order
-__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float *__restrict__ slab, int splits, size_t n, float *__restrict__ dw) {
-  const size_t n4 = n >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+// The slab reductions of every split problem of a table in ONE launch (round 4; they were one launch of ~7 us per split layer,
+// 32 per step): workgroup b finds its problem from the per-problem block counts (<= 24 problems: a scalar walk) and reduces its
+// share: dw[e] += sum over the splits of slab[s][e], eight slabs' loads in flight per thread, fixed per-element summation order.
+constexpr int kReduceBlocksMax = 1024;
+__device__ __forceinline__ int reduce_blocks_of(const WgradProblem &q) {
+  if (!q.slab) return 0;
+  const long b = (long)((q.slab_stride / 4 + 255) / 256);
+  return (int)(b < 1 ? 1 : (b > kReduceBlocksMax ? kReduceBlocksMax : b));
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradBatch tab) {
+  int b = blockIdx.x, pi = 0, nb = 0;
+  for (; pi < tab.n; ++pi) {
+    nb = reduce_blocks_of(tab.p[pi]);
+    if (b < nb) break;
+    b -= nb;
+  }
+  if (pi >= tab.n) return;
+  const WgradProblem &q = tab.p[pi];
+  const float *__restrict__ slab = q.slab;
+  float *__restrict__ dw = q.dw;
+  const size_t n = q.slab_stride, n4 = n >> 2;
+  const int splits = q.splits;
+  for (size_t i = (size_t)b * 256 + threadIdx.x; i < n4; i += (size_t)nb * 256) {
     float4 a = reinterpret_cast<const float4 *>(dw)[i];
     int s = 0;
     for (; s + 8 <= splits; s += 8) {
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float *__restr
     }
     reinterpret_cast<float4 *>(dw)[i] = a;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+  if (b == 0 && threadIdx.x < (n & 3)) {
     const size_t e = (n4 << 2) + threadIdx.x;
     float a = dw[e];
     for (int s = 0; s < splits; ++s) a += slab[(size_t)s * n + e];
@@ -467,14 +486,15 @@ int wgrad_ps_launch(const WgradBatch &tab, hipStream_t s, int na) {
     else hipLaunchKernelGGL((wgrad_ps_kernel<4, 1, 4, false>), grid, dim3(512), 0, s, tab);
   }
   SN_CHECK_LAUNCH();
+  long blocks = 0;
   for (int i = 0; i < tab.n; ++i) {
     const WgradProblem &q = tab.p[i];
     if (!q.slab) continue;
-    const size_t nel = q.slab_stride;
-    long blocks = (long)((nel / 4 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)q.slab, q.splits, nel, q.dw);
+    const long b = (long)((q.slab_stride / 4 + 255) / 256);
+    blocks += b < 1 ? 1 : (b > kReduceBlocksMax ? kReduceBlocksMax : b);
+  }
+  if (blocks > 0) {
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab);
     SN_CHECK_LAUNCH();
   }
   return SN_OK;

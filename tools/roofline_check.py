@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-FAMILY = ('conv_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_kernel', 'wgrad_ps_kernel', 'wgrad_reduce2_kernel')
+FAMILY = ('conv_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_kernel', 'wgrad_ps_kernel', 'wgrad_reduce2_kernel', 'wgrad_reduce_batch_kernel')
 
 
 def main():
