@@ -539,14 +539,22 @@ __device__ __forceinline__ unsigned long long radix_select_kth(Each each, int ke
         if (acc + h0 < (unsigned)k) { acc += h0; ++bin;
           if (acc + h1 < (unsigned)k) { acc += h1; ++bin;
             if (acc + h2 < (unsigned)k) { acc += h2; ++bin; } } }
-        *sh_prefix = prefix | ((unsigned long long)bin << shift);
-        *sh_keep = k - (int)acc;
+        const unsigned in_bin = bin == 4 * tid ? h0 : (bin == 4 * tid + 1 ? h1 : (bin == 4 * tid + 2 ? h2 : h3));
+        unsigned long long np = prefix | ((unsigned long long)bin << shift);
+        int nk = k - (int)acc;
+        if (in_bin == (unsigned)nk) {       // the whole bucket is kept: every composite with this prefix is <= prefix | ones -- done
+          np |= shift ? ((1ull << shift) - 1ull) : 0ull;          // (the keys are 32 random bits: two or three passes, not six)
+          nk = -1;
+        }
+        *sh_prefix = np;
+        *sh_keep = nk;
       }
     }
     __syncthreads();
     prefix = *sh_prefix;
     k = *sh_keep;
     __syncthreads();
+    if (k < 0) break;
   }
   return prefix;
 }
