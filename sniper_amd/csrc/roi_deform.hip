@@ -681,7 +681,8 @@ struct BinWinD {
 };
 // Occupancy (round 4, profiles/r04_kab_roi_occupancy.txt): both per-RoI gather kernels compile to 110 - 120 VGPRs = 4 waves per
 // SIMD.  Capped at 64 VGPRs (8 waves, ~170 B of scratch per lane) this kernel runs 253 -> 211 us; the forward gets SLOWER
-// (154 -> 211 / 267 us at 6 / 8 waves: its 4 x 4 window of loads spills), so only this one carries the cap.
+// (154 -> 211 / 267 us at 6 / 8 waves: its 4 x 4 window of loads spills; with only two window rows in flight it needs 108 VGPRs and
+// runs 157 us uncapped, 152 / 193 / 315 us capped at 5 / 6 / 8 waves), so only this one carries the cap.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                    const float *__restrict__ rois, const float *__restrict__ trans,
                                                                    float *__restrict__ d_trans, int R, int H, int W, int C, int P,
