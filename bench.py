@@ -520,7 +520,7 @@ def bench_inference(passes=5, jobs=None):
     # image preparation: ~10 ms of a 46 ms pass of 8 images, profiles/r04_infer_timeline.txt) that do not grow with the image count
     try:
         big, bdt = [dict(base[i % len(base)]) for i in range(64)], None
-        for _ in range(3):
+        for _ in range(4):                   # bind, capture, two replays
             roidb = [dict(r) for r in big]
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -121,11 +121,54 @@ def set_capture_allowed(flag):
     _CAPTURE_ALLOWED = bool(flag)
 
 
+class ActivationPool(object):
+    """Forward activations of the TEST-TIME executors of one Module, in memory they share.  A Module runs one executor at a time
+    (one per bucketed batch shape, all on the Module's stream) and a forward writes every activation before it reads it, so the
+    executors of every shape can lay their activations over the same bytes: what a Module holds is the footprint of its largest
+    shape, not the sum over the shapes it has seen (a 2 x 1408 x 2048 R101 forward is 9 GB of activations; 33 bound shapes held
+    184 GB of a 288 GB card and the cache evicted on every batch -- profiles/r04_infer_profile_64.txt).  MXNet's `reshape`
+    shares the memory of the bound executor the same way.  The pool is a list of buffers that never move (captured forwards
+    hold addresses inside them); every executor walks the list from the start with its own cursor, and a request that does not
+    fit the remaining buffers appends one."""
+    CHUNK = 1 << 30
+    ALIGN = 256
+
+    def __init__(self, device):
+        self.device = device
+        self.buffers = []
+
+    def cursor(self):
+        return [0, 0]          # buffer index, byte offset
+
+    def take(self, cur, shape, dtype):
+        shape = tuple(int(x) for x in shape)
+        n = 1
+        for x in shape:
+            n *= x
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        need = max(self.ALIGN, -(-nbytes // self.ALIGN) * self.ALIGN)
+        while True:
+            if cur[0] == len(self.buffers):
+                self.buffers.append(torch.empty((max(self.CHUNK, need),), dtype=torch.uint8, device=self.device))
+            buf = self.buffers[cur[0]]
+            if cur[1] + need <= buf.numel():
+                t = buf[cur[1]:cur[1] + nbytes].view(dtype).view(shape)
+                cur[1] += need
+                return t
+            cur[0], cur[1] = cur[0] + 1, 0
+
+    def nbytes(self):
+        return sum(b.numel() for b in self.buffers)
+
+
 class Executor(object):
     def __init__(self, symbol, input_shapes, for_training=True, fixed_param_names=(), device=None, data_names=None,
-                 label_names=None, loss_scale_hint=None, split_backward=False):
+                 label_names=None, loss_scale_hint=None, split_backward=False, act_pool=None):
         self.sym = symbol
         self.device = device or hip.require_gpu()
+        # test-time only: forward activations carved out of the Module's shared pool (ActivationPool)
+        self.act_pool = None if for_training else act_pool
+        self._act_cursor = self.act_pool.cursor() if self.act_pool is not None else None
         self.for_training = for_training
         self.nodes = symbol._topo()
         self.shapes = infer_shapes(symbol, input_shapes)
@@ -183,6 +226,13 @@ class Executor(object):
 
     def zeros(self, shape, dtype):
         return torch.zeros(tuple(int(s) for s in shape), dtype=dtype, device=self.device)
+
+    def act_empty(self, shape, dtype):
+        """A forward activation (a step's output, an input buffer, a column buffer): rewritten by every forward before it is
+        read.  From the Module's pool at test time, a tensor of its own otherwise."""
+        if self.act_pool is None:
+            return self.empty(shape, dtype)
+        return self.act_pool.take(self._act_cursor, shape, dtype)
 
     def const(self, key, fn):
         if key not in self._const:
@@ -615,7 +665,7 @@ class Executor(object):
                 if tuple(src.shape) != v.shape:
                     raise ValueError('input %s has shape %s, bound shape %s' % (node.name, tuple(src.shape), v.shape))
                 if v.t is None:
-                    v.t = self.empty(v.shape, F32)
+                    v.t = self.act_empty(v.shape, F32)
                 n = v.t.numel()
                 if (isinstance(src, torch.Tensor) and src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
                         and n % 8 == 0 and src.data_ptr() % 16 == 0 and v.t.data_ptr() % 16 == 0):

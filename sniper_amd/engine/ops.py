@@ -44,7 +44,7 @@ class Step(object):
         ex = self.ex
         v = Val('%s:%d' % (self.node.name, i), self.out_shape(i), fmt)
         if alloc:
-            v.t = ex.empty(v.nhwc(), F16) if fmt == 'act' else ex.empty(v.shape, F32)
+            v.t = ex.act_empty(v.nhwc(), F16) if fmt == 'act' else ex.act_empty(v.shape, F32)
         ex.vals[(id(self.node), i)] = v
         v.producer = self
         return v
@@ -361,7 +361,7 @@ class _GemmLike(Step):
             self.w.need_wT = True
         self.tmp_nhwc32 = None
         if self.out_f32 and self.Ho * self.Wo > 1:
-            self.tmp_nhwc32 = ex.empty((self.N, self.Ho, self.Wo, self.O), F32)
+            self.tmp_nhwc32 = ex.act_empty((self.N, self.Ho, self.Wo, self.O), F32)
 
     def refold(self, scale, shift):
         """Test-time fold of the BatchNorm that alone reads this convolution (BatchNormStep.setup): w' = scale[o] * w (from the
@@ -635,7 +635,7 @@ class DeformableConvolutionStep(Step):
         self.b = ex.register_param(self.pname('bias')) if 'bias' in self.slots else None
         self.y = self.new_out('act')
         self.y.needs_grad = ex.for_training
-        self.col = ex.empty((self.N * self.Ho * self.Wo, self.T * self.C), F16)
+        self.col = ex.act_empty((self.N * self.Ho * self.Wo, self.T * self.C), F16)
         self.wT_flat = None
 
     def transpose_jobs(self, only_trainable=False):

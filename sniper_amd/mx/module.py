@@ -116,18 +116,55 @@ class Module(object):
         from ..engine.executor import Executor
         key = tuple(sorted((k, tuple(v)) for k, v in shapes.items()))
         ex = self._exes.get(key)
+        if ex is not None and not self.for_training:
+            self._exes[key] = self._exes.pop(key)          # most recently used last
         if ex is None:
             # data parallel: backward in two segments, the first segment's gradients are all-reduced under the second
             ov = os.environ.get('SNIPER_OVERLAP_ALLREDUCE', '1')
             split = self.for_training and ((self.world > 1 and ov != '0') or ov == 'force')
+            pool = None
+            if not self.for_training and os.environ.get('SNIPER_SHARE_ACTIVATIONS', '1') != '0':
+                from ..engine.executor import ActivationPool
+                pool = self.__dict__.setdefault('_act_pool', None) or ActivationPool(self._device)
+                self._act_pool = pool
             ex = Executor(self.symbol, dict(shapes), for_training=self.for_training, fixed_param_names=self.fixed_param_names,
-                          device=self._device, split_backward=split)
+                          device=self._device, split_backward=split, act_pool=pool)
             if self._arg_params is not None:
                 ex.set_params(self._arg_params, self._aux_params)
-            if len(self._exes) >= 8 and not self.for_training:      # bound the activation memory of stale shapes
-                self._exes.pop(next(iter(self._exes)))
             self._exes[key] = ex
+            if not self.for_training:
+                self._evict_stale()
         return ex
+
+    def _evict_stale(self):
+        """Test-time executors are kept per (bucketed) batch shape, least recently used first out.  A pass over many images
+        walks its area-sorted chip shapes in the same order every time, so a small first-in-first-out cache misses on EVERY
+        batch once a scale has one shape more than it holds (64 images: 9 executors rebuilt per pass, 1.9 s instead of 0.3 --
+        profiles/r04_infer_profile_64.txt).  The bound is memory, not a count: shapes are dropped only while this process holds
+        more than SNIPER_EXE_CACHE_FRAC (default 0.6) of the card's HBM, or beyond SNIPER_EXE_CACHE executors (default 256)."""
+        cap = int(os.environ.get('SNIPER_EXE_CACHE', '256'))
+        frac = float(os.environ.get('SNIPER_EXE_CACHE_FRAC', '0.6'))
+        total = torch.cuda.get_device_properties(self._device).total_memory if self._device.type == 'cuda' else 0
+
+        def over():
+            if len(self._exes) > cap:
+                return True
+            return bool(total) and torch.cuda.memory_allocated(self._device) > frac * total
+        current, dropped = getattr(self, 'exe', None), False
+        while len(self._exes) > 1 and over():
+            key = next(k for k in self._exes)
+            if self._exes[key] is current:                 # never the executor in use: it goes to the back of the queue
+                self._exes[key] = self._exes.pop(key)
+                key = next(k for k in self._exes)
+                if self._exes[key] is current or len(self._exes) < 2:
+                    break
+            if key == next(reversed(self._exes)):          # only the executor just built is left to drop: keep it
+                break
+            self._exes.pop(key)
+            dropped = True
+            import gc
+            gc.collect()                                   # steps and executor reference each other: the tensors go with the cycle
+        return dropped
 
     # ---- parameters
     def init_params(self, initializer=None, arg_params=None, aux_params=None, allow_missing=False, force_init=False,

@@ -1,7 +1,7 @@
 """Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
 cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
 
-    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs]
+    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs] [images per pass: the 8 synthetic images repeated]
 """
 import cProfile
 import os
@@ -32,6 +32,8 @@ def main():
     if len(sys.argv) > 3 and sys.argv[3] != '-':
         cfg.TEST.BATCH_IMAGES = tuple(int(b) for b in sys.argv[3].split(','))
     jobs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    n_img = int(sys.argv[5]) if len(sys.argv) > 5 else len(base)
+    base = [base[i % len(base)] for i in range(n_img)]
     cache, blobs = {}, {}
 
     def fmap(scale_i, image, chip, net_map):        # (drawn once per (scale, image, chip), as bench.py does)
@@ -52,6 +54,10 @@ def main():
         if pr:
             pr.disable()
         print('pass %d: %.1f ms' % (p, (time.perf_counter() - t0) * 1e3), flush=True)
+    mods = [m for k, m in cache.items() if hasattr(m, '_exes')] + [m for k, v in cache.items() if isinstance(k, tuple) and k and
+                                                                   k[0] == '__lanes__' for m in v]
+    print('bound executors per Module: %s; HBM held by this process: %.1f GB' % (
+        [len(m._exes) for m in mods], torch.cuda.memory_allocated() / 1e9), flush=True)
     st = pstats.Stats(pr)
     st.sort_stats('cumulative').print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
 
