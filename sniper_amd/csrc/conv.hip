@@ -227,7 +227,7 @@ SN_EXPORT int sn_conv_dgrad_by_class(int on) {
   return SN_OK;
 }
 
-static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {
+static ConvPlan conv_plan(const ConvParams &p, bool dgrad, int use_cfg = -1) {
   // Layers whose taps are whole 64-channel K-steps and 16-byte addressable take a pipelined kernel; narrow outputs
   // (stage1 / RPN heads) and the packed stem stay on conv_igemm_kernel.
   ConvPlan q = {0, 0, 0, 0, 0u, 0u, 0, 0};
@@ -242,7 +242,7 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {
                           g_dgrad_by_class.load(std::memory_order_relaxed) != 0;
     const int nk_full = p.KH * p.KW * (p.Cin / 64);
     const int nk = by_class ? std::max(1, ((p.KH + 1) / 2) * ((p.KW + 1) / 2) * (p.Cin / 64)) : nk_full;    // the busiest class
-    const int cfg = forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, nk, dgrad);
+    const int cfg = use_cfg > 0 ? use_cfg : (forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, nk, dgrad));
     if (cfg > 0) {
       const ConvDmaConfig c = conv_dma_config(cfg);
       q.dma = cfg;
@@ -259,8 +259,8 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad) {
 }
 
 template <bool DGRAD>
-static int conv_launch(const ConvParams &p, hipStream_t s) {
-  const ConvPlan pl = conv_plan(p, DGRAD);
+static int conv_launch(const ConvParams &p, hipStream_t s, int use_cfg = -1) {
+  const ConvPlan pl = conv_plan(p, DGRAD, use_cfg);
   if (pl.dma) {
     ConvParams q = p;
     q.x_bytes = pl.x_bytes;
@@ -310,19 +310,29 @@ SN_EXPORT int sn_conv_fwd(const void *x, const void *w, const float *bias, const
 // the 36-step 3x3 at 108 TF/s.  With the contraction split over `ksplit` copies of the grid every CU has work and a workgroup's
 // serial chain is ksplit times shorter; the fp32 partial tiles are added by splitk_reduce_kernel in split order (deterministic)
 // together with the bias / residual / ReLU epilogue.
-struct SplitPlan { int ksplit; size_t slab_elems; };
+// A launch whose plan is one of the 8-fragment-wide tiles (FullyConnected over a few hundred RoIs: 600 x 12544 -> 1024 is 20 tiles of
+// 128 x 256 with 196 K-steps each -- 163 us at 94 TF/s) takes the 64 x 128 three-stage configuration instead when it splits.
+struct SplitPlan { int ksplit; size_t slab_elems; int cfg; };
 static SplitPlan conv_split_plan(const ConvParams &p) {
-  SplitPlan sp = {1, 0};
+  SplitPlan sp = {1, 0, -1};
   if (p.out_f32 || p.stats) return sp;
-  const ConvPlan pl = conv_plan(p, false);
+  ConvPlan pl = conv_plan(p, false);
   if (!pl.dma) return sp;
-  const ConvDmaConfig c = conv_dma_config(pl.dma);
-  if (c.bm * c.bn > 160 * 128) return sp;      // (the 8-fragment-wide tiles are not instantiated for it)
-  const long tiles = (long)pl.mtiles * pl.ntiles;
+  ConvDmaConfig c = conv_dma_config(pl.dma);
   const int nk = p.KH * p.KW * (p.Cin / 64);
-  if (tiles >= 160 || nk < 8) return sp;
+  if (c.bm * c.bn > 160 * 128) {               // (the 8-fragment-wide tiles are not instantiated for the split)
+    if (g_conv_cfg.load(std::memory_order_relaxed) >= 0 || p.M >= 8192 || nk < 32) return sp;
+    sp.cfg = 5;
+    pl = conv_plan(p, false, sp.cfg);
+    c = conv_dma_config(pl.dma);
+    if (!pl.dma || c.bm * c.bn > 160 * 128) return SplitPlan{1, 0, -1};
+  }
+  const long tiles = (long)pl.mtiles * pl.ntiles;
+  // fewer tiles than CUs and a contraction worth splitting; about one tile per CU only with a long one (the RPN's 3 x 3 over 3072
+  // channels on a 2-chip batch: 164 tiles x 432 K-steps)
+  if (nk < 8 || tiles > 256 || (tiles >= 160 && nk < 64)) return SplitPlan{1, 0, -1};
   int ks = (int)std::min<long>(std::min<long>(nk / 4, (448 + tiles - 1) / tiles), 8);
-  if (ks < 2) return sp;
+  if (ks < 2) return SplitPlan{1, 0, -1};
   sp.ksplit = ks;
   sp.slab_elems = (size_t)p.M * p.Nout;
   return sp;
@@ -386,7 +396,7 @@ SN_EXPORT int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias
   q.y = ws; q.out_f32 = 1; q.out_ps = p.Nout; q.bias = nullptr; q.res = nullptr; q.res_ps = 0; q.relu = 0;
   q.ksplit = sp.ksplit;
   q.ksplit_stride = (long)sp.slab_elems;
-  if (int rc = conv_launch<false>(q, sn_stream(stream))) return rc;
+  if (int rc = conv_launch<false>(q, sn_stream(stream), sp.cfg)) return rc;
   const long total = (long)p.M * (p.Nout / 8);
   long blocks = (total + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);

@@ -121,6 +121,21 @@ def set_capture_allowed(flag):
     _CAPTURE_ALLOWED = bool(flag)
 
 
+def settle_heap():
+    """A bound executor is some 10^5 long-lived Python objects (steps, values, parameters, plans) that reference each other.  The
+    cyclic collector walks every tracked object at each full collection: 4 ms per bound executor, 230 ms per collection with the
+    61 test-time executors of a 160-image pass, one collection per pass -- and 190 ms before EVERY forward capture
+    (profiles/r04_infer_gc.txt: 7.7 s of a first pass).  After a build / a capture the heap is collected once and moved to the
+    permanent generation (gc.freeze): reference counting still frees whatever is dropped, the collector no longer walks what
+    will not die.  Module._evict_stale thaws before it drops executors (their cycles need the collector).  SNIPER_GC_FREEZE=0:
+    leave the collector alone."""
+    if os.environ.get('SNIPER_GC_FREEZE', '1') == '0':
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 class ActivationPool(object):
     """Forward activations of the TEST-TIME executors of one Module, in memory they share.  A Module runs one executor at a time
     (one per bucketed batch shape, all on the Module's stream) and a forward writes every activation before it reads it, so the
@@ -149,8 +164,10 @@ class ActivationPool(object):
         need = max(self.ALIGN, -(-nbytes // self.ALIGN) * self.ALIGN)
         while True:
             if cur[0] == len(self.buffers):
-                self.buffers.append(torch.empty((max(self.CHUNK, need),), dtype=torch.uint8, device=self.device))
+                self.buffers.append(torch.empty((max(self.CHUNK, need) + self.ALIGN,), dtype=torch.uint8, device=self.device))
             buf = self.buffers[cur[0]]
+            if cur[1] == 0:
+                cur[1] = (-buf.data_ptr()) % self.ALIGN        # addresses, not offsets, are aligned
             if cur[1] + need <= buf.numel():
                 t = buf[cur[1]:cur[1] + nbytes].view(dtype).view(shape)
                 cur[1] += need
@@ -705,6 +722,9 @@ class Executor(object):
                         self._forward_body()
                     g.replay()
                     self._infer_graph = g
+                    if gc_was:
+                        gc.enable()
+                    settle_heap()
                     return self.outputs
                 except Exception as e:   # noqa: BLE001 -- a capture failure means "keep running eagerly"
                     warnings.warn('sniper_amd: hipGraph capture of the inference forward failed (%r); running eagerly' % (e,))

@@ -134,6 +134,8 @@ class Module(object):
             self._exes[key] = ex
             if not self.for_training:
                 self._evict_stale()
+                from ..engine.executor import settle_heap
+                settle_heap()
         return ex
 
     def _evict_stale(self):
@@ -144,7 +146,12 @@ class Module(object):
         more than SNIPER_EXE_CACHE_FRAC (default 0.6) of the card's HBM, or beyond SNIPER_EXE_CACHE executors (default 256)."""
         cap = int(os.environ.get('SNIPER_EXE_CACHE', '256'))
         frac = float(os.environ.get('SNIPER_EXE_CACHE_FRAC', '0.6'))
-        total = torch.cuda.get_device_properties(self._device).total_memory if self._device.type == 'cuda' else 0
+        total = 0
+        if self._device.type == 'cuda':
+            try:                          # (the runtime's own query: torch's device table can disagree with it under a
+                total = torch.cuda.mem_get_info(self._device)[1]      # CUDA_VISIBLE_DEVICES it does not parse, main_test.py)
+            except Exception:             # noqa: BLE001 -- no figure: the count bound alone
+                total = 0
 
         def over():
             if len(self._exes) > cap:
@@ -163,6 +170,7 @@ class Module(object):
             self._exes.pop(key)
             dropped = True
             import gc
+            gc.unfreeze()                                  # (engine/executor.py::settle_heap put the executors out of the collector's reach)
             gc.collect()                                   # steps and executor reference each other: the tensors go with the cycle
         return dropped
 

@@ -448,6 +448,80 @@ def test_set_params_after_capture_reaches_unfolded_batch_statistics_layers():
     assert not np.allclose(after, before)
 
 
+def _bound_test_module(bind, cfg, seed):
+    """R101 test graph bound at `bind`, MSRA weights with damped residual branches (activations stay inside fp16)."""
+    import sniper_amd.mx as mx
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
+
+    def module():
+        net = rn.resnet_mx_101_e2e(n_proposals=400, test_nbatch=bind[0][1][0])
+        sym = net.get_symbol_rcnn(cfg, is_train=False)
+        net.infer_shape(dict(bind))
+        mod = mx.mod.Module(symbol=sym, context=[mx.gpu(0)], data_names=[k for k, _ in bind], label_names=None)
+        mod.bind(bind, None, for_training=False)
+        return net, mod
+    net, first = module()
+    rs = np.random.RandomState(seed)
+    arg = {}
+    for k, s in net.arg_shape_dict.items():
+        if k in dict(bind):
+            continue
+        if k.endswith('_gamma'):
+            v = np.full(s, 0.3 if k.endswith('_bn3_gamma') else 1.0, np.float32)
+        elif k.endswith('_weight') and len(s) > 1:
+            v = (rs.standard_normal(s) * np.sqrt(2.0 / float(np.prod(s[1:])))).astype(np.float32)
+        else:
+            v = (rs.standard_normal(s) * 0.01).astype(np.float32)
+        arg[k] = mx.nd.array(v)
+    aux = {k: mx.nd.array(np.full(s, 1600.0 if k == 'bn_data_moving_var' else 1.0, np.float32) if k.endswith('_var')
+                          else np.zeros(s, np.float32)) for k, s in net.aux_shape_dict.items()}
+    first.init_params(arg_params=arg, aux_params=aux)
+
+    def another():
+        _, mod = module()
+        mod.init_params(arg_params=arg, aux_params=aux)
+        return mod
+    return first, another, rs
+
+
+def _test_batch(bind, h, w, rs, tag):
+    import sniper_amd.mx as mx
+    shp = [('data', (2, 3, h, w))] + bind[1:]
+    data = [mx.nd.array((rs.standard_normal((2, 3, h, w)) * 40).astype(np.float32)),
+            mx.nd.array(np.array([[h, w, 1.0], [h - 12, w, 0.9]], np.float32)),
+            mx.nd.array(np.array([tag, tag + 1], np.float32)), mx.nd.array(np.zeros(2, np.float32))]
+    return mx.io.DataBatch(data=data, label=None, pad=0, index=None, provide_data=shp, provide_label=None)
+
+
+def test_executor_cache_eviction_rebuilds_and_stays_correct(monkeypatch):
+    """SNIPER_EXE_CACHE=2 and three batch shapes in turn: every visit is a miss (the least recently used shape is dropped, its
+    cycles collected after gc.unfreeze, the shape rebuilt into the shared pool on its next visit) -- outputs equal those of a
+    Module that keeps all three, bit for bit."""
+    from sniper_amd import config as cfgmod
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 600, 100
+    bind = [('data', (2, 3, 256, 320)), ('im_info', (2, 3)), ('im_ids', (2,)), ('chip_ids', (2,))]
+    keeps, another, rs = _bound_test_module(bind, cfg, 13)
+    monkeypatch.setenv('SNIPER_EXE_CACHE', '2')
+    small = another()
+    built = []
+    for rnd in range(3):
+        for h, w in [(256, 320), (128, 192), (192, 256)]:
+            batch = _test_batch(bind, h, w, rs, rnd)
+            small.forward(batch, is_train=False)
+            a = [o.asnumpy() for o in small.get_outputs()]
+            built.append(id(small.exe))
+            assert len(small._exes) <= 2
+            monkeypatch.delenv('SNIPER_EXE_CACHE')
+            keeps.forward(batch, is_train=False)
+            monkeypatch.setenv('SNIPER_EXE_CACHE', '2')
+            b = [o.asnumpy() for o in keeps.get_outputs()]
+            for name, x, y in zip(small.output_names, a, b):
+                assert np.array_equal(x, y), (rnd, (h, w), name)
+    assert len(keeps._exes) == 3
+    assert len(small._act_pool.buffers) == len(keeps._act_pool.buffers)      # rebuilt shapes went back into the same pool
+
+
 def test_bound_shapes_of_one_module_share_their_activation_memory():
     """Test-time executors of one Module lie over the same activation bytes (engine/executor.py::ActivationPool).  Three batch
     shapes visited in turn, five rounds (eager, capture, replays interleaved): every output equals, bit for bit, the output of
@@ -522,7 +596,7 @@ def test_bound_shapes_of_one_module_share_their_activation_memory():
     first = next(iter(shared._exes.values()))              # the bind shape = the largest
     used = first._act_cursor
     assert used[0] == len(pool.buffers) - 1                 # the smaller shapes added no buffer
-    lo = pool.buffers[0].data_ptr()
+    lo = pool.buffers[0].data_ptr() + (-pool.buffers[0].data_ptr()) % pool.ALIGN
     for e in shared._exes.values():
         ptrs = [v.t.data_ptr() for v in e.vals.values() if v.t is not None and v.producer is not None]
         inside = [q for q in ptrs if any(b.data_ptr() <= q < b.data_ptr() + b.numel() for b in pool.buffers)]

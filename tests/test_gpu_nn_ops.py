@@ -649,6 +649,9 @@ def test_copy2d_vectorised_and_scalar_paths(rows, cols, in_ld, out_ld):
     (2, 256, 36, 36, 1024, 1, 0, 1, False, True, 0, False),           # four K-steps: too short a contraction to split
     (2, 512, 36, 40, 256, 3, 2, 2, True, True, 0, True),              # dilated, residual in the reduce
     (1, 3072, 30, 44, 512, 3, 1, 1, True, False, 1, True),            # the RPN convolution of one test image
+    (2, 3072, 36, 36, 512, 3, 1, 1, True, False, 1, True),            # ... of a 2-chip batch: 164 tiles, 432 K-steps
+    (2592, 4608, 1, 1, 512, 1, 0, 1, True, False, 0, True),           # the deformable GEMM of that batch: 164 tiles, 72 K-steps
+    (600, 12544, 1, 1, 1024, 1, 0, 1, True, False, 1, True),          # fc_new_1 over 600 RoIs: planned 128 x 256, split as 64 x 128
     (20, 256, 32, 32, 256, 3, 1, 1, True, False, 1, False)])          # a training-size launch: enough tiles
 def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr, relu, split):
     """sn_conv_fwd_splitk (test-time launches with far fewer output tiles than CUs: contraction split over copies of the tile grid,

@@ -1,7 +1,7 @@
 """Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
 cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
 
-    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs] [images per pass: the 8 synthetic images repeated]
+    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs] [images per pass: the 8 synthetic images repeated] [freeze: gc.freeze() after pass 2]
 """
 import cProfile
 import os
@@ -41,6 +41,17 @@ def main():
         if key not in blobs:
             blobs[key] = focus_map_blobs(scale_i, image, chip, net_map)
         return blobs[key]
+    import gc
+    freeze = len(sys.argv) > 6 and sys.argv[6] == 'freeze'
+    gc_t = [0.0, 0.0, 0]
+
+    def on_gc(phase, info):                      # time spent in the cyclic collector, per pass
+        if phase == 'start':
+            gc_t[1] = time.perf_counter()
+        else:
+            gc_t[0] += time.perf_counter() - gc_t[1]
+            gc_t[2] += info['generation'] == 2
+    gc.callbacks.append(on_gc)
     for p in range(9 if jobs > 1 else 7):                      # bind, capture, four replays timed plainly, one under cProfile
         roidb = [dict(r) for r in base]
         torch.cuda.synchronize()
@@ -53,7 +64,12 @@ def main():
         torch.cuda.synchronize()
         if pr:
             pr.disable()
-        print('pass %d: %.1f ms' % (p, (time.perf_counter() - t0) * 1e3), flush=True)
+        print('pass %d: %.1f ms (cyclic collector: %.1f ms, %d full collections)' % (p, (time.perf_counter() - t0) * 1e3, gc_t[0] * 1e3,
+                                                                                  gc_t[2]), flush=True)
+        gc_t[0], gc_t[2] = 0.0, 0
+        if freeze and p == 2:
+            gc.collect()
+            gc.freeze()
     mods = [m for k, m in cache.items() if hasattr(m, '_exes')] + [m for k, v in cache.items() if isinstance(k, tuple) and k and
                                                                    k[0] == '__lanes__' for m in v]
     print('bound executors per Module: %s; HBM held by this process: %.1f GB' % (
