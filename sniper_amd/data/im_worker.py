@@ -35,21 +35,53 @@ def target_scale(width, height, target_size):
     return scale
 
 
+class DeviceImageCache(object):
+    """Decoded uint8 images resident on the device, by path (or by object for in-memory arrays).  The reference reads and decodes
+    an image once per test scale (lib/data_utils/data_workers.py:49-78 under every scale's iterator); a coarse-to-fine pass visits
+    every image at three scales, so `imdb_detection_wrapper` hands ONE cache to the iterators of all its scales: one decode and one
+    upload per image and pass (a 5000-image pass of 640 x 480 images is 4.6 GB of a 288 GB card).  Bounded in bytes
+    (SNIPER_IMAGE_CACHE_GB, default 16): the oldest entries go first."""
+
+    def __init__(self, max_bytes=None):
+        import os
+        import threading
+        self.max_bytes = int(float(os.environ.get('SNIPER_IMAGE_CACHE_GB', '16')) * (1 << 30)) if max_bytes is None else int(max_bytes)
+        self._d, self._bytes, self._lock = {}, 0, threading.Lock()
+        self.hits = self.misses = 0
+
+    def get(self, image):
+        key = image if isinstance(image, str) else id(image)
+        with self._lock:
+            ent = self._d.get(key)
+            if ent is not None and (isinstance(image, str) or ent[0] is image):
+                self.hits += 1
+                return ent[1]
+        d = hip.dev(load_bgr(image))
+        n = d.numel() * d.element_size()
+        with self._lock:
+            self.misses += 1
+            while self._d and self._bytes + n > self.max_bytes:
+                gone = self._d.pop(next(iter(self._d)))
+                self._bytes -= gone[2]
+            # (the array itself is kept with an id() key: the id of a collected array can be reused by another image)
+            self._d[key] = (None if isinstance(image, str) else image, d, n)
+            self._bytes += n
+        return d
+
+    def __len__(self):
+        return len(self._d)
+
+
 class im_worker(object):
-    def __init__(self, cfg, crop_size=None, target_size=None):
+    def __init__(self, cfg, crop_size=None, target_size=None, image_cache=None):
         self.cfg = cfg
         self.crop_size = crop_size
         self.target_size = target_size if target_size else cfg.TRAIN.SCALES[0]
         self.means = np.asarray(cfg.network.PIXEL_MEANS, np.float32)
-        self._cache = {}
+        self._cache = image_cache if image_cache is not None else DeviceImageCache(256 * 4 << 20)
 
     def _device_image(self, image):
-        key = image if isinstance(image, str) else id(image)
-        if key not in self._cache:
-            if len(self._cache) > 256:
-                self._cache.clear()
-            self._cache[key] = hip.dev(load_bgr(image))
-        return self._cache[key]
+        return self._cache.get(image)
 
     def _run(self, image, out, crop, scale, flip):
         d = self._device_image(image)

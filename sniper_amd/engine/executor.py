@@ -125,7 +125,7 @@ def settle_heap():
     """A bound executor is some 10^5 long-lived Python objects (steps, values, parameters, plans) that reference each other.  The
     cyclic collector walks every tracked object at each full collection: 4 ms per bound executor, 230 ms per collection with the
     61 test-time executors of a 160-image pass, one collection per pass -- and 190 ms before EVERY forward capture
-    (profiles/r04_infer_gc.txt: 7.7 s of a first pass).  After a build / a capture the heap is collected once and moved to the
+    (profiles/r04_infer_long_pass.txt: 7.7 s of a first pass).  After a build / a capture the heap is collected once and moved to the
     permanent generation (gc.freeze): reference counting still frees whatever is dropped, the collector no longer walks what
     will not die.  Module._evict_stale thaws before it drops executors (their cycles need the collector).  SNIPER_GC_FREEZE=0:
     leave the collector alone."""
@@ -141,7 +141,7 @@ class ActivationPool(object):
     (one per bucketed batch shape, all on the Module's stream) and a forward writes every activation before it reads it, so the
     executors of every shape can lay their activations over the same bytes: what a Module holds is the footprint of its largest
     shape, not the sum over the shapes it has seen (a 2 x 1408 x 2048 R101 forward is 9 GB of activations; 33 bound shapes held
-    184 GB of a 288 GB card and the cache evicted on every batch -- profiles/r04_infer_profile_64.txt).  MXNet's `reshape`
+    184 GB of a 288 GB card and the cache evicted on every batch -- profiles/r04_infer_long_pass.txt).  MXNet's `reshape`
     shares the memory of the bound executor the same way.  The pool is a list of buffers that never move (captured forwards
     hold addresses inside them); every executor walks the list from the start with its own cursor, and a request that does not
     fit the remaining buffers appends one."""

@@ -12,6 +12,7 @@ moved to the GPU (MI355X first, not a translation of the host loops):
 Dataset I/O (imdb, pickled caches, visualisation) is out of scope: `imdb` only needs `result_path`, `num_classes`,
 `classes`, `name`."""
 import math
+import os
 import threading
 
 import numpy as np
@@ -547,7 +548,7 @@ class Tester(object):
         return all_boxes
 
 
-def detect_scale_worker(arguments, module_cache=None, lanes=1):
+def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None):
     """One test scale: bind the test graph for that scale's batch shape and run the Tester (:411-436).
     module_cache (dict, optional): keeps the bound Module of each scale across calls (its executors are cached per
     batch shape), which is what a long-running inference service -- and the throughput benchmark -- wants; the
@@ -558,7 +559,7 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1):
     [scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis] = arguments
     nGPUs = len(context)
     test_iter = MNIteratorTestAutoFocus(roidb=roidb, config=config, batch_size=nGPUs * nbatch, nGPUs=nGPUs, threads=32,
-                                        pad_rois_to=400, crop_size=None, test_scale=scale)
+                                        pad_rois_to=400, crop_size=None, test_scale=scale, image_cache=image_cache)
     n_batches = max(1, test_iter.size // max(1, nGPUs * nbatch))
     lanes = max(1, min(int(lanes), n_batches))
     # module_cache[(scale, nbatch)] stays ONE Module (what a caller reading the cache expects); further lanes live under
@@ -616,6 +617,11 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
             streams = module_cache.setdefault('__streams__', [torch.cuda.Stream() for _ in parts]) if module_cache is not None \
                 else [torch.cuda.Stream() for _ in parts]
     detections = []
+    # one decode + upload per image and PASS, not per scale (data/im_worker.py::DeviceImageCache); SNIPER_IMAGE_CACHE=0: per scale
+    image_cache = None
+    if os.environ.get('SNIPER_IMAGE_CACHE', '1') != '0' and torch.cuda.is_available():
+        from .data.im_worker import DeviceImageCache
+        image_cache = DeviceImageCache()
     for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
         def job(j):
             was, _SLOT.job = getattr(_SLOT, 'job', 0), j
@@ -623,18 +629,18 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
                 cache = None if module_cache is None else module_cache.setdefault(('__job__', j), {})
                 args = [scale, scale_i, nbatch, context, config, sym_def, parts[j], imdb, arg_params, aux_params, vis]
                 if streams is None:
-                    return detect_scale_worker(args, cache, lanes)
+                    return detect_scale_worker(args, cache, lanes, image_cache)
                 main = torch.cuda.current_stream()
                 streams[j].wait_stream(main)
                 with torch.cuda.stream(streams[j]):
-                    out = detect_scale_worker(args, cache, lanes)
+                    out = detect_scale_worker(args, cache, lanes, image_cache)
                 streams[j].synchronize()
                 return out
             finally:
                 _SLOT.job = was
         if len(parts) == 1:
             dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis],
-                                             module_cache, lanes)
+                                             module_cache, lanes, image_cache)
         else:
             # the first two passes over a module cache run the parts one after the other: that is when the bound executors
             # capture their forward graphs, which must not happen beside another thread's GPU work (engine/executor.py)

@@ -15,15 +15,16 @@ from .MNIteratorBase import MNIteratorBase
 
 class MNIteratorTestAutoFocus(MNIteratorBase):
     def __init__(self, roidb, config, test_scale, batch_size=4, threads=8, nGPUs=1, pad_rois_to=400, crop_size=(512, 512),
-                 num_classes=None):
+                 num_classes=None, image_cache=None):
         self.crop_size = crop_size
+        self.image_cache = image_cache         # data/im_worker.py::DeviceImageCache shared by the scales of one pass (or None)
         self.num_classes = num_classes if num_classes else roidb[0]['gt_overlaps'].shape[1]
         self.data_name = ['data', 'im_info', 'im_ids', 'chip_ids']
         self.label_name = None
         self.label = []
         self.context_size = 320
         self.im_worker = im_worker(crop_size=None if not self.crop_size else self.crop_size[0], cfg=config,
-                                   target_size=test_scale)
+                                   target_size=test_scale, image_cache=image_cache)
         self.test_scale = test_scale
         # the base constructor assembles one batch only to learn the shapes provide_data reports (MNIteratorBase.py:23-24):
         # that one allocates the tensors and skips the image preparation (a pass re-creates this iterator per scale)
@@ -34,7 +35,8 @@ class MNIteratorTestAutoFocus(MNIteratorBase):
 
     def set_scale(self, scale):
         self.test_scale = scale
-        self.im_worker = im_worker(crop_size=None if not self.crop_size else self.crop_size[0], cfg=self.cfg, target_size=scale)
+        self.im_worker = im_worker(crop_size=None if not self.crop_size else self.crop_size[0], cfg=self.cfg, target_size=scale,
+                                   image_cache=self.image_cache)
 
     def _get_batch(self, roidb, chip_ids, im_ids):
         n_batch = len(roidb)

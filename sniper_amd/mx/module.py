@@ -142,7 +142,7 @@ class Module(object):
         """Test-time executors are kept per (bucketed) batch shape, least recently used first out.  A pass over many images
         walks its area-sorted chip shapes in the same order every time, so a small first-in-first-out cache misses on EVERY
         batch once a scale has one shape more than it holds (64 images: 9 executors rebuilt per pass, 1.9 s instead of 0.3 --
-        profiles/r04_infer_profile_64.txt).  The bound is memory, not a count: shapes are dropped only while this process holds
+        profiles/r04_infer_long_pass.txt).  The bound is memory, not a count: shapes are dropped only while this process holds
         more than SNIPER_EXE_CACHE_FRAC (default 0.6) of the card's HBM, or beyond SNIPER_EXE_CACHE executors (default 256)."""
         cap = int(os.environ.get('SNIPER_EXE_CACHE', '256'))
         frac = float(os.environ.get('SNIPER_EXE_CACHE_FRAC', '0.6'))

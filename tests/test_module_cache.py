@@ -105,3 +105,24 @@ def test_test_time_executors_of_one_module_share_their_activations():
     assert not inside(small.params['stage3_unit1_conv2_weight'].w16)
     # a training executor never takes the pool
     assert Executor.__init__.__code__.co_varnames.count('act_pool') == 1
+
+
+def test_device_image_cache_bounds_bytes_and_survives_id_reuse(monkeypatch):
+    """data/im_worker.py::DeviceImageCache: one upload per image; oldest entries leave when the byte bound is reached; an in-memory
+    array is matched by identity, not by a recycled id()"""
+    import numpy as np
+    from sniper_amd.data import im_worker as iw
+    ups = []
+    monkeypatch.setattr(iw.hip, 'dev', lambda a: (ups.append(a.shape), torch.from_numpy(a.copy()))[1])
+    c = iw.DeviceImageCache(max_bytes=3 * 48)
+    ims = [np.full((4, 4, 3), i, np.uint8) for i in range(4)]
+    a0 = c.get(ims[0])
+    assert c.get(ims[0]) is a0 and (c.hits, c.misses) == (1, 1)
+    c.get(ims[1]); c.get(ims[2])
+    assert len(c) == 3
+    c.get(ims[3])                                   # 4 x 48 bytes > bound: the oldest goes
+    assert len(c) == 3 and c.get(ims[0]) is not a0 and len(ups) == 5
+    # a different array that happens to present the same key is a miss
+    key = id(ims[3])
+    c._d[key] = (ims[2], c._d[key][1], 48)
+    assert int(c.get(ims[3])[0, 0, 0]) == 3

@@ -1,7 +1,7 @@
 """Where the AutoFocus inference pass of bench.py (BASELINE C5) spends its time: cProfile of the second pass (executors bound and
 cached), cumulative time per function.  GPU time shows up at the first synchronising call after the launches (asnumpy).
 
-    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs] [images per pass: the 8 synthetic images repeated] [freeze: gc.freeze() after pass 2]
+    python tools/infer_profile.py [n_top] [lanes] [batch sizes per scale, e.g. 8,8,8 (default: the yml's 8,8,2) or -] [concurrent jobs] [images per pass: the 8 synthetic images repeated] [freeze: gc.freeze() after pass 2 | -] [distinct: one array per image]
 """
 import cProfile
 import os
@@ -33,7 +33,10 @@ def main():
         cfg.TEST.BATCH_IMAGES = tuple(int(b) for b in sys.argv[3].split(','))
     jobs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     n_img = int(sys.argv[5]) if len(sys.argv) > 5 else len(base)
-    base = [base[i % len(base)] for i in range(n_img)]
+    if len(sys.argv) > 7 and sys.argv[7] == 'distinct':          # every image its own array (its own upload), as bench.py does
+        base = [dict(base[i % len(base)], image=rs.randint(0, 256, (480, 640, 3)).astype(np.uint8)) for i in range(n_img)]
+    else:
+        base = [base[i % len(base)] for i in range(n_img)]
     cache, blobs = {}, {}
 
     def fmap(scale_i, image, chip, net_map):        # (drawn once per (scale, image, chip), as bench.py does)
