@@ -261,20 +261,25 @@ HBM_KERNELS = ('dpsroi_fwd_roi_kernel', 'dpsroi_bwd_data_mfma_kernel', 'dpsroi_b
                'sgd_dev', 'maxpool_kernel')
 
 
-def roofline_hbm():
+INFER_HBM_KERNELS = ('topk_select_sort_kernel', 'nms_lazy_kernel', 'dpsroi_fwd_roi_kernel', 'bn_apply_kernel', 'deform_im2col_kernel',
+                     'maxpool_kernel', 'im_prepare_kernel', 'splitk_reduce_kernel', 'det_compact', 'soft_nms_kernel',
+                     '__amd_rocclr_copyBuffer', 'FillFunctor')
+
+
+def roofline_hbm(path='pmc_kernels.json', names=None):
     """The memory-bound kernels of the step against the HBM roofline (8 TB/s): per kernel the launches, average duration and
     HBM bytes fetched / written per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
     (tools/gpu_session.sh pmc -> tools/pmc_report.py -> profiles/pmc_kernels.json; FETCH doubled, the gfx950 correction).  None
     unless that report was collected on THIS build of the kernel library."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_kernels.json')) as fh:
+        with open(os.path.join(ROOT, 'profiles', path)) as fh:
             d = json.load(fh)
     except (OSError, ValueError):
         return None
     if d.get('library_sources_hash') != library_sources_hash():
         return None
     out = []
-    for name in HBM_KERNELS:
+    for name in (names or HBM_KERNELS):
         # every kernel whose name contains `name` (the SGD update is a vec4 body kernel + a scalar head / tail kernel: one row,
         # launch-weighted), durations from the un-countered --stats run of the same command when the report has them (counter
         # collection slows a streaming kernel by ~50 %), else from the counter pass itself
@@ -569,6 +574,9 @@ def bench_inference(passes=5, jobs=None):
             'eager_seconds_per_pass': round(eager_dt, 3),
             'other_entries_ms_per_pass': {k: {'calls': v[0], 'ms': round(v[1], 3)} for k, v in sorted(extra_ms.items(), key=lambda kv: -kv[1][1])},
             'by_shape': table,
+            # the memory-bound kernels of the pass against 8 TB/s: bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes
+            # of a 16-image pass on THIS build (tools/gpu_session.sh pmcinf -> profiles/pmc_infer_kernels.json); None otherwise
+            'roofline_hbm': roofline_hbm('pmc_infer_kernels.json', INFER_HBM_KERNELS),
             'note': 'batches of 8 / 8 / 2 chips: most launches are a small fraction of a wave of tiles, so the conv family runs '
                     'far below the training step\'s rate; see DESIGN.md'}
     except Exception as e:      # noqa: BLE001 -- a report

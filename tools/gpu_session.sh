@@ -47,5 +47,17 @@ pmc)
       "$(find gpurun_out/prof_bench -name '*kernel_stats.csv' 2>/dev/null | head -1)" | head -60
   # (copy gpurun_out/pmc_traffic.json and gpurun_out/pmc_kernels.json to profiles/: bench.py reads them there, keyed on the source hash)
   find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete ;;
+pmcinf)
+  # HBM traffic of the inference pass's kernels: the same two counter passes over a 16-image AutoFocus pass,
+  # durations from an un-countered --stats run of the same command
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_inf16" -o inf16 -- \
+      python "$ROOT/tools/infer_profile.py" 1 3 - 1 16 - distinct > "$ROOT/gpurun_out/prof_inf16.log" 2>&1; echo "prof inf16 exit $?")
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/gpurun_out/pmcinf_$C" -o pmc -- \
+        python "$ROOT/tools/infer_profile.py" 1 3 - 1 16 - distinct > "$ROOT/gpurun_out/rocprof_pmcinf_$C.log" 2>&1; echo "pmcinf $C exit $?")
+  done
+  python tools/pmc_report.py gpurun_out/pmcinf_FETCH_SIZE gpurun_out/pmcinf_WRITE_SIZE gpurun_out/pmc_infer_kernels.json "" \
+      "$(find gpurun_out/prof_inf16 -name '*kernel_stats.csv' 2>/dev/null | head -1)" | head -40
+  find gpurun_out/pmcinf_FETCH_SIZE gpurun_out/pmcinf_WRITE_SIZE gpurun_out/prof_inf16 -name "*.csv" -size +8M -delete ;;
 esac
 done
