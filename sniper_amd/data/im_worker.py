@@ -35,6 +35,12 @@ def target_scale(width, height, target_size):
     return scale
 
 
+def _to_device(im):
+    """uint8 (H, W, 3) array -> device tensor.  (A ring of pinned staging slots with asynchronous copies was measured against this
+    plain copy on the 64-image pass: 390 - 420 ms instead of 286 - 300, profiles/r04_infer_long_pass.txt -- not adopted.)"""
+    return hip.dev(im)
+
+
 class DeviceImageCache(object):
     """Decoded uint8 images resident on the device, by path (or by object for in-memory arrays).  The reference reads and decodes
     an image once per test scale (lib/data_utils/data_workers.py:49-78 under every scale's iterator); a coarse-to-fine pass visits
@@ -56,7 +62,7 @@ class DeviceImageCache(object):
             if ent is not None and (isinstance(image, str) or ent[0] is image):
                 self.hits += 1
                 return ent[1]
-        d = hip.dev(load_bgr(image))
+        d = _to_device(load_bgr(image))
         n = d.numel() * d.element_size()
         with self._lock:
             self.misses += 1

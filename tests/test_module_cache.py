@@ -113,7 +113,7 @@ def test_device_image_cache_bounds_bytes_and_survives_id_reuse(monkeypatch):
     import numpy as np
     from sniper_amd.data import im_worker as iw
     ups = []
-    monkeypatch.setattr(iw.hip, 'dev', lambda a: (ups.append(a.shape), torch.from_numpy(a.copy()))[1])
+    monkeypatch.setattr(iw, '_to_device', lambda a: (ups.append(a.shape), torch.from_numpy(a.copy()))[1])
     c = iw.DeviceImageCache(max_bytes=3 * 48)
     ims = [np.full((4, 4, 3), i, np.uint8) for i in range(4)]
     a0 = c.get(ims[0])
