@@ -136,6 +136,16 @@ def settle_heap():
     gc.freeze()
 
 
+def thaw_heap():
+    """Before a Module binds: objects frozen by settle_heap that have since been dropped (a Module rebuilt per call, as the
+    reference's detect_scale_worker does -- its executors, pool and parameters are cycles) are only reclaimed by a collection that
+    can see them."""
+    import gc
+    if gc.get_freeze_count() > 0:
+        gc.unfreeze()
+        gc.collect()
+
+
 class ActivationPool(object):
     """Forward activations of the TEST-TIME executors of one Module, in memory they share.  A Module runs one executor at a time
     (one per bucketed batch shape, all on the Module's stream) and a forward writes every activation before it reads it, so the

@@ -92,6 +92,8 @@ class Module(object):
             return
         if self.world > 1:
             init_distributed()
+        from ..engine.executor import thaw_heap
+        thaw_heap()                  # (Modules dropped since the last settle_heap: their memory goes now)
         self.for_training = for_training
         self._data_shapes = [(d[0], tuple(d[1])) for d in data_shapes]
         self._label_shapes = [(d[0], tuple(d[1])) for d in (label_shapes or [])]

@@ -601,3 +601,27 @@ def test_bound_shapes_of_one_module_share_their_activation_memory():
         ptrs = [v.t.data_ptr() for v in e.vals.values() if v.t is not None and v.producer is not None]
         inside = [q for q in ptrs if any(b.data_ptr() <= q < b.data_ptr() + b.numel() for b in pool.buffers)]
         assert lo in ptrs and len(inside) > 100             # every shape starts at the pool's first byte
+
+
+def test_dropped_modules_release_their_memory():
+    """Bound executors leave the cyclic collector's reach (engine/executor.py::settle_heap); a Module that is dropped -- the
+    reference rebuilds one per scale and call (lib/inference.py:411-436) -- must still give its pool, parameters and executors
+    back: the next bind thaws and collects first (thaw_heap)."""
+    import gc
+    from sniper_amd import config as cfgmod
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 600, 100
+    bind = [('data', (2, 3, 256, 320)), ('im_info', (2, 3)), ('im_ids', (2,)), ('chip_ids', (2,))]
+    rs = np.random.RandomState(3)
+    held = []
+    for rnd in range(4):
+        mod, _, _ = _bound_test_module(bind, cfg, 17)
+        for _ in range(3):                                   # eager, capture, replay
+            mod.forward(_test_batch(bind, 256, 320, rs, rnd), is_train=False)
+            [o.asnumpy() for o in mod.get_outputs()]
+        assert gc.get_freeze_count() > 0                     # the executor's objects are out of the collector's reach
+        del mod
+        torch.cuda.synchronize()
+        held.append(torch.cuda.memory_allocated())
+    # every round starts by collecting the previous round's Module: what is held does not grow with the rounds
+    assert held[3] <= held[1] + (64 << 20), held
