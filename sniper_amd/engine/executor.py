@@ -190,9 +190,15 @@ class ActivationPool(object):
 
 class Executor(object):
     def __init__(self, symbol, input_shapes, for_training=True, fixed_param_names=(), device=None, data_names=None,
-                 label_names=None, loss_scale_hint=None, split_backward=False, act_pool=None):
+                 label_names=None, loss_scale_hint=None, split_backward=False, act_pool=None, share_params=None):
         self.sym = symbol
         self.device = device or hip.require_gpu()
+        # test-time only: the parameters (fp32 masters, fp16 copies, moving statistics, BatchNorm-folded weights) of another bound
+        # shape of the same Module are THIS executor's too -- one set per Module, not one per batch shape (0.5 GB and 70 ms of
+        # packing per shape for R101).  MXNet's `reshape` binds the new shape with shared parameter arrays the same way.
+        self._share = share_params if (share_params is not None and not for_training and not share_params.for_training) else None
+        self.fold_store = self._share.fold_store if self._share is not None else {}      # weight name -> (folded w16, folded bias)
+        self.shared_names = set()
         # test-time only: forward activations carved out of the Module's shared pool (ActivationPool)
         self.act_pool = None if for_training else act_pool
         self._act_cursor = self.act_pool.cursor() if self.act_pool is not None else None
@@ -477,7 +483,13 @@ class Executor(object):
 
     def register_aux(self, name):
         if name not in self.aux:
-            self.aux[name] = self.zeros(self.shapes[('var', name)], F32)
+            shp = tuple(int(x) for x in self.shapes[('var', name)])
+            t = self._share.aux.get(name) if self._share is not None else None
+            if t is not None and tuple(t.shape) == shp:
+                self.aux[name] = t
+                self.shared_names.add(name)
+            else:
+                self.aux[name] = self.zeros(shp, F32)
         return self.aux[name]
 
     def _alloc_params(self):
@@ -526,12 +538,22 @@ class Executor(object):
                 self.groups.append([key, off, off + _pad8(n)])
             off += _pad8(n)
         for p in ps:
-            if not p.trainable:
+            q = self._share.params.get(p.name) if self._share is not None else None
+            if q is not None and not (q.kind == p.kind and tuple(q.int_shape) == tuple(p.int_shape) and q.master is not None
+                                      and not q.trainable and not p.trainable):
+                q = None
+            if q is not None:
+                p.master, p.w16 = q.master, q.w16
+                self.shared_names.add(p.name)
+            elif not p.trainable:
                 p.master = self.zeros(p.int_shape, F32)
                 p.w16 = self.zeros(p.int_shape, F16)
             if p.need_wT and p.kind in ('conv', 'fc', 'deconv'):
                 o, t, i = p.int_shape
-                p.wT16 = self.zeros((i, t, _pad8(o)), F16)
+                if q is not None and q.wT16 is not None and tuple(q.wT16.shape) == (i, t, _pad8(o)):
+                    p.wT16 = q.wT16
+                else:
+                    p.wT16 = self.zeros((i, t, _pad8(o)), F16)
         self.n_trainable = total
 
     def _choose_split(self):

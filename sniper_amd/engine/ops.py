@@ -98,7 +98,8 @@ class BatchNormStep(Step):
             self.gamma.trainable = self.beta.trainable = False
         self.mean = ex.register_aux(self.pname('moving_mean'))
         self.var = ex.register_aux(self.pname('moving_var'))
-        ex.aux[self.pname('moving_var')].fill_(1.0)
+        if self.pname('moving_var') not in ex.shared_names:      # (a shared statistic already holds the Module's values)
+            ex.aux[self.pname('moving_var')].fill_(1.0)
         self.scale, self.shift = ex.empty((C,), F32), ex.empty((C,), F32)
         self.save_mean, self.save_invstd = ex.empty((C,), F32), ex.empty((C,), F32)
         self.bws = None
@@ -370,10 +371,15 @@ class _GemmLike(Step):
         w = self.w.master.view(self.O, -1) * scale.view(-1, 1)
         b = shift if self.b is None else self.b.master * scale + shift
         if getattr(self, 'wf', None) is None:
-            self.wf, self.bf = w.to(F16).view_as(self.w.w16).contiguous(), b.to(F32).contiguous().clone()
-        else:
-            self.wf.copy_(w.view_as(self.wf))
-            self.bf.copy_(b)
+            # one folded copy per Module: the executors of its other batch shapes fold the same masters with the same statistics
+            ent = self.ex.fold_store.get(self.w.name) if self.w.name in self.ex.shared_names else None
+            if ent is None or ent[0].shape != self.w.w16.shape:
+                self.wf, self.bf = w.to(F16).view_as(self.w.w16).contiguous(), b.to(F32).contiguous().clone()
+                self.ex.fold_store[self.w.name] = (self.wf, self.bf)
+                return
+            self.wf, self.bf = ent
+        self.wf.copy_(w.view_as(self.wf))
+        self.bf.copy_(b)
 
     def forward(self):
         ex = self.ex

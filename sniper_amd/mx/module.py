@@ -129,10 +129,16 @@ class Module(object):
                 from ..engine.executor import ActivationPool
                 pool = self.__dict__.setdefault('_act_pool', None) or ActivationPool(self._device)
                 self._act_pool = pool
+            share = None
+            if not self.for_training and self._exes and os.environ.get('SNIPER_SHARE_PARAMS', '1') != '0':
+                share = next(iter(self._exes.values()))          # any bound shape: they all hold the Module's one parameter set
             ex = Executor(self.symbol, dict(shapes), for_training=self.for_training, fixed_param_names=self.fixed_param_names,
-                          device=self._device, split_backward=split, act_pool=pool)
+                          device=self._device, split_backward=split, act_pool=pool, share_params=share)
             if self._arg_params is not None:
-                ex.set_params(self._arg_params, self._aux_params)
+                if share is not None and all(n in ex.shared_names for n in list(ex.params) + list(ex.aux)):
+                    ex.refresh_compute_copies()                  # the values are there: only this shape's derived buffers
+                else:
+                    ex.set_params(self._arg_params, self._aux_params)
             self._exes[key] = ex
             if not self.for_training:
                 self._evict_stale()

@@ -523,84 +523,73 @@ def test_executor_cache_eviction_rebuilds_and_stays_correct(monkeypatch):
 
 
 def test_bound_shapes_of_one_module_share_their_activation_memory():
-    """Test-time executors of one Module lie over the same activation bytes (engine/executor.py::ActivationPool).  Three batch
-    shapes visited in turn, five rounds (eager, capture, replays interleaved): every output equals, bit for bit, the output of
-    a Module whose executors own their activations (SNIPER_SHARE_ACTIVATIONS=0) -- no executor depends on bytes another one
-    overwrote -- and the pool holds the largest shape's footprint, not the sum."""
+    """Test-time executors of one Module lie over the same activation bytes (engine/executor.py::ActivationPool) and hold ONE set
+    of parameters (share_params).  Three batch shapes visited in turn, five rounds (eager, capture, replays interleaved), then
+    new parameters loaded into the Module and two more rounds: every output equals, bit for bit, the output of a Module whose
+    executors own their activations and parameters (SNIPER_SHARE_ACTIVATIONS=0, SNIPER_SHARE_PARAMS=0) -- no executor depends on
+    bytes another one overwrote, every shape sees a parameter load -- and the pool holds the largest shape's footprint, not the sum."""
     import os
     import sniper_amd.mx as mx
     from sniper_amd import config as cfgmod
-    from sniper_amd.symbols.faster import resnet_mx_101_e2e as rn
     cfg = cfgmod.res101_e2e_autofocus()
     cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 600, 100
     bind = [('data', (2, 3, 256, 320)), ('im_info', (2, 3)), ('im_ids', (2,)), ('chip_ids', (2,))]
     sizes = [(256, 320), (128, 192), (192, 256)]
-
-    def module():
-        net = rn.resnet_mx_101_e2e(n_proposals=400, test_nbatch=2)
-        sym = net.get_symbol_rcnn(cfg, is_train=False)
-        net.infer_shape(dict(bind))
-        mod = mx.mod.Module(symbol=sym, context=[mx.gpu(0)], data_names=[k for k, _ in bind], label_names=None)
-        mod.bind(bind, None, for_training=False)
-        return net, mod
-    net, shared = module()
-    rs = np.random.RandomState(11)
-    arg = {}
-    for k, s in net.arg_shape_dict.items():
-        if k in dict(bind):
-            continue
-        if k.endswith('_gamma'):
-            v = np.full(s, 0.3 if k.endswith('_bn3_gamma') else 1.0, np.float32)
-        elif k.endswith('_weight') and len(s) > 1:
-            v = (rs.standard_normal(s) * np.sqrt(2.0 / float(np.prod(s[1:])))).astype(np.float32)
-        else:
-            v = (rs.standard_normal(s) * 0.01).astype(np.float32)
-        arg[k] = mx.nd.array(v)
-    aux = {k: mx.nd.array(np.full(s, 1600.0 if k == 'bn_data_moving_var' else 1.0, np.float32) if k.endswith('_var')
-                          else np.zeros(s, np.float32)) for k, s in net.aux_shape_dict.items()}
-    shared.init_params(arg_params=arg, aux_params=aux)
-    old = os.environ.get('SNIPER_SHARE_ACTIVATIONS')
-    os.environ['SNIPER_SHARE_ACTIVATIONS'] = '0'
+    shared, another, rs = _bound_test_module(bind, cfg, 11)
+    old = {k: os.environ.get(k) for k in ('SNIPER_SHARE_ACTIVATIONS', 'SNIPER_SHARE_PARAMS')}
+    os.environ['SNIPER_SHARE_ACTIVATIONS'] = os.environ['SNIPER_SHARE_PARAMS'] = '0'
     try:
-        _, own = module()
-        own.init_params(arg_params=arg, aux_params=aux)
-        own_shapes = {}
-        for h, w in sizes:                 # bind the unshared Module's executors while the switch is off
+        own = another()
+        for h, w in sizes:                 # bind the unshared Module's executors while the switches are off
             full = dict([('data', (2, 3, h, w))] + bind[1:])
-            own_shapes[(h, w)] = own._exe_for({k: full[k] for k in own.exe.input_names})
+            own._exe_for({k: full[k] for k in own.exe.input_names})
     finally:
-        if old is None:
-            del os.environ['SNIPER_SHARE_ACTIVATIONS']
-        else:
-            os.environ['SNIPER_SHARE_ACTIVATIONS'] = old
-    if True:
-        for rnd in range(5):
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+    def rounds(n, tag0):
+        for rnd in range(n):
             for h, w in sizes:
-                shp = [('data', (2, 3, h, w))] + bind[1:]
-                data = [mx.nd.array((rs.standard_normal((2, 3, h, w)) * 40).astype(np.float32)),
-                        mx.nd.array(np.array([[h, w, 1.0], [h - 12, w, 0.9]], np.float32)),
-                        mx.nd.array(np.array([rnd, rnd + 1], np.float32)), mx.nd.array(np.zeros(2, np.float32))]
-                batch = mx.io.DataBatch(data=data, label=None, pad=0, index=None, provide_data=shp, provide_label=None)
+                batch = _test_batch(bind, h, w, rs, tag0 + rnd)
                 shared.forward(batch, is_train=False)
                 a = [o.asnumpy() for o in shared.get_outputs()]
                 own.forward(batch, is_train=False)
                 b = [o.asnumpy() for o in own.get_outputs()]
                 for name, x, y in zip(shared.output_names, a, b):
-                    assert np.array_equal(x, y), (rnd, (h, w), name)
+                    assert np.array_equal(x, y), (tag0 + rnd, (h, w), name)
                 assert np.isfinite(a[1]).all()
-    assert all(e.act_pool is None for e in own._exes.values()) and all(e.act_pool is shared._act_pool for e in shared._exes.values())
+    rounds(5, 0)
+    assert all(e.act_pool is None and not e.shared_names for e in own._exes.values())
+    assert all(e.act_pool is shared._act_pool for e in shared._exes.values())
     assert len(shared._exes) == len(own._exes) == 3
     assert all(e._infer_graph is not None for e in shared._exes.values())
+    exes = list(shared._exes.values())
+    name = 'stage3_unit1_conv2_weight'
+    assert len({e.params[name].w16.data_ptr() for e in exes}) == 1 and len({e.params[name].master.data_ptr() for e in exes}) == 1
+    assert len({e.aux['stage3_unit1_bn2_moving_var'].data_ptr() for e in exes}) == 1
+    assert len({e.params[name].w16.data_ptr() for e in own._exes.values()}) == 3
+    # a parameter load after the captures reaches every bound shape (shared masters, per-shape derived buffers)
+    arg, aux = shared.get_params()
+    r2 = np.random.RandomState(5)
+    arg2 = {k: mx.nd.array(v.asnumpy() * (1.0 + 0.05 * r2.standard_normal(v.shape).astype(np.float32))) for k, v in arg.items()}
+    aux2 = {k: mx.nd.array(v.asnumpy() * (1.3 if k.endswith('_var') else 1.0) + (0.0 if k.endswith('_var') else 0.01))
+            for k, v in aux.items()}
+    shared.set_params(arg2, aux2)
+    own.set_params(arg2, aux2)
+    before = [o.asnumpy().copy() for o in shared.get_outputs()]
+    rounds(2, 100)
     assert getattr(own, '_act_pool', None) is None
     pool = shared._act_pool
-    first = next(iter(shared._exes.values()))              # the bind shape = the largest
-    used = first._act_cursor
-    assert used[0] == len(pool.buffers) - 1                 # the smaller shapes added no buffer
     lo = pool.buffers[0].data_ptr() + (-pool.buffers[0].data_ptr()) % pool.ALIGN
     for e in shared._exes.values():
         ptrs = [v.t.data_ptr() for v in e.vals.values() if v.t is not None and v.producer is not None]
         inside = [q for q in ptrs if any(b.data_ptr() <= q < b.data_ptr() + b.numel() for b in pool.buffers)]
         assert lo in ptrs and len(inside) > 100             # every shape starts at the pool's first byte
+    del before
+
 
 
 def test_dropped_modules_release_their_memory():

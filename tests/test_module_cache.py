@@ -126,3 +126,28 @@ def test_device_image_cache_bounds_bytes_and_survives_id_reuse(monkeypatch):
     key = id(ims[3])
     c._d[key] = (ims[2], c._d[key][1], 48)
     assert int(c.get(ims[3])[0, 0, 0]) == 3
+
+
+def test_test_time_executors_share_one_parameter_set():
+    """share_params: masters, fp16 copies, moving statistics and the BatchNorm-folded weights of a second bound shape ARE the
+    first shape's tensors; a training executor never shares"""
+    from sniper_amd import config as cfgmod
+    from sniper_amd.engine.executor import Executor
+    from sniper_amd.symbols.faster import resnet_mx_101_e2e as ours
+    cfg = cfgmod.res101_e2e_autofocus()
+    sym = ours.resnet_mx_101_e2e(n_proposals=400, test_nbatch=1).get_symbol_rcnn(cfg, is_train=False)
+    args = set(sym.list_arguments())
+
+    def bind(h, w, share=None):
+        shapes = {k: v for k, v in dict(data=(1, 3, h, w), im_info=(1, 3), im_ids=(1,), chip_ids=(1,)).items() if k in args}
+        return Executor(sym, shapes, False, (), device=torch.device('cpu'), share_params=share)
+    a = bind(192, 256)
+    b = bind(128, 192, a)
+    assert not a.shared_names and b.fold_store is a.fold_store
+    assert set(b.shared_names) == set(b.params) | set(b.aux)
+    for name in ('conv0_weight', 'stage3_unit1_conv2_weight', 'fc_new_1_weight', 'rpn_conv_3x3_weight'):
+        assert b.params[name].master.data_ptr() == a.params[name].master.data_ptr()
+        assert b.params[name].w16.data_ptr() == a.params[name].w16.data_ptr()
+    assert b.aux['stage1_unit1_bn2_moving_var'].data_ptr() == a.aux['stage1_unit1_bn2_moving_var'].data_ptr()
+    c = bind(128, 192)
+    assert c.params['conv0_weight'].master.data_ptr() != a.params['conv0_weight'].master.data_ptr()
