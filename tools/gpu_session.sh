@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit.  Everything lands in gpurun_out/ (copy what should be judged into profiles/).
-# usage: tools/gpu_session.sh [tests|bench|prof|pmc|micro]...
+# usage: tools/gpu_session.sh [tests|bench|prof|pmc|pmcinf|micro]...
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 ROOT=$(pwd)
 mkdir -p gpurun_out
