@@ -292,3 +292,31 @@ def test_native_aggregation_equals_the_numpy_statement():
     # a chip without the compact form sends the whole call to the numpy statement
     del scales[1].compact[(2, 0)]
     assert _aggregate_stacked_native(scales, ((-1, -1),) * 3, n_img, nc) is None
+
+
+def test_cap_detections_per_image_equals_the_per_class_loops():
+    """inference.cap_detections_per_image against the reference's statement of the MAX_PER_IMAGE rule (lib/inference.py:203-211):
+    hstack the scores, threshold = the max_per_image-th best, per class `where(score >= threshold)`; ties, empty classes, fewer
+    rows than the cap"""
+    from sniper_amd.inference import cap_detections_per_image
+    rs = np.random.RandomState(4)
+    for case in range(40):
+        nc = int(rs.randint(1, 81))
+        per_class = []
+        for j in range(nc):
+            n = int(rs.randint(0, 9)) if rs.rand() < 0.8 else 0
+            d = rs.rand(n, 5).astype(np.float32)
+            if case % 3 == 0 and n:
+                d[:, 4] = np.round(d[:, 4] * 4) / 4           # many equal scores: ties at the threshold stay
+            per_class.append(d)
+        cap = int(rs.randint(1, 120))
+        scores = np.hstack([d[:, -1] for d in per_class]) if per_class else np.zeros(0)
+        got = cap_detections_per_image(per_class, cap)
+        if len(scores) <= cap:
+            assert got is None
+            continue
+        thresh = np.sort(scores)[-cap]
+        want = [d[np.where(d[:, -1] >= thresh)[0], :] for d in per_class]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
