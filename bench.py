@@ -546,6 +546,7 @@ def bench_inference(passes=5, jobs=None):
     # events on their stream.  FLOPs from the entries' arguments (as the training roofline), so it is what these chips cost.
     try:
         os.environ['SNIPER_HIP_GRAPHS'] = '0'
+        cache.clear()                 # (the timed passes' Modules: their pools and graphs go at the next bind, Module.bind -> thaw_heap)
         cache2 = {}
         extra = ('sn_multi_proposal', 'sn_dpsroi_pool_fwd', 'sn_deform_im2col', 'sn_bn_apply', 'sn_bbox_decode', 'sn_det_compact',
                  'sn_soft_nms_batch', 'sn_im_prepare', 'sn_maxpool_fwd', 'sn_softmax_fwd', 'sn_transpose_batched', 'sn_copy2d')
