@@ -65,6 +65,13 @@ class DeviceImageCache(object):
         d = _to_device(load_bgr(image))
         n = d.numel() * d.element_size()
         with self._lock:
+            ent = self._d.get(key)
+            if ent is not None and (isinstance(image, str) or ent[0] is image):
+                self.hits += 1                 # another pool thread uploaded the same image meanwhile (chips of one image share a
+                return ent[1]                  # batch): keep its tensor, this copy is dropped
+            old = self._d.pop(key, None)       # an id() reused by another array: the stale entry's bytes leave the count
+            if old is not None:
+                self._bytes -= old[2]
             self.misses += 1
             while self._d and self._bytes + n > self.max_bytes:
                 gone = self._d.pop(next(iter(self._d)))

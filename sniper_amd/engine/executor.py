@@ -134,6 +134,26 @@ def settle_heap():
     import gc
     gc.collect()
     gc.freeze()
+    _SETTLED[0] += 1
+
+
+_SETTLED = [0]          # settle_heap calls since the last resettle_heap
+
+
+def resettle_heap():
+    """End of a pass (sniper_amd.inference.imdb_detection_wrapper, after the pass's own objects are dropped): settle_heap runs
+    INSIDE a pass -- Module.forward builds / captures when a batch has a new shape -- so whatever is alive at that moment is frozen
+    with the executors: the pass's iterators, its image cache (up to SNIPER_IMAGE_CACHE_GB of device images), its batches.  What of
+    that has died by the end of the pass and sits in a reference cycle would stay until the next thaw; so a pass that settled
+    anything thaws, collects and freezes again once, when only the long-lived objects are left.  A pass over shapes already bound
+    does nothing here."""
+    if _SETTLED[0] == 0 or os.environ.get('SNIPER_GC_FREEZE', '1') == '0':
+        return
+    import gc
+    _SETTLED[0] = 0
+    gc.unfreeze()
+    gc.collect()
+    gc.freeze()
 
 
 def thaw_heap():

@@ -548,9 +548,12 @@ class Tester(object):
         # batch order) before the lane is reused, so `lanes` forwards are in flight while the host slices an earlier batch.
         compact = None if (evaluate or not self.device_compact) else (cls_thresh, do_pruning)
         lanes = len(self.modules)
+        # one lane (the default): still two batches in flight -- batch k + 1 is enqueued BEFORE batch k is collected, so the host
+        # slices k under the forward of k + 1 (a lane's pinned result sets alternate: k is out of its set before k + 2 is launched)
+        depth = lanes if lanes > 1 else 2
         pending = []
         for k, batch in enumerate(self.test_iter):
-            if len(pending) >= lanes:
+            if len(pending) >= depth:
                 post(*self._collect(pending.pop(0)))
             pending.append(self._launch(batch, k % lanes, compact))
         while pending:
@@ -695,4 +698,9 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
         module_cache['__passes__'] = module_cache.get('__passes__', 0) + 1
     tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
     out = tester.aggregate(detections, vis=False, cache_name=None)
+    # the pass's own objects (iterators, device image cache) are gone or go now; if a new batch shape froze the heap while they
+    # were alive, collect what died in cycles and freeze again (engine/executor.py::resettle_heap)
+    del image_cache, tester
+    from .engine.executor import resettle_heap
+    resettle_heap()
     return (out, detections) if return_scale_dets else out

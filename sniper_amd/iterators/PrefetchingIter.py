@@ -36,41 +36,44 @@ class PrefetchingIter(mx.io.DataIter):
         except Exception:  # noqa: BLE001
             self._device = None
 
-        def prefetch_func():
-            if self._device is not None:
-                import torch
-                torch.cuda.set_device(self._device)
-            while True:
-                with self._cv:
-                    while self.started and (self._exhausted or len(self._queue) >= self.depth):
-                        self._cv.wait()
-                    if not self.started:
-                        break
-                    epoch, self._busy = self._epoch, True
-                batch, error = None, None
-                try:
-                    batch = self.iters[0].next()
-                    if self._device is not None:
-                        import torch
-                        ev = torch.cuda.Event()
-                        ev.record()
-                        batch.ready_event = ev
-                except StopIteration:
-                    batch = None
-                except Exception as e:  # noqa: BLE001 -- surface worker failures in the consumer thread
-                    batch, error = None, e
-                with self._cv:
-                    self._busy = False
-                    if epoch == self._epoch:
-                        self._queue.append((batch, error))
-                        self._exhausted = batch is None
-                    self._cv.notify_all()
-        self._prefetch_func = prefetch_func
         self._start()
+
+    def _prefetch_loop(self):
+        """The worker thread's body: a METHOD, not a closure kept on self -- a closure over self stored on self is a reference
+        cycle that outlives close() until a cyclic collection sees it (and forever once the heap is frozen, engine/executor.py::
+        settle_heap); a finished Thread drops its target, so a closed iterator dies by reference counting."""
+        if self._device is not None:
+            import torch
+            torch.cuda.set_device(self._device)
+        while True:
+            with self._cv:
+                while self.started and (self._exhausted or len(self._queue) >= self.depth):
+                    self._cv.wait()
+                if not self.started:
+                    break
+                epoch, self._busy = self._epoch, True
+            batch, error = None, None
+            try:
+                batch = self.iters[0].next()
+                if self._device is not None:
+                    import torch
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    batch.ready_event = ev
+            except StopIteration:
+                batch = None
+            except Exception as e:  # noqa: BLE001 -- surface worker failures in the consumer thread
+                batch, error = None, e
+            with self._cv:
+                self._busy = False
+                if epoch == self._epoch:
+                    self._queue.append((batch, error))
+                    self._exhausted = batch is None
+                self._cv.notify_all()
 
     def _start(self):
         self.started = True
-        self.prefetch_thread = threading.Thread(target=self._prefetch_func, daemon=True)
+        self.prefetch_thread = threading.Thread(target=self._prefetch_loop, daemon=True)
         self.prefetch_thread.start()
 
     def close(self):

@@ -141,12 +141,12 @@ class Module(object):
                     ex.set_params(self._arg_params, self._aux_params)
             self._exes[key] = ex
             if not self.for_training:
-                self._evict_stale()
+                self._evict_stale(keep=ex)
                 from ..engine.executor import settle_heap
                 settle_heap()
         return ex
 
-    def _evict_stale(self):
+    def _evict_stale(self, keep=None):
         """Test-time executors are kept per (bucketed) batch shape, least recently used first out.  A pass over many images
         walks its area-sorted chip shapes in the same order every time, so a small first-in-first-out cache misses on EVERY
         batch once a scale has one shape more than it holds (64 images: 9 executors rebuilt per pass, 1.9 s instead of 0.3 --
@@ -166,16 +166,18 @@ class Module(object):
                 return True
             return bool(total) and torch.cuda.memory_allocated(self._device) > frac * total
         current, dropped = getattr(self, 'exe', None), False
-        while len(self._exes) > 1 and over():
-            key = next(k for k in self._exes)
-            if self._exes[key] is current:                 # never the executor in use: it goes to the back of the queue
+        rotated = 0
+        while len(self._exes) > 1 and over() and rotated < len(self._exes):
+            key = next(iter(self._exes))
+            if self._exes[key] is current or self._exes[key] is keep:
+                # never the executor in use nor the one just built (`keep`, about to become self.exe): to the back of the queue
                 self._exes[key] = self._exes.pop(key)
-                key = next(k for k in self._exes)
-                if self._exes[key] is current or len(self._exes) < 2:
-                    break
-            if key == next(reversed(self._exes)):          # only the executor just built is left to drop: keep it
-                break
+                rotated += 1
+                continue
             self._exes.pop(key)
+            live = set(kv for k in self._exes for kv in k)                 # (input name, shape) pairs some bound executor still takes
+            for bk in [b for b in getattr(self, '_bucket_bufs', {}) if (b[0], tuple(b[1])) not in live]:
+                del self._bucket_bufs[bk]              # the dropped shape's zero-padded input buffers (69 MB each at 1408 x 2048) go with it
             dropped = True
             import gc
             gc.unfreeze()                                  # (engine/executor.py::settle_heap put the executors out of the collector's reach)

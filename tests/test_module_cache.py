@@ -151,3 +151,41 @@ def test_test_time_executors_share_one_parameter_set():
     assert b.aux['stage1_unit1_bn2_moving_var'].data_ptr() == a.aux['stage1_unit1_bn2_moving_var'].data_ptr()
     c = bind(128, 192)
     assert c.params['conv0_weight'].master.data_ptr() != a.params['conv0_weight'].master.data_ptr()
+
+
+def test_closed_prefetching_iter_dies_by_reference_counting_even_with_a_frozen_heap():
+    """a closure over self kept on self made a closed PrefetchingIter a reference cycle; frozen by settle_heap it (and
+    the pass's device image cache behind it) stayed alive until the next thaw."""
+    import gc
+    import weakref
+    from sniper_amd.iterators.PrefetchingIter import PrefetchingIter
+
+    class Payload(object):
+        pass
+
+    class It(object):
+        provide_data, provide_label = [('data', (1, 3, 4, 4))], []
+        batch_size = 1
+
+        def __init__(self):
+            self.payload = Payload()
+
+        def reset(self):
+            pass
+
+        def next(self):
+            raise StopIteration
+
+    inner = It()
+    alive = weakref.ref(inner.payload)
+    it = PrefetchingIter(inner)
+    gc.collect()
+    gc.freeze()
+    try:
+        gc.disable()
+        it.close()
+        del it, inner
+        assert alive() is None, 'the closed iterator is still reachable: a cycle the frozen collector cannot see'
+    finally:
+        gc.enable()
+        gc.unfreeze()
