@@ -610,6 +610,62 @@ def bench_inference(passes=5, jobs=None):
     return out
 
 
+def dist_probe(tr, step, sync, dist, world, reps=3):
+    """N > 1 only, untimed extra steps on EVERY rank (collectives): what the gradient exchange costs and how much of it the split
+    backward hides.
+      allreduce_ms      the whole gradient arena summed over the ranks, alone on an idle device (fp16 + fp32 buckets as in a step)
+      overlap_frac      of the first segment's collective (gradients of the steps behind the split), the part that ran under the
+                        second backward segment: |[comm start, comm end] intersect [segment-2 start, segment-2 end]| / comm
+                        duration, from HIP events on the two streams (comm start = segment-2 start: the collective is released
+                        by the event that ends segment 1)
+      rccl_ranks_seen   sum over the ranks of 1 through the process group (= world when every rank took part)"""
+    import sniper_amd.parallel as par
+    mod, ex = tr.mod, tr.mod.exe
+    ones = torch.ones(1, device='cuda')
+    dist.all_reduce(ones)
+    ranges = [(h, a, b) for _, h, a, b in ex.ar_ranges]
+    half = mod._half_buf()
+    par.allreduce_ranges(ex.grad_arena(), ranges, dist, half)                  # warm (communicator set-up)
+    sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n_coll = 0
+    for _ in range(reps):
+        n_coll = par.allreduce_ranges(ex.grad_arena(), ranges, dist, half)
+    e1.record()
+    sync()
+    ar_ms = e0.elapsed_time(e1) / reps
+    nbytes = sum((b - a) * (2 if (h and os.environ.get('SNIPER_GRAD_FP16', '1') != '0') else 4) for h, a, b in ranges)
+    rep = {'backend': dist.get_backend(), 'rccl_ranks_seen': int(round(float(ones.item()))), 'allreduce_ms': round(ar_ms, 3),
+           'allreduce_mb': round(nbytes / 1e6, 1), 'collectives_per_step': n_coll,
+           'allreduce_gb_s_algorithmic': round(nbytes / (ar_ms * 1e-3) / 1e9, 1) if ar_ms > 0 else None,
+           'split_backward': bool(ex.split_k), 'overlap_frac': None, 'first_segment_ms': None}
+    if ex.split_k:
+        mod._comm_probe = []
+        try:
+            for i in range(reps):
+                step(i)
+            sync()
+            fr, ms = [], []
+            for p in mod._comm_probe:
+                if 'seg2_end' not in p:
+                    continue
+                comm = p['seg2_start'].elapsed_time(p['comm_end'])
+                seg2 = p['seg2_start'].elapsed_time(p['seg2_end'])
+                if comm > 0:
+                    fr.append(max(0.0, min(comm, seg2)) / comm)
+                    ms.append(comm)
+            if fr:
+                rep['overlap_frac'] = round(sum(fr) / len(fr), 3)
+                rep['first_segment_ms'] = round(sum(ms) / len(ms), 3)
+        finally:
+            mod._comm_probe = None
+    t = torch.tensor([rep['allreduce_ms']], device='cuda', dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                                   # the slowest rank's exchange (overlap_frac: rank 0's)
+    rep['allreduce_ms'] = round(float(t[0].item()), 3)
+    return rep
+
+
 LINE_LIMIT = 4096      # bytes of the final JSON line (the driver keeps a tail of about 8 KB of stdout)
 
 
@@ -789,6 +845,9 @@ def main():
             'by_shape': profile.by_shape,
             'by_entry': {k: {'launches': v[0] // 2, 'ms_per_step': round(v[1] / 2, 3),
                              'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0} for k, v in per.items()}}
+    dist_report = None
+    if dist is not None:
+        dist_report = dist_probe(tr, step, sync, dist, world)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -828,6 +887,8 @@ def main():
             'library_sources_hash': library_sources_hash(),
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if dist_report is not None:
+            out['dist'] = dist_report
         # the committed rocprofv3 --kernel-trace --stats cross-check of this same command ON THIS BUILD (tools/roofline_check.py,
         # same session as a bench line of that card): lets a reader tell card-to-card spread from a regression
         try:

@@ -133,11 +133,13 @@ int sn_soft_nms_batch(float *d_boxes, const int32_t *d_off, int P, int max_n, si
 
 /* ------------------------------------------------------------------ test-time host loops ----- */
 /* im_worker.worker / worker_autofocus after the decode (lib/data_utils/data_workers.py:49-121): d_src_bgr (H,W,3) u8,
- * flip, crop [x1,x2) x [y1,y2) (clamped to the image), bilinear resize by `scale`, zero padded (3,out_h,out_w) f32 with
- * channel j = BGR[2-j] - pixel_means_bgr3[2-j].  resized_hw2 (host, may be NULL) receives the resized height, width
- * (im_info).  Restatement of cv2.resize(INTER_LINEAR): parity unpinned (no OpenCV here). */
-int sn_im_prepare(const uint8_t *d_src_bgr, int src_h, int src_w, int crop_x1, int crop_y1, int crop_x2, int crop_y2, float scale,
-                  int flip, const float *pixel_means_bgr3, float *d_out, int out_h, int out_w, int32_t *resized_hw2,
+ * flip, crop [x1,x2) x [y1,y2) (clamped to the image), cv2.resize(fx = fy = scale, INTER_LINEAR) in OpenCV's 8-bit
+ * fixed-point arithmetic (scale is the double the reference passes as fx / fy), zero padded (3,out_h,out_w) f32 with
+ * channel j = BGR[2-j] - pixel_means_bgr3[2-j] (host array of 3 doubles: numpy subtracts in float64).  resized_hw2
+ * (host, may be NULL) receives the resized height, width (im_info).  Bit-exact against oracle/cv_resize.py, the
+ * restatement of OpenCV's published algorithm. */
+int sn_im_prepare(const uint8_t *d_src_bgr, int src_h, int src_w, int crop_x1, int crop_y1, int crop_x2, int crop_y2, double scale,
+                  int flip, const double *pixel_means_bgr3, float *d_out, int out_h, int out_w, int32_t *resized_hw2,
                   sn_stream_t stream);
 /* bbox_pred + clip_boxes + /scale as applied per chip by lib/inference.py:127-131 (lib/bbox/bbox_transform.py:93-130,35-50):
  * rois (B*R,5) f32 with rows of chip b contiguous, deltas (B,R,4) f32, im_info (B,3) f32 -> boxes (B,R,4) f64. */

@@ -103,3 +103,19 @@ def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=2):
     m = _lib().orc_soft_nms_f32(_p(boxes), boxes.shape[0], ctypes.c_float(sigma), ctypes.c_float(Nt),
                                 ctypes.c_float(threshold), ctypes.c_uint(method))
     return boxes[:m].copy()
+
+
+def cv_resize_linear_u8c3(im, fx, fy=None):
+    """Scalar C restatement of cv2.resize(uint8 HxWx3, fx, fy, INTER_LINEAR) (sniper_oracle.c::orc_cv_resize_linear_u8c3)."""
+    fy = fx if fy is None else fy
+    im = np.ascontiguousarray(im, np.uint8)
+    H, W, C = im.shape
+    assert C == 3
+    dh, dw = ctypes.c_int(), ctypes.c_int()
+    _lib().orc_cv_dsize(H, W, ctypes.c_double(fx), ctypes.c_double(fy), ctypes.byref(dh), ctypes.byref(dw))
+    out = np.empty((max(dh.value, 0), max(dw.value, 0), 3), np.uint8)
+    _lib().orc_cv_resize_linear_u8c3.restype = ctypes.c_int
+    rc = _lib().orc_cv_resize_linear_u8c3(_p(im), H, W, ctypes.c_double(fx), ctypes.c_double(fy), _p(out))
+    if rc != 0:
+        raise ValueError('cv::resize: empty dsize')
+    return out

@@ -317,3 +317,103 @@ ORC_API int orc_soft_nms_f32(float *boxes, int N, float sigma, float Nt, float t
   }
   return N;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * cv::resize(8UC3, INTER_LINEAR, fx, fy, dsize empty) -- scalar restatement in the loop structure of OpenCV's
+ * modules/imgproc/src/resize.cpp (cv::resize -> cv::hal::resize -> resizeGeneric_ / resizeAreaFast_), see
+ * oracle/cv_resize.py for the function-by-function citation.  What im_worker (lib/data_utils/data_workers.py:65,107)
+ * calls on the decoded uint8 image.  dst must hold orc_cv_dsize() pixels.  Returns 0, or -1 for an empty dsize.
+ * Pinned to the published algorithm (no OpenCV in this image to mint vectors).                                        */
+static int orc_cv_round(double v) { return (int)lrint(v); }            /* cvRound: nearest, ties to even */
+static int orc_cv_roundf(float v) { return (int)lrintf(v); }
+static int orc_cv_floorf(float v) { int i = (int)v; return i - (i > v); }
+static short orc_sat_short_f(float v) { int i = orc_cv_roundf(v); return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i); }
+static unsigned char orc_sat_u8_f(float v) { int i = orc_cv_roundf(v); return (unsigned char)(i < 0 ? 0 : i > 255 ? 255 : i); }
+static int orc_clip(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+
+void orc_cv_dsize(int h, int w, double fx, double fy, int *dh, int *dw) {
+  *dw = orc_cv_round(w * fx);
+  *dh = orc_cv_round(h * fy);
+}
+
+int orc_cv_resize_linear_u8c3(const unsigned char *src, int H, int W, double inv_scale_x, double inv_scale_y, unsigned char *dst) {
+  const int cn = 3;
+  int dw, dh;
+  orc_cv_dsize(H, W, inv_scale_x, inv_scale_y, &dh, &dw);
+  if (dw <= 0 || dh <= 0) return -1;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  const int iscale_x = orc_cv_round(scale_x), iscale_y = orc_cv_round(scale_y);
+  const int is_area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+  if (is_area_fast && iscale_x == 2 && iscale_y == 2) {          /* INTER_LINEAR -> INTER_AREA (fast), 2 x 2 */
+    const int dwidth1 = (W / 2) * cn, dwidth = dw * cn, swidth = W * cn;
+    for (int dy = 0; dy < dh; ++dy) {
+      unsigned char *D = dst + (size_t)dy * dwidth;
+      const int sy0 = dy * 2;
+      const int w = sy0 + 2 <= H ? dwidth1 : 0;
+      int dx = 0;
+      if (sy0 >= H) { for (; dx < dwidth; ++dx) D[dx] = 0; continue; }
+      const unsigned char *S = src + (size_t)sy0 * swidth, *nextS = S + swidth;
+      for (; dx < w; ++dx) {                                     /* ResizeAreaFastVec, fast_mode, cn == 3 */
+        const int index = (dx / cn) * 2 * cn + dx % cn;
+        D[dx] = (unsigned char)((S[index] + S[index + cn] + nextS[index] + nextS[index + cn] + 2) >> 2);
+      }
+      for (; dx < dwidth; ++dx) {
+        int sum = 0, count = 0;
+        const int sx0 = (dx / cn) * 2 * cn + dx % cn;
+        if (sx0 >= swidth) D[dx] = 0;
+        for (int sy = 0; sy < 2; ++sy) {
+          if (sy0 + sy >= H) break;
+          const unsigned char *R = src + (size_t)(sy0 + sy) * swidth + sx0;
+          for (int sx = 0; sx < 2 * cn; sx += cn) {
+            if (sx0 + sx >= swidth) break;
+            sum += R[sx];
+            ++count;
+          }
+        }
+        D[dx] = orc_sat_u8_f((float)sum / count);
+      }
+    }
+    return 0;
+  }
+  int *xofs = (int *)malloc(sizeof(int) * (size_t)dw), *yofs = (int *)malloc(sizeof(int) * (size_t)dh);
+  short *ialpha = (short *)malloc(sizeof(short) * 2 * (size_t)dw), *ibeta = (short *)malloc(sizeof(short) * 2 * (size_t)dh);
+  int *row0 = (int *)malloc(sizeof(int) * (size_t)dw * cn), *row1 = (int *)malloc(sizeof(int) * (size_t)dw * cn);
+  int xmax = dw;
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = orc_cv_floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0, sx = 0; }
+    if (sx + 1 >= W) {
+      xmax = xmax < dx ? xmax : dx;
+      if (sx >= W - 1) { fx = 0, sx = W - 1; }
+    }
+    xofs[dx] = sx;
+    ialpha[dx * 2] = orc_sat_short_f((1.f - fx) * 2048);
+    ialpha[dx * 2 + 1] = orc_sat_short_f(fx * 2048);
+  }
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = orc_cv_floorf(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    ibeta[dy * 2] = orc_sat_short_f((1.f - fy) * 2048);
+    ibeta[dy * 2 + 1] = orc_sat_short_f(fy * 2048);
+  }
+  for (int dy = 0; dy < dh; ++dy) {
+    int *rows[2] = {row0, row1};
+    for (int k = 0; k < 2; ++k) {                                /* HResizeLinear over the two source rows of dy */
+      const unsigned char *S = src + (size_t)orc_clip(yofs[dy] + k, 0, H) * W * cn;
+      int *Dr = rows[k];
+      for (int dx = 0; dx < dw; ++dx)
+        for (int c = 0; c < cn; ++c)
+          Dr[dx * cn + c] = dx < xmax ? S[xofs[dx] * cn + c] * ialpha[dx * 2] + S[(xofs[dx] + 1) * cn + c] * ialpha[dx * 2 + 1]
+                                      : S[xofs[dx] * cn + c] * 2048;
+    }
+    const short b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+    unsigned char *D = dst + (size_t)dy * dw * cn;
+    for (int x = 0; x < dw * cn; ++x) D[x] = (unsigned char)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(xofs); free(yofs); free(ialpha); free(ibeta); free(row0); free(row1);
+  return 0;
+}

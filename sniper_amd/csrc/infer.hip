@@ -1,48 +1,84 @@
 // infer.hip -- the two host loops either side of the test-time graph, on the GPU.
 //
 //  * im_prepare: im_worker.worker / worker_autofocus (lib/data_utils/data_workers.py:49-121) after the JPEG decode:
-//    optional horizontal flip, integer crop, bilinear resize by `scale`, zero padding to (3, Hm, Wm) float32 with
-//    channel j = BGR[2 - j] - PIXEL_MEANS[2 - j].  The reference resizes with cv2.resize(INTER_LINEAR) on uint8
-//    (fixed-point coefficients, rounded uint8 output); OpenCV is not in this image, so the arithmetic here --
-//    half-pixel centres, source size round(n * scale), float bilinear, result rounded to the nearest integer like the
-//    uint8 image cv2 returns -- is a documented restatement: PARITY UNPINNED.
+//    optional horizontal flip, integer crop, cv2.resize(fx = fy = scale, INTER_LINEAR) on uint8, zero padding to
+//    (3, Hm, Wm) float32 with channel j = BGR[2 - j] - PIXEL_MEANS[2 - j].  The resize is OpenCV's published 8-bit
+//    algorithm in its own integer arithmetic (11-bit fixed-point coefficients, integer horizontal and vertical passes,
+//    the 2 x 2 INTER_AREA substitution), bit-exact against oracle/cv_resize.py and its scalar C twin: pinned to the
+//    published algorithm (OpenCV itself is not in this image).
 //  * bbox_decode: bbox_pred (= nonlinear_pred, lib/bbox/bbox_transform.py:93-130) + clip_boxes (:35-50) + division by
 //    the image scale, as lib/inference.py:127-131 applies them per chip; float64 like the numpy original
 //    (boxes.astype(np.float)), compiled with -ffp-contract=off, exp() in double.
 #include "common.h"
 #include <string.h>
 
+// cv::resize's 8-bit INTER_LINEAR in OpenCV's own integer arithmetic (modules/imgproc/src/resize.cpp; restated with the
+// function-by-function citation in oracle/cv_resize.py): coefficient of a destination column / row from
+// f = (float)((d + 0.5) * scale - 0.5) in double-then-float as written there, 11-bit fixed-point coefficients
+// (saturate_cast<short>(c * 2048), ties to even), integer horizontal pass, vertical pass
+// (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  An exact 2 x 2 decimation is OpenCV's INTER_AREA fast path
+// instead (AREA = true): whole blocks (a + b + c + d + 2) >> 2, the ragged last column / row of an odd source size the float mean
+// of the pixels that exist, rounded to even.  One thread per destination pixel, three channels; this file is compiled with
+// -ffp-contract=off (no FMA where OpenCV's scalar code has none).
+__device__ __forceinline__ int cv_sat_short(float v) {
+  const int i = (int)rintf(v);                          // cvRound: nearest, ties to even
+  return i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
+}
+
+template <bool AREA>
 __global__ __launch_bounds__(256) void im_prepare_kernel(const unsigned char *__restrict__ src, int SH, int SW, int x1, int y1,
-                                                         int cw, int ch, float scale, int flip, float m0, float m1, float m2,
+                                                         int cw, int ch, double scale, int flip, double m0, double m1, double m2,
                                                          float *__restrict__ out, int Hm, int Wm, int oh, int ow) {
   const long total = (long)Hm * Wm;
+  const double mean[3] = {m0, m1, m2};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(i % Wm), oy = (int)(i / Wm);
     float v[3] = {0.f, 0.f, 0.f};
     if (oy < oh && ox < ow) {
-      // cv2.resize with fx = fy = scale: source coordinate of the centre of destination pixel (ox, oy)
-      const float inv = 1.f / scale;
-      float fx = ((float)ox + 0.5f) * inv - 0.5f, fy = ((float)oy + 0.5f) * inv - 0.5f;
-      int sx = (int)floorf(fx), sy = (int)floorf(fy);
-      float ax = fx - (float)sx, ay = fy - (float)sy;
-      if (sx < 0) { sx = 0; ax = 0.f; }
-      if (sy < 0) { sy = 0; ay = 0.f; }
-      if (sx >= cw - 1) { sx = cw - 1 > 0 ? cw - 2 : 0; ax = cw > 1 ? 1.f : 0.f; }
-      if (sy >= ch - 1) { sy = ch - 1 > 0 ? ch - 2 : 0; ay = ch > 1 ? 1.f : 0.f; }
-      const int sx1 = sx + (cw > 1 ? 1 : 0), sy1 = sy + (ch > 1 ? 1 : 0);
-      auto px = [&](int yy, int xx, int c) -> float {
+      auto px = [&](int yy, int xx, int c) -> int {
         int gx = x1 + xx;
         if (flip) gx = SW - 1 - gx;                      // im[:, ::-1, :] before the crop (worker:88-89)
-        return (float)src[((size_t)(y1 + yy) * SW + gx) * 3 + c];
+        return (int)src[((size_t)(y1 + yy) * SW + gx) * 3 + c];
       };
-      const float mean[3] = {m0, m1, m2};
+      int res[3];
+      if (AREA) {
+        const int sx0 = 2 * ox, sy0 = 2 * oy;
+        const bool whole = sx0 + 2 <= cw && sy0 + 2 <= ch;
+        const int nx = sx0 + 2 <= cw ? 2 : 1, ny = sy0 + 2 <= ch ? 2 : 1;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int c = 2 - j;                              // output channel j = BGR[2 - j]
-        const float top = px(sy, sx, c) * (1.f - ax) + px(sy, sx1, c) * ax;
-        const float bot = px(sy1, sx, c) * (1.f - ax) + px(sy1, sx1, c) * ax;
-        v[j] = rintf(top * (1.f - ay) + bot * ay) - mean[c];
+        for (int c = 0; c < 3; ++c) {
+          int sum = 0;
+          for (int yy = 0; yy < ny; ++yy)
+            for (int xx = 0; xx < nx; ++xx) sum += px(sy0 + yy, sx0 + xx, c);
+          if (whole) {
+            res[c] = (sum + 2) >> 2;
+          } else {
+            const int r = (int)rintf((float)sum / (float)(nx * ny));          // saturate_cast<uchar>((float)sum / count)
+            res[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+          }
+        }
+      } else {
+        float fx = (float)(((double)ox + 0.5) * scale - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= cw - 1) { fx = 0.f; sx = cw - 1; }
+        const int a0 = cv_sat_short((1.f - fx) * 2048.f), a1 = cv_sat_short(fx * 2048.f);
+        const int sx1 = sx + 1 < cw ? sx + 1 : cw - 1;   // (a1 = 0 wherever sx + 1 leaves the row: OpenCV's S[sx] * 2048 branch)
+        float fy = (float)(((double)oy + 0.5) * scale - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;                                 // rows are clipped, the coefficients are not
+        const int b0 = cv_sat_short((1.f - fy) * 2048.f), b1 = cv_sat_short(fy * 2048.f);
+        const int r0 = sy < 0 ? 0 : (sy < ch ? sy : ch - 1), r1 = sy + 1 < 0 ? 0 : (sy + 1 < ch ? sy + 1 : ch - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int t0 = px(r0, sx, c) * a0 + px(r0, sx1, c) * a1;
+          const int t1 = px(r1, sx, c) * a0 + px(r1, sx1, c) * a1;
+          res[c] = ((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v[j] = (float)((double)res[2 - j] - mean[2 - j]);   // uint8 - float64 -> float64 -> float32 (:71,117)
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) out[(size_t)j * Hm * Wm + i] = v[j];
@@ -50,23 +86,30 @@ __global__ __launch_bounds__(256) void im_prepare_kernel(const unsigned char *__
 }
 
 SN_EXPORT int sn_im_prepare(const uint8_t *d_src_bgr, int src_h, int src_w, int crop_x1, int crop_y1, int crop_x2, int crop_y2,
-                            float scale, int flip, const float *pixel_means_bgr3, float *d_out, int out_h, int out_w,
+                            double scale, int flip, const double *pixel_means_bgr3, float *d_out, int out_h, int out_w,
                             int32_t *resized_hw2, sn_stream_t stream) {
-  SN_REQUIRE(d_src_bgr && d_out && pixel_means_bgr3 && src_h > 0 && src_w > 0 && out_h > 0 && out_w > 0 && scale > 0.f,
+  SN_REQUIRE(d_src_bgr && d_out && pixel_means_bgr3 && src_h > 0 && src_w > 0 && out_h > 0 && out_w > 0 && scale > 0.,
              "sn_im_prepare: bad arguments");
   const int x1 = crop_x1 < 0 ? 0 : crop_x1, y1 = crop_y1 < 0 ? 0 : crop_y1;
   const int x2 = crop_x2 > src_w ? src_w : crop_x2, y2 = crop_y2 > src_h ? src_h : crop_y2;
   SN_REQUIRE(x2 > x1 && y2 > y1, "sn_im_prepare: empty crop");
   const int cw = x2 - x1, ch = y2 - y1;
-  int rw = (int)lrintf((float)cw * scale), rh = (int)lrintf((float)ch * scale);   // cv2: saturate_cast<int>(n * f)
-  if (rw < 1) rw = 1;
-  if (rh < 1) rh = 1;
+  const int rw = (int)lrint((double)cw * scale), rh = (int)lrint((double)ch * scale);   // cv::resize: saturate_cast<int>(n * f)
+  SN_REQUIRE(rw > 0 && rh > 0, "sn_im_prepare: the resized image is empty (cv::resize asserts !dsize.empty())");
   if (resized_hw2) { resized_hw2[0] = rh; resized_hw2[1] = rw; }
   const int oh = rh < out_h ? rh : out_h, ow = rw < out_w ? rw : out_w;
+  // cv::hal::resize: scale = 1 / inv_scale; INTER_LINEAR with an exact 2 x 2 decimation runs as INTER_AREA (fast)
+  const double inv = 1. / scale;
+  const int iscale = (int)lrint(inv);
+  const bool area = fabs(inv - (double)iscale) < 2.220446049250313e-16 && iscale == 2;
   long blocks = ((long)out_h * out_w + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(im_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), d_src_bgr, src_h, src_w, x1, y1, cw,
-                     ch, scale, flip, pixel_means_bgr3[0], pixel_means_bgr3[1], pixel_means_bgr3[2], d_out, out_h, out_w, oh, ow);
+  if (area)
+    hipLaunchKernelGGL(im_prepare_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), d_src_bgr, src_h, src_w, x1, y1,
+                       cw, ch, /* scale_x = scale_y = */ inv, flip, pixel_means_bgr3[0], pixel_means_bgr3[1], pixel_means_bgr3[2], d_out, out_h, out_w, oh, ow);
+  else
+    hipLaunchKernelGGL(im_prepare_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), d_src_bgr, src_h, src_w, x1, y1,
+                       cw, ch, /* scale_x = scale_y = */ inv, flip, pixel_means_bgr3[0], pixel_means_bgr3[1], pixel_means_bgr3[2], d_out, out_h, out_w, oh, ow);
   SN_CHECK_LAUNCH();
   return SN_OK;
 }

@@ -90,7 +90,7 @@ class im_worker(object):
         self.cfg = cfg
         self.crop_size = crop_size
         self.target_size = target_size if target_size else cfg.TRAIN.SCALES[0]
-        self.means = np.asarray(cfg.network.PIXEL_MEANS, np.float32)
+        self.means = np.asarray(cfg.network.PIXEL_MEANS, np.float64)      # (uint8 - float64 in the reference: the subtraction is done in double)
         self._cache = image_cache if image_cache is not None else DeviceImageCache(256 * 4 << 20)
 
     def _device_image(self, image):

@@ -612,11 +612,80 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None)
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
+def shard_images(n_images, rank, world):
+    """Images of rank `rank`: every world-th image (shard images across ranks).  Interleaved, not contiguous: a roidb is
+    sorted by nothing in particular, but its tail may hold the large images."""
+    return list(range(int(rank), int(n_images), int(world)))
+
+
+def merge_rank_detections(gathered, n_images, num_classes, world):
+    """Per-rank per-scale detections (what every rank's `_multi_scale_detections` produced for ITS images, in local image order)
+    -> per-scale detections over all images in roidb order: image g = rank + world * local.  The counterpart of the reference's
+    merge across its forked jobs (lib/inference.py:494-500), done before `aggregate`."""
+    n_scales = len(gathered[0])
+    merged = []
+    for s in range(n_scales):
+        d = _Detections([[[] for _ in range(n_images)] for _ in range(num_classes)])
+        for r in range(world):
+            cls_lists, compact = gathered[r][s]
+            ids = shard_images(n_images, r, world)
+            for j in range(num_classes):
+                for li, g in enumerate(ids):
+                    d[j][g] = cls_lists[j][li]
+            d.compact.update({(ids[li], c): v for (li, c), v in compact.items()})
+        merged.append(d)
+    return merged
+
+
 def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
-                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=1):
+                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=1, rank=None, world=None,
+                           group=None):
+    """Multi-scale inference + aggregation (lib/inference.py:439-529), see `_multi_scale_detections`.
+    rank / world (default: the initialised torch.distributed group, else one process): rank r runs images r, r + world, ... through
+    all the scales -- (image, chip) units are independent, the FocusChips of an image come from its own maps -- the per-scale
+    detections are gathered on rank 0 (`gather_object`; rows of a few MB per rank and pass, no tensor collective) and rank 0 alone
+    aggregates, as the reference merges its forked jobs before `aggregate` (:494-500).  Other ranks return None."""
+    if world is None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            world, rank = 1, 0
+    rank = int(rank or 0)
+    if world > 1:
+        import torch.distributed as dist
+        ids = shard_images(len(roidb), rank, world)
+        local = [roidb[g] for g in ids]
+        fmap = None if focus_map_fn is None else (lambda s_i, i, c, m: focus_map_fn(s_i, ids[i], c, m))
+        dets = _multi_scale_detections(sym_def, config, imdb, local, context, arg_params, aux_params, vis, module_cache, fmap,
+                                       concurrent_jobs, lanes) if local else \
+            [_Detections([[] for _ in range(imdb.num_classes)]) for _ in config.TEST.SCALES]
+        payload = [([list(d[j]) for j in range(imdb.num_classes)], dict(getattr(d, 'compact', {}))) for d in dets]
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(payload, gathered, dst=0, group=group)
+        from .engine.executor import resettle_heap
+        if rank != 0:
+            resettle_heap()
+            return (None, None) if return_scale_dets else None
+        detections = merge_rank_detections(gathered, len(roidb), imdb.num_classes, world)
+    else:
+        detections = _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis, module_cache,
+                                             focus_map_fn, concurrent_jobs, lanes)
+    tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
+    out = tester.aggregate(detections, vis=False, cache_name=None)
+    # the pass's own objects (iterators, device image cache) are gone; if a new batch shape froze the heap while they were alive,
+    # collect what died in cycles and freeze again (engine/executor.py::resettle_heap)
+    del tester
+    from .engine.executor import resettle_heap
+    resettle_heap()
+    return (out, detections) if return_scale_dets else out
+
+
+def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
+                            focus_map_fn=None, concurrent_jobs=1, lanes=1):
     """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
-    AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips); detections of all scales
-    are aggregated under TEST.VALID_RANGES with per-class NMS.
+    AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips).  -> the per-scale detections
+    (imdb_detection_wrapper aggregates them under TEST.VALID_RANGES with per-class NMS).
     concurrent_jobs (TEST.CONCURRENT_JOBS, :452-500): the roidb is cut into that many contiguous parts and every scale runs the
     parts CONCURRENTLY -- the reference forks one model process per part; here one thread per part, each with its own bound
     Module and its own HIP stream on this process's GPU (a batch of two FocusChips at the finest scale leaves most of the 256
@@ -696,11 +765,5 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
         pool.close()
     if module_cache is not None:
         module_cache['__passes__'] = module_cache.get('__passes__', 0) + 1
-    tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
-    out = tester.aggregate(detections, vis=False, cache_name=None)
-    # the pass's own objects (iterators, device image cache) are gone or go now; if a new batch shape froze the heap while they
-    # were alive, collect what died in cycles and freeze again (engine/executor.py::resettle_heap)
-    del image_cache, tester
-    from .engine.executor import resettle_heap
-    resettle_heap()
-    return (out, detections) if return_scale_dets else out
+    del image_cache
+    return detections

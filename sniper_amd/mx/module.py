@@ -350,13 +350,16 @@ class Module(object):
         exe = self.exe
         if getattr(self, '_comm_stream', None) is None:
             self._comm_stream = torch.cuda.Stream(device=exe.arena_grad.device)
-        ready = torch.cuda.Event()
+        probe = getattr(self, '_comm_probe', None)       # bench.py: a list -> timed events of this step's overlap (else untimed events)
+        ready = torch.cuda.Event(enable_timing=probe is not None)
         ready.record(torch.cuda.current_stream())
         self._comm_stream.wait_event(ready)
         with torch.cuda.stream(self._comm_stream):
             allreduce_ranges(exe.grad_arena(), [(h, a, b) for ph, h, a, b in exe.ar_ranges if ph == 0], d, self._half_buf())
-            self._comm_event = torch.cuda.Event()
+            self._comm_event = torch.cuda.Event(enable_timing=probe is not None)
             self._comm_event.record(self._comm_stream)
+        if probe is not None:
+            probe.append({'seg2_start': ready, 'comm_end': self._comm_event})
 
     def update(self):
         from ..parallel import allreduce_ranges
@@ -364,6 +367,11 @@ class Module(object):
         if d is not None and d.get_world_size() > 1:          # sum over ranks == kvstore 'device' push/pull
             exe = self.exe
             first_done = getattr(self, '_comm_event', None) is not None
+            probe = getattr(self, '_comm_probe', None)
+            if probe and first_done and 'seg2_end' not in probe[-1]:
+                e = torch.cuda.Event(enable_timing=True)       # the second backward segment has been enqueued: its end on the main stream
+                e.record(torch.cuda.current_stream())
+                probe[-1]['seg2_end'] = e
             rest = [(h, a, b) for ph, h, a, b in exe.ar_ranges if not (first_done and ph == 0)]
             allreduce_ranges(exe.grad_arena(), rest, d, self._half_buf())
             if first_done:

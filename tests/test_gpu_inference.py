@@ -23,62 +23,50 @@ def _roidb(n, rs, sizes=((480, 640), (640, 480))):
     return out
 
 
-def _np_im_prepare(im, crop, scale, flip, means, out_hw):
-    """numpy statement of sn_im_prepare's documented arithmetic (half-pixel centres, float bilinear, rint)."""
-    if flip:
-        im = im[:, ::-1, :]
-    x1, y1, x2, y2 = crop
-    im = im[max(y1, 0):min(y2, im.shape[0]), max(x1, 0):min(x2, im.shape[1]), :].astype(np.float32)
-    ch, cw = im.shape[:2]
-    rh, rw = max(int(np.rint(np.float32(ch) * np.float32(scale))), 1), max(int(np.rint(np.float32(cw) * np.float32(scale))), 1)
-    inv = np.float32(1.0) / np.float32(scale)
-
-    def axis(n_out, n_in):
-        f = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * inv - np.float32(0.5)
-        s = np.floor(f).astype(int)
-        a = (f - s).astype(np.float32)
-        a[s < 0] = 0
-        s[s < 0] = 0
-        hi = s >= n_in - 1
-        s[hi] = max(n_in - 2, 0)
-        a[hi] = 1.0 if n_in > 1 else 0.0
-        return s, np.minimum(s + (1 if n_in > 1 else 0), n_in - 1), a
-    sy, sy1, ay = axis(rh, ch)
-    sx, sx1, ax = axis(rw, cw)
-    top = im[sy][:, sx] * (1 - ax)[None, :, None] + im[sy][:, sx1] * ax[None, :, None]
-    bot = im[sy1][:, sx] * (1 - ax)[None, :, None] + im[sy1][:, sx1] * ax[None, :, None]
-    res = np.rint(top * (1 - ay)[:, None, None] + bot * ay[:, None, None])
-    out = np.zeros((3, out_hw[0], out_hw[1]), np.float32)
-    h, w = min(rh, out_hw[0]), min(rw, out_hw[1])
-    for j in range(3):
-        out[j, :h, :w] = res[:h, :w, 2 - j] - means[2 - j]
-    return out, (rh, rw)
-
-
-def test_im_prepare_against_its_statement():
+def test_im_prepare_is_bit_exact_with_opencv_8bit_inter_linear():
+    """sn_im_prepare == im_worker.worker / worker_autofocus (lib/data_utils/data_workers.py:49-121) with cv2.resize(INTER_LINEAR) on
+    uint8 restated from OpenCV's published fixed-point algorithm (oracle/cv_resize.py, cross-checked against its scalar C twin in
+    tests/test_oracle_cv_resize.py): flips, crops beyond the image, up- and down-scaling, the 2 x 2 INTER_AREA substitution with
+    odd sizes, the SNIPER train / test scales, tiny crops, padding smaller and larger than the resized image.  Byte work: equal."""
     import ctypes
+    from oracle import cv_resize
     from sniper_amd import hip
     rs = np.random.RandomState(0)
-    im = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
-    means = np.array([103.939, 116.779, 123.68], np.float32)
+    means = np.array([103.939, 116.779, 123.68], np.float64)
+    cases = 0
+    for (H, W) in ((37, 53), (48, 64), (31, 31), (5, 7)):
+        im = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        d = torch.from_numpy(im).to(dev())
+        for scale in (1.0, 1.7, 0.5, 3.0, 2.25, 512.0 / 480.0, 1.0 / 0.6, 2.9167, 0.8, 1400.0 / 480.0, 0.3, 2.0, 0.5000001, 0.25):
+            for flip in (0, 1):
+                x1, y1 = int(rs.randint(-3, W // 2)), int(rs.randint(-3, H // 2))
+                x2, y2 = int(rs.randint(max(x1, 0) + 1, W + 4)), int(rs.randint(max(y1, 0) + 1, H + 4))
+                crop = (0, 0, W, H) if rs.rand() < 0.3 else (x1, y1, x2, y2)
+                cw, ch = min(crop[2], W) - max(crop[0], 0), min(crop[3], H) - max(crop[1], 0)
+                rh, rw = cv_resize.dsize_of(ch, cw, scale, scale)
+                if rh < 1 or rw < 1:
+                    continue
+                out_hw = (int(rs.randint(max(rh - 6, 1), rh + 9)), int(rs.randint(max(rw - 6, 1), rw + 9)))
+                out = torch.full((3,) + out_hw, 9.0, dtype=torch.float32, device=dev())
+                hw = (ctypes.c_int32 * 2)()
+                hip.call('sn_im_prepare', d, H, W, crop[0], crop[1], crop[2], crop[3], float(scale), flip,
+                         means.ctypes.data_as(ctypes.c_void_p), out, out_hw[0], out_hw[1], hw, hip.stream())
+                want, got_hw = cv_resize.im_prepare(im, crop, scale, bool(flip), means, out_hw)
+                assert (hw[0], hw[1]) == got_hw == (rh, rw)
+                got = out.cpu().numpy()
+                assert np.array_equal(got, want), (H, W, crop, scale, flip, out_hw, np.abs(got - want).max(), (got != want).mean())
+                cases += 1
+    assert cases > 100
+    # a 640 x 480 image at the three AutoFocus test scales, whole image (what the first scale of a pass prepares)
+    im = rs.randint(0, 256, (480, 640, 3)).astype(np.uint8)
     d = torch.from_numpy(im).to(dev())
-    for crop, scale, flip, out_hw in (((0, 0, 53, 37), 1.0, 0, (40, 56)), ((5, 3, 40, 30), 1.7, 0, (64, 64)),
-                                      ((0, 0, 53, 37), 0.5, 1, (19, 27)), ((10, 10, 11, 11), 3.0, 0, (8, 8)),
-                                      ((-4, -2, 60, 50), 2.25, 1, (90, 100))):
-        out = torch.full((3,) + out_hw, 9.0, dtype=torch.float32, device=dev())
-        hw = (ctypes.c_int32 * 2)()
-        hip.call('sn_im_prepare', d, 37, 53, crop[0], crop[1], crop[2], crop[3], scale, flip, means.ctypes.data_as(ctypes.c_void_p), out,
-                 out_hw[0], out_hw[1], hw, hip.stream())
-        want, (rh, rw) = _np_im_prepare(im, crop, scale, flip, means, out_hw)
-        assert (hw[0], hw[1]) == (rh, rw)
-        got = out.cpu().numpy()
-        # bilinear weights are float32 on both sides; an exact .5 before rint may round differently: allow 1 level on <0.1%
-        diff = np.abs(got - want)
-        assert diff.max() <= 1.0 and (diff > 0).mean() < 1e-3, (crop, scale, diff.max(), (diff > 0).mean())
-    # scale 1, no crop: exact copy with channel reversal and mean subtraction
-    out = torch.empty((3, 37, 53), dtype=torch.float32, device=dev())
-    hip.call('sn_im_prepare', d, 37, 53, 0, 0, 53, 37, 1.0, 0, means.ctypes.data_as(ctypes.c_void_p), out, 37, 53, None, hip.stream())
-    assert np.array_equal(out.cpu().numpy(), im[:, :, ::-1].transpose(2, 0, 1).astype(np.float32) - means[::-1, None, None])
+    for scale in (1.0, 800.0 / 480.0, 1400.0 / 480.0):
+        rh, rw = cv_resize.dsize_of(480, 640, scale, scale)
+        out = torch.empty((3, rh + 3, rw + 5), dtype=torch.float32, device=dev())
+        hip.call('sn_im_prepare', d, 480, 640, 0, 0, 640, 480, float(scale), 0, means.ctypes.data_as(ctypes.c_void_p), out, rh + 3, rw + 5,
+                 None, hip.stream())
+        want, _ = cv_resize.im_prepare(im, (0, 0, 640, 480), scale, False, means, (rh + 3, rw + 5))
+        assert np.array_equal(out.cpu().numpy(), want)
 
 
 def test_bbox_decode_matches_numpy_bbox_pred():
@@ -249,6 +237,21 @@ def test_lanes_and_device_compaction_equal_the_host_loops():
         for j in range(1, 81):
             for wi, gi in zip(want_final[j], got_final[j]):
                 assert np.array_equal(wi, gi)
+
+
+def test_rank_sharded_inference_equals_one_process():
+    """two ranks (gloo, sharing this one card -- a rehearsal of the control flow) each run every second image through
+    both scales, rank 0 gathers and aggregates: final boxes bit-equal to the whole roidb in one process (tests/infer_shard_worker.py;
+    the CPU-only twin with stand-in forwards is tests/test_infer_shard_gloo.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONDONTWRITEBYTECODE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(root, 'tests', 'infer_shard_worker.py')]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and 'SHARD_RESULT ok=1' in r.stdout, r.stdout[-3000:]
 
 
 def test_inference_forward_graph_replay_equals_eager():
