@@ -737,6 +737,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--inference', action='store_true', help='(default on rank 0 at N = 1; kept for old command lines)')
     ap.add_argument('--no-inference', action='store_true', help='skip BASELINE config C5 (inf images/sec)')
+    ap.add_argument('--no-fit-path', action='store_true', help='skip the reference main_train.py throughput leg (fit_path)')
     args = ap.parse_args()
 
     # the host driver only supports dmabuf IPC: without this RCCL's peer mapping fails with hipIpcGetMemHandle: invalid argument
@@ -870,6 +871,23 @@ def main():
                 {'value': None, 'sample': 'failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
         except Exception as e:   # noqa: BLE001
             cpu['chip_db_through_shim'] = {'value': None, 'sample': 'failed: %r' % (e,)}
+    fit_path = None
+    if rank == 0 and world == 1 and not args.no_fit_path:
+        # what a user of the drop-in gets: the reference's unchanged main_train.py -- PrefetchingIter + mod.fit +
+        # its six EvalMetrics + Speedometer -- at BATCH_IMAGES 20 over the lib/iterators mirrors, images decoded from JPEG files,
+        # chips/s from wall time over 50 batches; own process, on this card right after the timed steps (tools/fit_path_bench.py)
+        try:
+            import subprocess
+            torch.cuda.empty_cache()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fit_path_bench.py'), 'mirror', str(args.batch), '50'], cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420,
+                               env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            fit_path = json.loads(lines[-1]) if lines else {'value': None, 'sample': 'failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
+            if fit_path.get('value'):
+                fit_path['ratio_to_value'] = round(fit_path['value'] / value, 3)
+        except Exception as e:   # noqa: BLE001 -- a report
+            fit_path = {'value': None, 'sample': 'failed: %r' % (e,)}
     if rank == 0:
         out = {
             'metric': 'train chips/sec (512x512, R101)', 'value': round(value, 2), 'unit': 'chips/s', 'n_gpus': world,
@@ -889,6 +907,8 @@ def main():
         }
         if dist_report is not None:
             out['dist'] = dist_report
+        if fit_path is not None:
+            out['fit_path'] = fit_path
         # the committed rocprofv3 --kernel-trace --stats cross-check of this same command ON THIS BUILD (tools/roofline_check.py,
         # same session as a bench line of that card): lets a reader tell card-to-card spread from a regression
         try:

@@ -81,6 +81,12 @@ class DeviceImageCache(object):
             self._bytes += n
         return d
 
+    def holds(self, image):
+        key = image if isinstance(image, str) else id(image)
+        with self._lock:
+            ent = self._d.get(key)
+            return ent is not None and (isinstance(image, str) or ent[0] is image)
+
     def __len__(self):
         return len(self._d)
 

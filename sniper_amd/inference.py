@@ -263,7 +263,7 @@ class Tester(object):
         self.test_iter = test_iter
         self._own_iter = False
         if test_iter is not None and not isinstance(test_iter, PrefetchingIter):
-            self.test_iter = PrefetchingIter(self.test_iter, depth=len(module) if isinstance(module, (list, tuple)) else 1)
+            self.test_iter = PrefetchingIter(self.test_iter, depth=max(2, len(module)) if isinstance(module, (list, tuple)) else 2)
             self._own_iter = True
             self.scale = test_iter.test_scale
         self.cfg = cfg
@@ -351,9 +351,9 @@ class Tester(object):
             return self._launch_on(batch, lane, compact)
 
     def _launch_on(self, batch, lane, compact):
-        ready = getattr(batch, 'ready_event', None)        # the prefetch thread's image-preparation launches (PrefetchingIter)
-        if ready is not None:
-            torch.cuda.current_stream().wait_event(ready)
+        if getattr(batch, 'ready_event', None) is not None:   # the prefetch thread's image-preparation launches, on ITS stream
+            from .iterators.PrefetchingIter import adopt_batch
+            adopt_batch(batch)
         data = dict(zip(self.data_names, batch.data))
         outputs = self.forward(batch, lane)
         flips = self.__dict__.setdefault('_pin_flip', {})
@@ -597,6 +597,7 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None)
         sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
         sym = sym_inst.get_symbol_rcnn(config, is_train=False)
         mod = mx.mod.Module(symbol=sym, context=context, data_names=[k[0] for k in test_iter.provide_data_single], label_names=None)
+        mod.slice_inputs = False         # test time: a rank's batches are its own images (imdb_detection_wrapper shards the roidb)
         mod.bind(test_iter.provide_data, test_iter.provide_label, for_training=False)
         if mods:                 # a further lane: the first lane's parameters (a random initialisation must not differ per lane)
             a0, x0 = mods[0].get_params()

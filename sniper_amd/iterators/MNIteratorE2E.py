@@ -68,6 +68,10 @@ class MNIteratorE2E(mx.io.DataIter):
         else:
             self.im_worker = None
             self.im_source = synthetic_im_source(crop_size) if im_source == 'synthetic' else im_source
+        # the reference decodes the images of a batch on `threads` pool threads (self.thread_pool.map_async(im_worker.worker), :147);
+        # here the pool only decodes + uploads the batch's images that are not yet resident (DeviceImageCache) -- the crop / resize
+        # / mean subtraction of a chip is a kernel launch
+        self.threads, self._decode_pool = max(1, int(threads)), None
         self.epiter = 0
         self.seed = 0
         self.batch = None
@@ -166,6 +170,7 @@ class MNIteratorE2E(mx.io.DataIter):
         worker_data = []
         dev = hip.require_gpu()
         if self.im_worker is not None:      # chips are written in HBM by sn_im_prepare, one launch per chip
+            self._decode_ahead([r['image'] for r in roidb], dev)
             ims = torch.zeros((n, 3, self.crop_size[0], self.crop_size[1]), dtype=torch.float32, device=dev)
         else:
             ims = np.zeros((n, 3, self.crop_size[0], self.crop_size[1]), np.float32)
@@ -205,6 +210,33 @@ class MNIteratorE2E(mx.io.DataIter):
                                 provide_data=self.provide_data, provide_label=self.provide_label)
         batch.worker_data = worker_data   # the anchor-labelling inputs (bench.py re-runs the labelling per step)
         return batch
+
+
+    def _decode_ahead(self, images, dev):
+        """Decode + upload the distinct images of a batch that the device cache does not hold yet, on `threads` threads (JPEG /
+        PNG decoding releases the interpreter lock; one image is 3-10 ms, a batch of 20 chips meets ~3-20 new ones)."""
+        if self.threads <= 1:
+            return
+        cache = getattr(self.im_worker, '_cache', None)
+        need, seen = [], set()
+        for im in images:
+            key = im if isinstance(im, str) else id(im)
+            if key in seen or (cache is not None and cache.holds(im)):
+                continue
+            seen.add(key)
+            need.append(im)
+        if len(need) < 2:
+            return
+        if self._decode_pool is None:
+            from multiprocessing.pool import ThreadPool
+            st = torch.cuda.current_stream()       # uploads on the assembling thread's stream (the prefetch worker's own), not on
+            #                                        the default stream the training step occupies
+
+            def init():
+                torch.cuda.set_device(dev)
+                torch.cuda.set_stream(st)
+            self._decode_pool = ThreadPool(self.threads, initializer=init)
+        self._decode_pool.map(self.im_worker._device_image, need, chunksize=1)
 
 
 # data parallel, one process per GPU: rank r assembles chips [cur_i + r B, cur_i + (r + 1) B) of every global batch

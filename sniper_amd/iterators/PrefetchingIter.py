@@ -1,18 +1,35 @@
 """Background prefetch around a single iterator, contract of lib/iterators/PrefetchingIter.py:15-148 (used by main_train.py:142
-and Tester.__init__, lib/inference.py:33-34): one batch ahead by default, like the reference; `depth` batches ahead for a consumer
-that keeps several batches in flight (the lanes of Tester.get_detections).  The worker thread binds the iterator's GPU: batch
+and Tester.__init__, lib/inference.py:33-34): the reference keeps one batch ahead; here two by default (a batch of 20 chips is
+63 MB of a 288 GB card, and one spare batch absorbs a burst of image decodes -- the order of the batches is the iterator's, unchanged),
+`depth` batches ahead for a consumer that keeps several batches in flight (the lanes of Tester.get_detections).  The worker thread binds the iterator's GPU: batch
 assembly here is kernel launches (anchor labelling, image preparation), enqueued while the main thread is busy with the previous
-step.  A batch carries `ready_event`, recorded on the worker's stream behind those launches: a consumer on ANOTHER stream waits for
-it on the device (stream.wait_event) -- the host never blocks on the assembly; a consumer on the same (default) stream is ordered
-behind it anyway."""
+step -- on the worker's own HIP stream.  A batch carries `ready_event`, recorded on that stream behind those launches: the consumer
+waits for it on the device (`adopt_batch`: stream.wait_event + record_stream) -- the host never blocks on the assembly."""
 import collections
 import threading
 
 import sniper_amd.mx as mx
 
 
+def adopt_batch(batch, stream=None):
+    """Consumer side of a batch assembled on the worker's stream: make `stream` (default: the current one) wait for the batch's
+    `ready_event` and tell the allocator that the batch's device tensors are in use on it (`record_stream`) -- the host runs
+    ahead of the device, so a batch object is dropped while the copy that reads it is still queued, and without the record the
+    worker's next batch could be written into the same memory first."""
+    ev = getattr(batch, 'ready_event', None)
+    if ev is None:
+        return
+    import torch
+    st = stream or torch.cuda.current_stream()
+    st.wait_event(ev)
+    for a in list(batch.data or []) + list(batch.label or []):
+        t = getattr(a, '_data', a)
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(st)
+
+
 class PrefetchingIter(mx.io.DataIter):
-    def __init__(self, iters, rename_data=None, rename_label=None, depth=1):
+    def __init__(self, iters, rename_data=None, rename_label=None, depth=2):
         super(PrefetchingIter, self).__init__()
         if not isinstance(iters, list):
             iters = [iters]
@@ -42,9 +59,15 @@ class PrefetchingIter(mx.io.DataIter):
         """The worker thread's body: a METHOD, not a closure kept on self -- a closure over self stored on self is a reference
         cycle that outlives close() until a cyclic collection sees it (and forever once the heap is frozen, engine/executor.py::
         settle_heap); a finished Thread drops its target, so a closed iterator dies by reference counting."""
+        stream = None
         if self._device is not None:
             import torch
             torch.cuda.set_device(self._device)
+            # the worker's OWN stream: batch assembly is small uploads from pageable memory (synchronous copies: each waits for
+            # everything queued before it on its stream) and small kernels -- on the consumer's stream every one of them would wait
+            # for the training step in flight, and a batch took longer to assemble than a step to run (profiles/r05_fit_path.txt)
+            stream = self._stream = torch.cuda.Stream(device=self._device)
+            torch.cuda.set_stream(stream)
         while True:
             with self._cv:
                 while self.started and (self._exhausted or len(self._queue) >= self.depth):
@@ -58,8 +81,8 @@ class PrefetchingIter(mx.io.DataIter):
                 if self._device is not None:
                     import torch
                     ev = torch.cuda.Event()
-                    ev.record()
-                    batch.ready_event = ev
+                    ev.record(stream)
+                    batch.ready_event = ev          # the consumer: stream.wait_event + adopt_batch (record_stream), below
             except StopIteration:
                 batch = None
             except Exception as e:  # noqa: BLE001 -- surface worker failures in the consumer thread

@@ -274,6 +274,9 @@ class Module(object):
         return a
 
     def _feed(self, data_batch):
+        if getattr(data_batch, 'ready_event', None) is not None:       # assembled on the prefetch worker's stream
+            from ..iterators.PrefetchingIter import adopt_batch
+            adopt_batch(data_batch)
         feed = {}
         for name, arr in zip(self.data_names, data_batch.data):
             feed[name] = self._slice(arr)
@@ -393,6 +396,48 @@ class Module(object):
     def update_metric(self, eval_metric, labels):
         eval_metric.update(labels, self.get_outputs())
 
+    def _snapshot_for_metric(self, slot):
+        """Outputs and labels of the step just enqueued -> pinned host copies (two alternating sets), without waiting: a device
+        clone on the step's stream (the next replay overwrites the outputs), the device -> host copy on a side stream."""
+        st = self.__dict__.setdefault('_metric_state', {'stream': torch.cuda.Stream(device=self._device), 'sets': {}})
+        tensors = [('o', i, t) for i, t in enumerate(self.exe.outputs)]
+        host_labels = {}
+        for i, a in enumerate(self._labels):
+            d = a._data if isinstance(a, nd.NDArray) else a
+            if isinstance(d, torch.Tensor) and d.is_cuda:
+                tensors.append(('l', i, d))
+            else:
+                host_labels[i] = a if isinstance(a, nd.NDArray) else nd.NDArray(np.asarray(d))
+        bufs = st['sets'].setdefault(slot, {})
+        main = torch.cuda.current_stream(self._device)
+        staged = []
+        for kind, i, t in tensors:
+            key = (kind, i, tuple(t.shape), t.dtype)
+            ent = bufs.get(key)
+            if ent is None:
+                ent = bufs[key] = (torch.empty_like(t), torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True))
+            ent[0].copy_(t)                                   # on the step's stream: ordered before the next replay
+            staged.append((kind, i, ent))
+        cloned = torch.cuda.Event()
+        cloned.record(main)
+        side = st['stream']
+        side.wait_event(cloned)
+        with torch.cuda.stream(side):
+            for _, _, (dcopy, hcopy) in staged:
+                hcopy.copy_(dcopy, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        return staged, host_labels, done
+
+    def _update_metric_from(self, eval_metric, snap):
+        staged, host_labels, done = snap
+        done.synchronize()
+        outs, labels = {}, dict(host_labels)
+        for kind, i, (_, hcopy) in staged:
+            a = hcopy.float().numpy() if hcopy.dtype in (torch.float16, torch.bfloat16) else hcopy.numpy()
+            (outs if kind == 'o' else labels)[i] = nd.NDArray(a)
+        eval_metric.update([labels[i] for i in sorted(labels)], [outs[i] for i in sorted(outs)])
+
     def _sync_epoch(self, train_data, epoch):
         """Data parallel with a GLOBAL-batch iterator (slice_inputs): every rank builds the epoch's chip database itself, from
         numpy's global RNG (chip stride, chip permutations, negative-chip choice, index shuffle -- MNIteratorE2E.reset).  All
@@ -439,14 +484,35 @@ class Module(object):
                 pass                              # the iterator was re-seeded and reset on every rank
             elif epoch > begin_epoch:
                 train_data.reset()
+            # The reference's metrics read every output with asnumpy() (lib/train_utils/metric.py:50-369).  Under MXNet that waits
+            # for the FORWARD outputs only and the backward pass runs on beneath the host's numpy; here a step is one captured
+            # graph on one stream, so reading batch k's outputs right away would wait for the whole step and leave the GPU idle
+            # while the host computes metrics and enqueues batch k + 1 (measured: 27.5 ms per batch for a 22.9 ms step,
+            # profiles/r05_fit_path.txt).  So: outputs + labels of batch k are snapshotted on the device, copied to pinned host
+            # memory on a side stream, and the metrics of batch k are updated one iteration later -- when the copy has long
+            # landed and batch k + 1 is already queued.  The running metrics a batch_end_callback sees therefore cover the
+            # batches up to k - 1 (the epoch-end values cover all); SNIPER_METRIC_LAG=0: update at once, as before.
+            lag = os.environ.get('SNIPER_METRIC_LAG', '1') != '0' and getattr(self, '_device', None) is not None and \
+                self._device.type == 'cuda' and hasattr(eval_metric, 'update')
+            held = None
             for data_batch in train_data:
                 self.forward_backward(data_batch)
                 self.update()
-                if hasattr(eval_metric, 'update'):
+                if lag:
+                    snap = self._snapshot_for_metric(nbatch & 1)
+                    if held is not None:
+                        self._update_metric_from(eval_metric, held)
+                    held = snap
+                elif hasattr(eval_metric, 'update'):
                     self.update_metric(eval_metric, self._labels)
-                for cb in cbs(batch_end_callback):
-                    cb(BatchEndParam(epoch=epoch, nbatch=nbatch, eval_metric=eval_metric, locals=locals()))
+                if batch_end_callback is not None:
+                    param = BatchEndParam(epoch=epoch, nbatch=nbatch, eval_metric=eval_metric, locals=locals())     # (once per batch)
+                    for cb in cbs(batch_end_callback):
+                        cb(param)
                 nbatch += 1
+            if held is not None:
+                self._update_metric_from(eval_metric, held)
+                held = None
             if hasattr(eval_metric, 'get_name_value'):
                 for name, val in eval_metric.get_name_value():
                     self.logger.info('Epoch[%d] Train-%s=%f', epoch, name, val)

@@ -29,7 +29,7 @@ bench)
 prof)
   # kernel stats of the SAME command (minus the CPU / inference legs): 3 + 10 + 1 + 3 = 17 steps of conv launches
   (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_bench" -o bench -- \
-      python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-inference > "$ROOT/gpurun_out/rocprof_bench.log" 2>&1; echo "rocprof exit $?")
+      python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-inference --no-fit-path > "$ROOT/gpurun_out/rocprof_bench.log" 2>&1; echo "rocprof exit $?")
   F=$(find gpurun_out/prof_bench -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && head -30 "$F" && python tools/roofline_check.py "$F" gpurun_out/rocprof_bench.log 17 gpurun_out/roofline_check.json
   T=$(find gpurun_out/prof_bench -name "*kernel_trace.csv" | head -1)
@@ -39,7 +39,7 @@ pmc)
   # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC has 4 slots: 3 + 2); counters only, no other trace domain
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/gpurun_out/pmc_$C" -o pmc -- \
-        python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference > "$ROOT/gpurun_out/rocprof_pmc_$C.log" 2>&1; echo "pmc $C exit $?")
+        python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-fit-path > "$ROOT/gpurun_out/rocprof_pmc_$C.log" 2>&1; echo "pmc $C exit $?")
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json > /dev/null
   # (rates also over the un-countered durations of the `prof` step's kernel statistics, when that step ran in this visit)
