@@ -159,6 +159,19 @@ int sn_focus_chips_host(const float *map_hw, int H, int W, int d, float thresh, 
 int sn_aggregate_problems_host(const uint64_t *part_rows, const int64_t *lens, const int32_t *part_of_image, const float *range2,
                                int P, int nc, int num_images, float *out_rows, long capacity_rows, int64_t *out_sizes,
                                int64_t *total_rows);
+/* The same regrouping ON THE DEVICE, over the rows sn_det_compact left in HBM (Tester.aggregate, lib/inference.py:166-190): d_parts
+ * = P records {const double *rows; const int32_t *counts; float lo2, hi2;} (device addresses of one chip's float64 rows grouped
+ * by class and its nc rows-per-class; the scale's valid range squared as float32, <= 0: no bound), in (image, scale, chip) order.
+ * sn_aggregate_count -> d_kept (P,nc) i32: rows of (part, class) inside the range; the caller scans them into d_dst_off (P,nc):
+ * first row of (part, class) in the stacked output, (image, class, scale, chip) order; sn_aggregate_scatter writes the rows that
+ * pass, narrowed to float32, there in order -- the array sn_soft_nms_batch takes.  Equal to sn_aggregate_problems_host. */
+int sn_aggregate_count(const void *d_parts, int P, int nc, int32_t *d_kept, sn_stream_t stream);
+int sn_aggregate_scatter(const void *d_parts, int P, int nc, const int32_t *d_dst_off, float *d_out_rows, sn_stream_t stream);
+/* TEST.MAX_PER_IMAGE (lib/inference.py:203-211) on the device, after the NMS: problems q = image*nc + class hold d_count[q] rows
+ * at d_off[q]; an image with more than max_per_image rows over its classes keeps, per class, the rows whose score reaches the
+ * max_per_image-th best score of the image (ties stay) -- in place, in order; d_count is updated. */
+int sn_det_cap_per_image(float *d_rows, const int32_t *d_off, int32_t *d_count, int num_images, int nc, int max_per_image,
+                         sn_stream_t stream);
 /* The per-class score threshold of Tester.get_detections (lib/inference.py:289-295: inds = where(scores[:, j] > thresh), rows
  * hstack(boxes[inds, 0:4], scores[inds, j])) and, when h_crops != NULL, the AutoFocus border pruning that follows it (:336-353,
  * check_valid :236-259: rows shifted by the chip origin, dropped within `delta` px of a chip border that is not an image

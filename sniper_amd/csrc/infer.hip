@@ -229,3 +229,163 @@ SN_EXPORT int sn_det_compact(const float *d_scores, const double *d_boxes, const
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Multi-scale aggregation on the device: the regrouping half of Tester.aggregate (lib/inference.py:166-190) and its
+// MAX_PER_IMAGE rule (:203-211), over the rows sn_det_compact left in HBM -- nothing of a chip's detections goes to the host
+// between the forward pass and the final boxes.  A PART is one chip of one scale: rows (n_p, 5) float64 grouped by class +
+// rows per class.  The reference walks classes x images x scales x chips, filters every chip's rows by the scale's valid range
+// (_valid_range_filter :176-186: areas = (y2 - y1) * (x2 - x1) on the float32 rows, compared in float32) and stacks what is left
+// per (image, class) for the NMS pool; here
+//   sn_aggregate_count    one wave per (part, class): rows inside the part's valid range            -> kept (P, nc)
+//   (host: the (image, class, part) exclusive scan of `kept`: a few thousand integers)
+//   sn_aggregate_scatter  one wave per (part, class): the rows that pass, narrowed to float32, written in order behind those of
+//                         the parts before it -> the stacked rows of all (image, class) problems, (image, class, scale, chip, row)
+//                         order = the array sn_soft_nms_batch takes
+//   sn_det_cap_per_image  after the NMS: one workgroup per image; with more than max_per_image rows over all classes every class
+//                         keeps its rows whose score reaches the max_per_image-th best of the image (ties stay): radix select on
+//                         the score bits, then a stable in-place compaction per class.
+// Order-preserving throughout (soft-NMS breaks score ties by position).  Tested equal to the host statement.
+struct AggPart {
+  const double *rows;      // (n_p, 5) float64, grouped by class
+  const int32_t *counts;   // (nc) rows per class
+  float lo2, hi2;          // the scale's valid range squared as float32; <= 0: no bound
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void aggregate_kernel(const AggPart *__restrict__ parts, int nc, int32_t *__restrict__ kept,
+                                                       const int32_t *__restrict__ dst_off, float *__restrict__ out) {
+  const int j = blockIdx.x, p = blockIdx.y, lane = threadIdx.x;
+  const AggPart part = parts[p];
+  int base = 0;
+  for (int k = lane; k < j; k += 64) base += part.counts[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+  const int cnt = part.counts[j];
+  const double *src = part.rows + (size_t)base * 5;
+  float *dst = WRITE ? out + (size_t)dst_off[(size_t)p * nc + j] * 5 : nullptr;
+  int n = 0;
+  for (int r0 = 0; r0 < cnt; r0 += 64) {
+    const int r = r0 + lane;
+    bool keep = false;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < cnt) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = (float)src[(size_t)r * 5 + k];
+      const float area = (v[3] - v[1]) * (v[2] - v[0]);           // float32 products, as _valid_range_filter
+      keep = !(part.lo2 > 0.f && !(area > part.lo2)) && !(part.hi2 > 0.f && !(area <= part.hi2));
+    }
+    const unsigned long long m = __ballot(keep);
+    if (WRITE && keep) {
+      float *d = dst + (size_t)(n + __popcll(m & ((1ull << lane) - 1ull))) * 5;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) d[k] = v[k];
+    }
+    n += __popcll(m);
+  }
+  if (!WRITE && lane == 0) kept[(size_t)p * nc + j] = n;
+}
+
+SN_EXPORT int sn_aggregate_count(const void *d_parts, int P, int nc, int32_t *d_kept, sn_stream_t stream) {
+  SN_REQUIRE(d_parts && d_kept && P > 0 && nc > 0 && P <= 65535, "sn_aggregate_count: bad arguments");
+  hipLaunchKernelGGL(aggregate_kernel<false>, dim3(nc, P), dim3(64), 0, sn_stream(stream), (const AggPart *)d_parts, nc, d_kept,
+                     (const int32_t *)nullptr, (float *)nullptr);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+SN_EXPORT int sn_aggregate_scatter(const void *d_parts, int P, int nc, const int32_t *d_dst_off, float *d_out_rows, sn_stream_t stream) {
+  SN_REQUIRE(d_parts && d_dst_off && d_out_rows && P > 0 && nc > 0 && P <= 65535, "sn_aggregate_scatter: bad arguments");
+  hipLaunchKernelGGL(aggregate_kernel<true>, dim3(nc, P), dim3(64), 0, sn_stream(stream), (const AggPart *)d_parts, nc,
+                     (int32_t *)nullptr, d_dst_off, d_out_rows);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
+// rows (total, 5) f32, problems q = image * nc + class at off[q] .. off[q] + count[q] (count: survivors of the NMS, a prefix of the
+// problem's segment).  In place: count[q] shrinks, the kept rows move to the front of the segment in order.
+__device__ __forceinline__ unsigned score_key(float s) {            // order-preserving map float32 -> uint32 (any sign, no NaN)
+  const unsigned u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void det_cap_kernel(float *__restrict__ rows, const int32_t *__restrict__ off,
+                                                      int32_t *__restrict__ count, int nc, int max_per_image) {
+  __shared__ int hist[256];
+  __shared__ int s_total, s_bucket, s_above;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int q0 = img * nc;
+  if (tid == 0) {
+    int t = 0;
+    for (int j = 0; j < nc; ++j) t += count[q0 + j];
+    s_total = t;
+  }
+  __syncthreads();
+  const int total = s_total;
+  if (total <= max_per_image) return;
+  // the max_per_image-th largest key: 4 radix passes from the top byte; `want` = rank (1-based, from the top) still to find
+  unsigned prefix = 0, mask = 0;
+  int want = max_per_image;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (int j = 0; j < nc; ++j) {
+      const float *seg = rows + (size_t)off[q0 + j] * 5;
+      const int n = count[q0 + j];
+      for (int r = tid; r < n; r += 256) {
+        const unsigned k = score_key(seg[(size_t)r * 5 + 4]);
+        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int above = 0, b = 255;
+      for (; b > 0; --b) {
+        if (above + hist[b] >= want) break;
+        above += hist[b];
+      }
+      s_bucket = b;
+      s_above = above;
+    }
+    __syncthreads();
+    prefix |= (unsigned)s_bucket << shift;
+    mask |= 255u << shift;
+    want -= s_above;
+    __syncthreads();
+  }
+  const unsigned thresh = prefix;               // key of the max_per_image-th best score: keep key >= thresh (ties stay)
+  // stable in-place compaction, one wave per class at a time (a chunk is read whole before any of it is written, and writes
+  // land at or before the positions read)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int j = wave; j < nc; j += 4) {
+    float *seg = rows + (size_t)off[q0 + j] * 5;
+    const int n = count[q0 + j];
+    int kept = 0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int r = r0 + lane;
+      float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      bool keep = false;
+      if (r < n) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = seg[(size_t)r * 5 + k];
+        keep = score_key(v[4]) >= thresh;
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        float *d = seg + (size_t)(kept + __popcll(m & ((1ull << lane) - 1ull))) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] = v[k];
+      }
+      kept += __popcll(m);
+    }
+    if (lane == 0) count[q0 + j] = kept;
+  }
+}
+
+SN_EXPORT int sn_det_cap_per_image(float *d_rows, const int32_t *d_off, int32_t *d_count, int num_images, int nc, int max_per_image,
+                                   sn_stream_t stream) {
+  SN_REQUIRE(d_rows && d_off && d_count && num_images > 0 && nc > 0 && max_per_image > 0, "sn_det_cap_per_image: bad arguments");
+  hipLaunchKernelGGL(det_cap_kernel, dim3(num_images), dim3(256), 0, sn_stream(stream), d_rows, d_off, d_count, nc, max_per_image);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}

@@ -253,10 +253,26 @@ class _Detections(list):
     def __init__(self, *a):
         super(_Detections, self).__init__(*a)
         self.compact = {}
+        # {(image, chip): (device rows (cap, 5) float64 grouped by class, device rows-per-class (nc,) int32)}: what sn_det_compact
+        # left in HBM for that chip -- the input of the device aggregation (Tester.aggregate_device)
+        self.device_parts = {}
+
+    def __reduce__(self):              # (pickled for the per-scale caches / gathered across ranks: host content only)
+        return (_rebuild_detections, (list(self), self.compact))
+
+
+def _rebuild_detections(items, compact):
+    d = _Detections(items)
+    d.compact = compact
+    return d
 
 
 class Tester(object):
     device_compact = True        # threshold + prune on the GPU (sn_det_compact); False: the numpy statement of the same (tests)
+    # rows of a compacting launch: keep them in HBM for the device aggregation (keep_device_rows) and / or bring them to the host
+    # (host_rows: the per-scale detection lists, pickles, visualisation, the host aggregation).  imdb_detection_wrapper sets both.
+    keep_device_rows = False
+    host_rows = True
 
     def __init__(self, module, imdb, roidb, test_iter, cfg, rcnn_output_names=None, rpn_output_names=None, logger=None,
                  batch_size=None):
@@ -359,7 +375,7 @@ class Tester(object):
         flips = self.__dict__.setdefault('_pin_flip', {})
         flip = flips[lane] = 1 - flips.get(lane, 0)
         has_focus_maps = self.rcnn_output_names['scale_map'] in outputs[0]
-        parts = []
+        parts, parts_dev = [], []
         for g, gpu_out in enumerate(outputs):
             rois = gpu_out[self.rpn_output_names['rois']]._data              # (B*R, 5) device, rows of chip b contiguous
             deltas = gpu_out[self.rcnn_output_names['bbox']]._data           # (B, R, 4)
@@ -384,7 +400,17 @@ class Tester(object):
                 counts = torch.empty((B, NC - 1), dtype=torch.int32, device=cls.device)
                 hip.call('sn_det_compact', cls.contiguous(), boxes, crops, wh, float(cls_thresh), 10.0, B, R, NC, rows, counts,
                          hip.stream())
-                want['rows'], want['counts'] = rows, counts
+                if self.keep_device_rows:
+                    ids_b = np.asarray(data['im_ids'].asnumpy()).astype(int).reshape(-1)[g * B:(g + 1) * B]
+                    cids_b = np.asarray(data['chip_ids'].asnumpy()).astype(int).reshape(-1)[g * B:(g + 1) * B]
+                    dev_parts = [(int(i), int(c), rows[k], counts[k]) for k, (i, c) in enumerate(zip(ids_b, cids_b))]
+                else:
+                    dev_parts = None
+                if self.host_rows or not self.keep_device_rows:
+                    want['rows'], want['counts'] = rows, counts
+                else:
+                    want['device_only'] = torch.zeros((), dtype=torch.int8)          # (host marker: the rows stay in HBM)
+                parts_dev.extend(dev_parts or [])
             else:
                 want['boxes'], want['cls'] = boxes, cls
             if has_focus_maps:
@@ -401,14 +427,15 @@ class Tester(object):
         if torch.cuda.is_available():
             ev = torch.cuda.Event()
             ev.record()
-        return data, parts, has_focus_maps, ev
+        return data, parts, has_focus_maps, ev, parts_dev
 
     def _collect(self, handle):
         """-> scores, boxes, data, im_ids, maps, chip_ids; after a compacting launch `scores` is None and boxes[i] is the pair
         (rows of chip i grouped by class, float64 (n, 5); rows per class, (NC - 1,))."""
-        data, parts, has_focus_maps, ev = handle
+        data, parts, has_focus_maps, ev, parts_dev = handle
         if ev is not None:
             ev.synchronize()
+        self._last_device_parts = parts_dev
         scores, preds, maps = [], [], []
         im_ids = np.array([], dtype=int)
         chip_ids = np.array([], dtype=int)
@@ -422,6 +449,9 @@ class Tester(object):
                 counts, rows = host['counts'].numpy().astype(np.int64), host['rows'].numpy()
                 for idx in range(B):
                     preds.append((rows[idx, :int(counts[idx].sum())].copy(), counts[idx]))
+            elif 'device_only' in host:
+                compacted = True
+                preds.extend([None] * B)             # thresholded, pruned and kept in HBM (device_parts)
             else:
                 gpu_scores, boxes = host['cls'].numpy().copy(), host['boxes'].numpy().copy()
                 for idx in range(B):
@@ -446,6 +476,10 @@ class Tester(object):
                   vis_ext='.png'):
         n_scales = len(scale_cls_dets)
         assert n_scales == len(self.cfg.TEST.VALID_RANGES), 'A valid range should be specified for each test scale'
+        if not vis:
+            done = self.aggregate_device(scale_cls_dets)
+            if done is not None:
+                return done
         all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
         # one batched launch instead of Pool(32).map; the problems go up as the one stacked array they are built as
         rows, sizes = aggregate_problems(scale_cls_dets, self.cfg.TEST.VALID_RANGES, self.num_images, self.num_classes, stacked=True)
@@ -462,6 +496,76 @@ class Tester(object):
                 if kept is not None:
                     for j in range(1, self.num_classes):
                         all_boxes[j][i] = kept[j - 1]
+        return all_boxes
+
+    def aggregate_device(self, scale_cls_dets):
+        """Tester.aggregate (:152-230) with nothing of it on the host: every chip's thresholded / pruned rows are still in HBM
+        (`_Detections.device_parts`, left there by sn_det_compact); the valid-range filter + regrouping per (image, class)
+        (sn_aggregate_count / sn_aggregate_scatter), the batched soft-NMS and the MAX_PER_IMAGE rule (sn_det_cap_per_image) run on
+        them, and ONE copy brings the final boxes back.  The host's share: the (image, class, part) exclusive scan of a few
+        thousand counts.  -> all_boxes, or None when some chip's rows are not on the device / hard NMS is configured (the host
+        statement above runs).  Bit-equal to it (tests/test_gpu_inference.py)."""
+        nms = self.nms_worker.nms_wrapper
+        if nms.thresh > 0 or not torch.cuda.is_available():
+            return None
+        nc, n_img = self.num_classes - 1, self.num_images
+        recs, part_image = [], []
+        for i in range(n_img):
+            for dets, vr in zip(scale_cls_dets, self.cfg.TEST.VALID_RANGES):
+                ready = getattr(dets, 'device_parts', None)
+                n_chips = len(dets[1][i]) if len(dets) > 1 else 0
+                for c in range(n_chips):
+                    hit = ready.get((i, c)) if ready else None
+                    if hit is None:
+                        return None
+                    # `areas > vr * vr` against a float32 array compares in float32 (numpy's weak Python scalars)
+                    recs.append((hit[0].data_ptr(), hit[1].data_ptr(), np.float32(vr[0] * vr[0]) if vr[0] > 0 else np.float32(0),
+                                 np.float32(vr[1] * vr[1]) if vr[1] > 0 else np.float32(0)))
+                    part_image.append(i)
+        all_boxes = [[np.zeros((0, 5), np.float32) for _ in range(n_img)] for _ in range(self.num_classes)]
+        for i in range(n_img):
+            all_boxes[0][i] = []
+        P = len(recs)
+        if P == 0:
+            return all_boxes
+        table = np.array(recs, dtype=[('rows', '<u8'), ('counts', '<u8'), ('lo2', '<f4'), ('hi2', '<f4')])      # struct AggPart
+        d_table = hip.dev(table.view(np.uint8).reshape(P, 24))
+        kept = torch.empty((P, nc), dtype=torch.int32, device=d_table.device)
+        CH = 32768                                    # parts per launch (grid.y)
+        for a in range(0, P, CH):
+            hip.call('sn_aggregate_count', d_table[a:], min(CH, P - a), nc, kept[a:], hip.stream())
+        k = kept.cpu().numpy().astype(np.int64)
+        part_image = np.asarray(part_image)
+        sizes = np.zeros((n_img, nc), np.int64)
+        np.add.at(sizes, part_image, k)
+        off = np.zeros(n_img * nc + 1, np.int64)
+        off[1:] = np.cumsum(sizes.ravel())
+        total = int(off[-1])
+        if total == 0:
+            return all_boxes
+        assert total < 2 ** 31
+        before = np.cumsum(k, axis=0) - k             # rows of class j in the parts before p (all images)
+        first = np.searchsorted(part_image, np.arange(n_img))          # first part of every image (parts are image-major)
+        dst = off[:-1].reshape(n_img, nc)[part_image] + before - before[first[part_image]]
+        rows = torch.empty((total, 5), dtype=torch.float32, device=d_table.device)
+        d_dst = hip.dev(np.ascontiguousarray(dst, np.int32))
+        for a in range(0, P, CH):
+            hip.call('sn_aggregate_scatter', d_table[a:], min(CH, P - a), nc, d_dst[a:], rows, hip.stream())
+        d_off = hip.dev(off.astype(np.int32))
+        cnt = torch.empty((n_img * nc,), dtype=torch.int32, device=rows.device)
+        from .ext.cpu_nms import _soft_ws
+        max_n = int(sizes.max())
+        hip.call('sn_soft_nms_batch', rows, d_off, n_img * nc, max_n, total, float(nms.sigma), 0.3, 0.001, 2,
+                 _soft_ws(max_n, total, rows.device), cnt, hip.stream())
+        if self.cfg.TEST.MAX_PER_IMAGE > 0:
+            hip.call('sn_det_cap_per_image', rows, d_off, cnt, n_img, nc, int(self.cfg.TEST.MAX_PER_IMAGE), hip.stream())
+        h, c = rows.cpu().numpy(), cnt.cpu().numpy()
+        starts, ends = off[:-1].tolist(), (off[:-1] + c).tolist()
+        q = 0
+        for i in range(n_img):
+            for j in range(1, self.num_classes):
+                all_boxes[j][i] = h[starts[q]:ends[q]]
+                q += 1
         return all_boxes
 
     # ---- per-scale detection loop (:232-370) --------------------------------------------------------
@@ -502,9 +606,13 @@ class Tester(object):
 
         def post(scores, boxes, data, im_ids, maps, chip_ids):
             todo = []
+            for i_, c_, rows_, counts_ in getattr(self, '_last_device_parts', None) or ():
+                all_boxes.device_parts[(i_, c_)] = (rows_, counts_)
             for i, (cboxes, im_id, chip_id) in enumerate(zip(boxes, im_ids, chip_ids)):
                 if autofocus:
                     all_maps[im_id][chip_id] = maps[i]
+                if scores is None and cboxes is None:
+                    continue                       # the chip's rows stayed in HBM (all_boxes.device_parts)
                 if scores is None:
                     # thresholded (and pruned) on the GPU: rows grouped by class + rows per class -- only slice
                     big, lens = cboxes
@@ -573,7 +681,7 @@ class Tester(object):
         return all_boxes
 
 
-def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None):
+def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None, rows=(False, True)):
     """One test scale: bind the test graph for that scale's batch shape and run the Tester (:411-436).
     module_cache (dict, optional): keeps the bound Module of each scale across calls (its executors are cached per
     batch shape), which is what a long-running inference service -- and the throughput benchmark -- wants; the
@@ -609,6 +717,7 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None)
         module_cache[(tuple(scale), nbatch)] = mods[0]
         module_cache[('__lanes__', tuple(scale), nbatch)] = mods[1:]
     tester = Tester(mods[:lanes], imdb, roidb, test_iter, cfg=config, batch_size=nbatch)
+    tester.keep_device_rows, tester.host_rows = bool(rows[0]), bool(rows[1])      # (keep in HBM for aggregate_device, copy to the host)
     return tester.get_detections(vis=False, evaluate=False, cache_name='dets_scale_{}x{}'.format(scale[0], scale[1]),
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
@@ -640,12 +749,19 @@ def merge_rank_detections(gathered, n_images, num_classes, world):
 
 def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
                            focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=1, rank=None, world=None,
-                           group=None):
+                           group=None, device_aggregate=None):
     """Multi-scale inference + aggregation (lib/inference.py:439-529), see `_multi_scale_detections`.
     rank / world (default: the initialised torch.distributed group, else one process): rank r runs images r, r + world, ... through
     all the scales -- (image, chip) units are independent, the FocusChips of an image come from its own maps -- the per-scale
     detections are gathered on rank 0 (`gather_object`; rows of a few MB per rank and pass, no tensor collective) and rank 0 alone
-    aggregates, as the reference merges its forked jobs before `aggregate` (:494-500).  Other ranks return None."""
+    aggregates, as the reference merges its forked jobs before `aggregate` (:494-500).  Other ranks return None.
+    device_aggregate (default: on, SNIPER_DEVICE_AGGREGATE=0 turns it off): the thresholded / pruned rows of every chip stay in HBM
+    and the valid-range regrouping, the soft-NMS and the MAX_PER_IMAGE rule run on them there (Tester.aggregate_device); the
+    rows come to the host per batch only when the per-scale detection lists are asked for (return_scale_dets, vis)."""
+    if device_aggregate is None:
+        device_aggregate = os.environ.get('SNIPER_DEVICE_AGGREGATE', '1') != '0'
+    device_aggregate = bool(device_aggregate) and torch.cuda.is_available() and Tester.device_compact and config.TEST.NMS <= 0
+    rows = (device_aggregate, bool(return_scale_dets or vis or not device_aggregate))      # (keep in HBM, copy to the host)
     if world is None:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -659,7 +775,7 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
         local = [roidb[g] for g in ids]
         fmap = None if focus_map_fn is None else (lambda s_i, i, c, m: focus_map_fn(s_i, ids[i], c, m))
         dets = _multi_scale_detections(sym_def, config, imdb, local, context, arg_params, aux_params, vis, module_cache, fmap,
-                                       concurrent_jobs, lanes) if local else \
+                                       concurrent_jobs, lanes, (False, True)) if local else \
             [_Detections([[] for _ in range(imdb.num_classes)]) for _ in config.TEST.SCALES]
         payload = [([list(d[j]) for j in range(imdb.num_classes)], dict(getattr(d, 'compact', {}))) for d in dets]
         gathered = [None] * world if rank == 0 else None
@@ -671,7 +787,7 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
         detections = merge_rank_detections(gathered, len(roidb), imdb.num_classes, world)
     else:
         detections = _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis, module_cache,
-                                             focus_map_fn, concurrent_jobs, lanes)
+                                             focus_map_fn, concurrent_jobs, lanes, rows)
     tester = Tester(None, imdb, roidb, None, cfg=config, batch_size=config.TEST.BATCH_IMAGES[-1])
     out = tester.aggregate(detections, vis=False, cache_name=None)
     # the pass's own objects (iterators, device image cache) are gone; if a new batch shape froze the heap while they were alive,
@@ -683,7 +799,7 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
 
 
 def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
-                            focus_map_fn=None, concurrent_jobs=1, lanes=1):
+                            focus_map_fn=None, concurrent_jobs=1, lanes=1, rows=(False, True)):
     """Coarse-to-fine multi-scale inference (:439-529): every image starts as one crop = the whole image; with
     AUTO_FOCUS the FocusPixel maps of scale s generate the chips of scale s+1 (add_chips).  -> the per-scale detections
     (imdb_detection_wrapper aggregates them under TEST.VALID_RANGES with per-class NMS).
@@ -724,18 +840,18 @@ def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, a
                 cache = None if module_cache is None else module_cache.setdefault(('__job__', j), {})
                 args = [scale, scale_i, nbatch, context, config, sym_def, parts[j], imdb, arg_params, aux_params, vis]
                 if streams is None:
-                    return detect_scale_worker(args, cache, lanes, image_cache)
+                    return detect_scale_worker(args, cache, lanes, image_cache, rows)
                 main = torch.cuda.current_stream()
                 streams[j].wait_stream(main)
                 with torch.cuda.stream(streams[j]):
-                    out = detect_scale_worker(args, cache, lanes, image_cache)
+                    out = detect_scale_worker(args, cache, lanes, image_cache, rows)
                 streams[j].synchronize()
                 return out
             finally:
                 _SLOT.job = was
         if len(parts) == 1:
             dets, maps = detect_scale_worker([scale, scale_i, nbatch, context, config, sym_def, roidb, imdb, arg_params, aux_params, vis],
-                                             module_cache, lanes, image_cache)
+                                             module_cache, lanes, image_cache, rows)
         else:
             # the first two passes over a module cache run the parts one after the other: that is when the bound executors
             # capture their forward graphs, which must not happen beside another thread's GPU work (engine/executor.py)
@@ -756,6 +872,7 @@ def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, a
                     dets[j] += d[j]
                 maps += m
                 dets.compact.update({(first + i, c): v for (i, c), v in getattr(d, 'compact', {}).items()})
+                dets.device_parts.update({(first + i, c): v for (i, c), v in getattr(d, 'device_parts', {}).items()})
         detections.append(dets)
         # chips of the next scale from this scale's FocusPixel maps (:497-499)
         if scale_i + 1 < len(config.TEST.SCALES) and config.TEST.DO_PRUNING[scale_i + 1]:

@@ -239,6 +239,65 @@ def test_lanes_and_device_compaction_equal_the_host_loops():
                 assert np.array_equal(wi, gi)
 
 
+def test_device_aggregation_equals_the_host_statement():
+    """Tester.aggregate_device (valid-range regrouping, soft-NMS and the MAX_PER_IMAGE rule on the rows sn_det_compact left in HBM)
+    == Tester.aggregate's host statement, bit for bit: three scales with both range bounds, chips without rows, classes without
+    rows, an image without chips at a scale, tied scores on the MAX_PER_IMAGE boundary, images below and above the cap."""
+    from sniper_amd import config as cfgmod
+    from sniper_amd import inference
+    rs = np.random.RandomState(3)
+    NC, n_img = 9, 7                                  # 8 foreground classes
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.VALID_RANGES = ((30, -1), (-1, 60), (10, 45))
+    cfg.TEST.MAX_PER_IMAGE = 40
+    dets = []
+    for s_i in range(3):
+        d = inference._Detections([[[] for _ in range(n_img)] for _ in range(NC)])
+        for i in range(n_img):
+            n_chips = 0 if (s_i == 2 and i == 4) else 1 + (i + s_i) % 3
+            for j in range(NC):
+                d[j][i] = [np.zeros((0, 5)) for _ in range(n_chips)]
+            for c in range(n_chips):
+                lens = rs.randint(0, 9, NC - 1) * (rs.rand(NC - 1) < 0.7)
+                if i == 5:
+                    lens = np.minimum(lens, 1) * (np.arange(NC - 1) < 3)           # an image that stays below the cap
+                if (i + c) % 5 == 0:
+                    lens[:] = 0                                                    # a chip without detections
+                n = int(lens.sum())
+                xy = rs.uniform(0, 300, (n, 2))
+                wh = rs.uniform(5, 80, (n, 2))
+                sc = np.round(rs.uniform(0.01, 1.0, (n, 1)), 2 if i == 2 else 6)    # image 2: many tied scores
+                big = np.ascontiguousarray(np.hstack((xy, xy + wh, sc)), np.float64)
+                ends = np.cumsum(lens)
+                for j in range(1, NC):
+                    d[j][i][c] = big[ends[j - 1] - lens[j - 1]:ends[j - 1]]
+                d.compact[(i, c)] = (big, lens.astype(np.int64))
+                cap = n + 5                                                        # (the device buffer is a capacity, not a count)
+                dev_rows = torch.full((cap, 5), 7.0, dtype=torch.float64, device=dev())
+                dev_rows[:n] = torch.from_numpy(big).to(dev())
+                d.device_parts[(i, c)] = (dev_rows, torch.from_numpy(lens.astype(np.int32)).to(dev()))
+        dets.append(d)
+
+    class Imdb(object):
+        num_classes, classes, name, result_path = NC, None, 'synthetic', None
+    tester = inference.Tester(None, Imdb(), [{} for _ in range(n_img)], None, cfg=cfg, batch_size=2)
+    got = tester.aggregate_device(dets)
+    assert got is not None
+    for d in dets:
+        d.device_parts = {}                                                        # -> the host statement
+    want = tester.aggregate(dets)
+    capped = 0
+    for i in range(n_img):
+        n_i = 0
+        for j in range(1, NC):
+            w, g = np.asarray(want[j][i], np.float32).reshape(-1, 5), np.asarray(got[j][i], np.float32).reshape(-1, 5)
+            assert w.shape == g.shape and np.array_equal(w, g), (i, j, w.shape, g.shape)
+            n_i += len(g)
+        capped += n_i >= cfg.TEST.MAX_PER_IMAGE
+        assert n_i > 0
+    assert capped >= 3 and sum(len(got[j][5]) for j in range(1, NC)) < cfg.TEST.MAX_PER_IMAGE
+
+
 def test_rank_sharded_inference_equals_one_process():
     """two ranks (gloo, sharing this one card -- a rehearsal of the control flow) each run every second image through
     both scales, rank 0 gathers and aggregates: final boxes bit-equal to the whole roidb in one process (tests/infer_shard_worker.py;

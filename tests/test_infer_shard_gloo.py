@@ -28,6 +28,7 @@ class _Cfg(object):
         BATCH_IMAGES = [8, 2]
         VALID_RANGES = [(-1, -1), (-1, -1)]
         NMS, NMS_SIGMA = -1, 0.55
+        MAX_PER_IMAGE = 100
 
 
 def _fake_scale_detections(inference, roidb, focus_map_fn):
@@ -69,7 +70,7 @@ def _run(rank, world, port, n_images, out):
         os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         dist.init_process_group('gloo', rank=rank, world_size=world)
     calls = {'aggregate': 0}
-    inference._multi_scale_detections = lambda sym, cfg, imdb, roidb, ctx, a, b, vis, cache, fmap, jobs, lanes: \
+    inference._multi_scale_detections = lambda sym, cfg, imdb, roidb, ctx, a, b, vis, cache, fmap, jobs, lanes, rows=None: \
         _fake_scale_detections(inference, roidb, fmap)
 
     def aggregate(self, scale_cls_dets, **kw):
