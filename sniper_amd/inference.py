@@ -279,7 +279,8 @@ class Tester(object):
         self.test_iter = test_iter
         self._own_iter = False
         if test_iter is not None and not isinstance(test_iter, PrefetchingIter):
-            self.test_iter = PrefetchingIter(self.test_iter, depth=max(2, len(module)) if isinstance(module, (list, tuple)) else 2)
+            self.test_iter = PrefetchingIter(self.test_iter, depth=max(2, len(module)) if isinstance(module, (list, tuple)) else 2,
+                                             own_stream=False)
             self._own_iter = True
             self.scale = test_iter.test_scale
         self.cfg = cfg

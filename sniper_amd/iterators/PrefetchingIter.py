@@ -29,7 +29,7 @@ def adopt_batch(batch, stream=None):
 
 
 class PrefetchingIter(mx.io.DataIter):
-    def __init__(self, iters, rename_data=None, rename_label=None, depth=2):
+    def __init__(self, iters, rename_data=None, rename_label=None, depth=2, own_stream=True):
         super(PrefetchingIter, self).__init__()
         if not isinstance(iters, list):
             iters = [iters]
@@ -40,6 +40,11 @@ class PrefetchingIter(mx.io.DataIter):
         self.batch_size = self.iters[0].get_batch_size() if hasattr(self.iters[0], 'get_batch_size') else \
             self.provide_data[0][1][0]
         self.depth = max(1, int(depth))
+        # own_stream: the worker assembles batches on a HIP stream of its own (training: the consumer's stream is busy with the step).
+        # False: on the consumer's default stream -- the test-time Tester, whose lanes already hold the runtime's four hardware
+        # queues: a fifth stream shares a queue with a lane and the 64-image pass measured 310 instead of 262 ms
+        # (profiles/r05_infer_prefetch_stream_ab.txt)
+        self.own_stream = bool(own_stream)
         self._cv = threading.Condition()
         self._queue = collections.deque()       # (batch or None at the end of the epoch, exception or None)
         self._epoch = 0                         # bumped by reset(): a batch assembled across a reset is dropped
@@ -66,8 +71,10 @@ class PrefetchingIter(mx.io.DataIter):
             # the worker's OWN stream: batch assembly is small uploads from pageable memory (synchronous copies: each waits for
             # everything queued before it on its stream) and small kernels -- on the consumer's stream every one of them would wait
             # for the training step in flight, and a batch took longer to assemble than a step to run (profiles/r05_fit_path.txt)
-            stream = self._stream = torch.cuda.Stream(device=self._device)
-            torch.cuda.set_stream(stream)
+            import os
+            if self.own_stream and os.environ.get('SNIPER_PREFETCH_STREAM', '1') != '0':      # (=0: never, A/B)
+                stream = self._stream = torch.cuda.Stream(device=self._device)
+                torch.cuda.set_stream(stream)
         while True:
             with self._cv:
                 while self.started and (self._exhausted or len(self._queue) >= self.depth):
