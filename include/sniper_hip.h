@@ -206,6 +206,17 @@ size_t sn_conv_fwd_splitk_workspace_bytes(int N, int H, int W, int Cin, int in_p
 int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
                        int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad,
                        int dil, int relu, void *ws, size_t ws_bytes, sn_stream_t stream);
+/* Forward convolution with a SECOND output (test-time residual units): y as sn_conv_fwd / sn_conv_fwd_splitk write it (fp16) and
+ * y2 = act(y2_scale * y + y2_shift) of the stored y, fp16, pixel stride y2_pix_stride -- the moving-statistics BatchNorm + ReLU that
+ * opens the next pre-activation unit (resnet_mx_101_e2e.py:38-40) and reads the residual sum this epilogue writes.  ws / ws_bytes:
+ * the split-K scratch of sn_conv_fwd_splitk_workspace_bytes (0 / NULL: never split).  sn_conv_fwd_dual_ok -> 1 when the layer
+ * qualifies (pipelined kernel, 16-byte rows), else use sn_conv_fwd + sn_bn_apply. */
+int sn_conv_fwd_dual_ok(int N, int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH,
+                        int KW, int stride, int pad, int dil, int y2_pix_stride);
+int sn_conv_fwd_dual(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
+                     int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad, int dil,
+                     int relu, void *y2, int y2_pix_stride, const float *y2_scale, const float *y2_shift, int y2_relu, void *ws,
+                     size_t ws_bytes, sn_stream_t stream);
 /* Kernel-selection override for sn_conv_fwd / sn_conv_dgrad (tuning hook, tools/conv_tune.py; no reference counterpart):
  * -1 = built-in per-layer table (default), 0 = the register-staged kernel only, 4 / 5 / 6 / 7 / 14 / 16 / 18 = that LDS-DMA tile
  * configuration for every layer that qualifies (see conv_dma.hip; other numbers are rejected).  Results are identical up to fp32 summation order inside a tile's K loop

@@ -341,7 +341,9 @@ static SplitPlan conv_split_plan(const ConvParams &p) {
 // out[m][n] = act(sum_z slab[z][m][n] + bias[n] + res[m][n]) as fp16; 8 channels per thread (Nout % 8 == 0)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int ksplit, size_t stride, long M, int Nout,
                                                             const float *__restrict__ bias, const half_t *__restrict__ res, int res_ps,
-                                                            half_t *__restrict__ out, int out_ps, int relu) {
+                                                            half_t *__restrict__ out, int out_ps, int relu,
+                                                            half_t *__restrict__ out2, int out2_ps, const float *__restrict__ o2_scale,
+                                                            const float *__restrict__ o2_shift, int o2_relu) {
   const int cpr = Nout >> 3;
   const long total = M * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -366,6 +368,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = (half_t)((relu && v[r] < 0.f) ? 0.f : v[r]);
     *reinterpret_cast<half8 *>(out + (size_t)m * out_ps + n) = o;
+    if (out2) {                              // second output: act(scale * stored value + shift), as the dual epilogue of conv_dma.hip
+      half8 o2;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float f = (float)o[r] * o2_scale[n + r] + o2_shift[n + r];
+        if (o2_relu) f = f > 0.f ? f : 0.f;
+        o2[r] = (half_t)f;
+      }
+      *reinterpret_cast<half8 *>(out2 + (size_t)m * out2_ps + n) = o2;
+    }
   }
 }
 
@@ -401,9 +413,62 @@ SN_EXPORT int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias
   long blocks = (total + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), (const float *)ws, sp.ksplit,
-                     sp.slab_elems, (long)p.M, p.Nout, bias, (const half_t *)residual, res_pix_stride, (half_t *)y, out_pix_stride, relu);
+                     sp.slab_elems, (long)p.M, p.Nout, bias, (const half_t *)residual, res_pix_stride, (half_t *)y, out_pix_stride, relu,
+                     (half_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, 0);
   SN_CHECK_LAUNCH();
   return SN_OK;
+}
+
+// ---- forward with a second output (test-time residual units) ---------------------------------------------------------------
+// y = conv(x) (+ bias, residual, ReLU) as sn_conv_fwd / sn_conv_fwd_splitk write it, and y2 = act(y2_scale * y + y2_shift) of the
+// STORED fp16 y: the moving-statistics BatchNorm + ReLU that opens the next pre-activation unit (resnet_mx_101_e2e.py:38-40).  That
+// BatchNorm reads the residual SUM (two readers: itself and the next add), so it cannot fold into the convolution's weights; as a
+// second output of the epilogue that has the sum in registers it costs one more 16-byte store per lane instead of a launch that
+// reads and writes the whole tensor (2 880 sn_bn_apply launches per 64-image AutoFocus pass).  sn_conv_fwd_dual_ok: 1 when the
+// layer takes the pipelined kernel's 16-byte epilogue (else the caller keeps sn_conv_fwd + sn_bn_apply).
+static bool conv_dual_ok(const ConvParams &p, int y2_pix_stride) {
+  if (p.Ho <= 0 || p.Wo <= 0 || p.out_f32 || p.Nout % 8 != 0 || p.out_ps % 8 != 0 || (p.res && p.res_ps % 8 != 0) || y2_pix_stride % 8 != 0)
+    return false;
+  return conv_plan(p, false).dma != 0;
+}
+
+SN_EXPORT int sn_conv_fwd_dual_ok(int N, int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride,
+                                  int KH, int KW, int stride, int pad, int dil, int y2_pix_stride) {
+  ConvParams p;
+  conv_fwd_params(p, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH,
+                  KW, stride, pad, dil, 0, 0);
+  if (res_pix_stride % 8 != 0) return 0;
+  return conv_dual_ok(p, y2_pix_stride) ? 1 : 0;
+}
+
+SN_EXPORT int sn_conv_fwd_dual(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W,
+                               int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride,
+                               int pad, int dil, int relu, void *y2, int y2_pix_stride, const float *y2_scale, const float *y2_shift,
+                               int y2_relu, void *ws, size_t ws_bytes, sn_stream_t stream) {
+  ConvParams p;
+  conv_fwd_params(p, x, w, bias, residual, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH, KW, stride, pad,
+                  dil, relu, 0);
+  if (int rc = conv_check(p, "sn_conv_fwd_dual")) return rc;
+  SN_REQUIRE(y2 && y2_scale && y2_shift && conv_dual_ok(p, y2_pix_stride),
+             "sn_conv_fwd_dual: the layer does not take the 16-byte pipelined epilogue (query sn_conv_fwd_dual_ok)");
+  const SplitPlan sp = conv_split_plan(p);
+  if (sp.ksplit > 1 && ws && ws_bytes >= (size_t)sp.ksplit * sp.slab_elems * sizeof(float)) {
+    ConvParams q = p;
+    q.y = ws; q.out_f32 = 1; q.out_ps = p.Nout; q.bias = nullptr; q.res = nullptr; q.res_ps = 0; q.relu = 0;
+    q.ksplit = sp.ksplit;
+    q.ksplit_stride = (long)sp.slab_elems;
+    if (int rc = conv_launch<false>(q, sn_stream(stream), sp.cfg)) return rc;
+    const long total = (long)p.M * (p.Nout / 8);
+    long blocks = (total + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), (const float *)ws, sp.ksplit,
+                       sp.slab_elems, (long)p.M, p.Nout, bias, (const half_t *)residual, res_pix_stride, (half_t *)y, out_pix_stride, relu,
+                       (half_t *)y2, y2_pix_stride, y2_scale, y2_shift, y2_relu);
+    SN_CHECK_LAUNCH();
+    return SN_OK;
+  }
+  p.out2 = (half_t *)y2; p.out2_ps = y2_pix_stride; p.o2_scale = y2_scale; p.o2_shift = y2_shift; p.o2_relu = y2_relu;
+  return conv_launch<false>(p, sn_stream(stream));
 }
 
 // Forward convolution that also emits the BatchNorm statistics of its (fp16) output: partials (blocks, 2, Cout) fp32 with

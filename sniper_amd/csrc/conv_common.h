@@ -44,6 +44,12 @@ struct ConvParams {
   int ksplit = 1, ksplit_grid = 0;
   long ksplit_stride = 0;
   unsigned long long *trace = nullptr;   // phase timeline of every workgroup (tools/conv_trace.py; SNIPER_CONV_TRACE), normally null
+  // optional SECOND output of a forward convolution (sn_conv_fwd_dual, test-time graphs): y2 = act(scale * y + shift) of the stored
+  // fp16 output -- the moving-statistics BatchNorm (+ ReLU) of the NEXT residual unit, which reads the residual sum this
+  // convolution's epilogue writes and cannot fold into it (the sum has a second reader, the next add)
+  half_t *out2 = nullptr;
+  const float *o2_scale = nullptr, *o2_shift = nullptr;
+  int out2_ps = 0, o2_relu = 0;
   float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
                        // STORED fp16 values (what bn_stats_kernel would read back), or null
 };

@@ -491,6 +491,19 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
             for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
             // (non-temporal stores measured: no difference in the step, profiles/r04_ab_class_nt_fold.txt)
             *reinterpret_cast<half8 *>(reinterpret_cast<half_t *>(ybase) + (size_t)m * p.out_ps + n) = o;
+            if constexpr (!DGRAD) if (p.out2) {   // the next unit's moving-statistics BatchNorm (+ ReLU) of the value just stored
+              const float4 s0 = *reinterpret_cast<const float4 *>(p.o2_scale + n), s1 = *reinterpret_cast<const float4 *>(p.o2_scale + n + 4);
+              const float4 h0 = *reinterpret_cast<const float4 *>(p.o2_shift + n), h1 = *reinterpret_cast<const float4 *>(p.o2_shift + n + 4);
+              const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+              half8 o2;
+  #pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                float f = (float)o[r] * sc[r] + sh[r];              // as bn_apply_kernel (nn_ops.hip) forms it
+                if (p.o2_relu) f = f > 0.f ? f : 0.f;
+                o2[r] = (half_t)f;
+              }
+              *reinterpret_cast<half8 *>(p.out2 + (size_t)m * p.out2_ps + n) = o2;
+            }
             if (p.stats) {
               bool done = false;
               if constexpr (kBnHoist) {

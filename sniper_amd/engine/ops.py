@@ -129,6 +129,18 @@ class BatchNormStep(Step):
                 and os.environ.get('SNIPER_INFER_FOLD_BN', '1') != '0'):
             self.folded_into = prod
             prod.fold_bn = self
+        # Test-time graphs, second case: the BatchNorm (+ ReLU) that opens a pre-activation unit reads the residual SUM of the unit
+        # before it -- two readers (this layer and the next add), so it cannot fold into the convolution that wrote the sum; that
+        # convolution's epilogue has the sum in registers and writes act(scale * sum + shift) as a SECOND output straight into this
+        # step's tensor (sn_conv_fwd_dual): the sn_bn_apply launch and its read + write of the whole tensor disappear (33 per R101
+        # forward, 2 880 per 64-image AutoFocus pass).  SNIPER_INFER_DUAL_BN=0: the separate launch.
+        self.dual_from = None
+        if (not ex.for_training and self.folded_into is None and not self.is_stem and self.x.fmt == 'act' and self.act in (0, 1)
+                and os.environ.get('SNIPER_INFER_DUAL_BN', '1') != '0'):
+            src = self.x.producer
+            conv = getattr(src, 'fused_conv', None) if type(src).__name__ == 'BinaryStep' else src
+            if type(conv).__name__ == 'ConvolutionStep' and conv.request_dual(self):
+                self.dual_from = conv
         if self.is_stem:
             self.y = self.new_out('f32', alloc=False)
             self.y.stem = (self.x, self.scale, self.shift)
@@ -182,6 +194,8 @@ class BatchNormStep(Step):
         ex = self.ex
         if self.folded_into is not None:
             return                       # the producing convolution wrote act(scale * conv + shift) into the shared tensor
+        if self.dual_from is not None and not ex.is_train:
+            return                       # ... or wrote it as its second output into this step's own tensor (sn_conv_fwd_dual)
         g = None if self.fix_gamma else self.gamma.master
         if not self._use_batch_stats():
             if not self._global_ready:
@@ -486,6 +500,19 @@ class ConvolutionStep(_GemmLike):
             self.stats_buf, self.stats_blocks = self.ex.empty((nblk, 2, self.O), F32), nblk
         return self.stats_buf, self.stats_blocks
 
+    def request_dual(self, bn):
+        """A test-time moving-statistics BatchNorm (+ ReLU) that reads this convolution's output -- or the residual sum its
+        epilogue writes -- and cannot fold into it asks to be written as the epilogue's second output.  -> accepted?"""
+        if (getattr(self, 'dual_bn', None) is not None or getattr(self, 'fold_bn', None) is not None or self.is_stem or
+                self.depthwise or self.out_f32 or self.ex.for_training):
+            return False
+        res = getattr(self, 'fused_residual', None)
+        if not hip.query('sn_conv_fwd_dual_ok', self.N, self.H, self.W, self.C, self.C, self.O, self.O, 0 if res is None else self.O,
+                         self.k[0], self.k[1], self.s[0], self.p[0], self.d[0], self.O):
+            return False
+        self.dual_bn = bn
+        return True
+
     def launch_fwd(self, x, dst, bias):
         ex = self.ex
         if self.is_stem:
@@ -533,6 +560,17 @@ class ConvolutionStep(_GemmLike):
             if getattr(self, '_splitk_bytes', None) is None:
                 self._splitk_bytes = 0 if os.environ.get('SNIPER_CONV_SPLITK', '1') == '0' else \
                     int(hip.query('sn_conv_fwd_splitk_workspace_bytes', *geom))
+            dual = getattr(self, 'dual_bn', None)
+            if dual is not None and not ex.is_train:
+                # the next unit's BatchNorm + ReLU as the epilogue's second output (BatchNormStep.setup), split-K or not
+                if not dual._global_ready:
+                    hip.call('sn_bn_global_scale_shift', None if dual.fix_gamma else dual.gamma.master, dual.beta.master, dual.mean,
+                             dual.var, dual.C, dual.eps, dual.scale, dual.shift, hip.stream())
+                    dual._global_ready = True
+                hip.call('sn_conv_fwd_dual', x, w, b, None if res is None else res.t, dst, *geom, relu, dual.y.t, self.O, dual.scale,
+                         dual.shift, 1 if dual.act == 1 else 0, ex.ws.get(self._splitk_bytes) if self._splitk_bytes else None,
+                         self._splitk_bytes, hip.stream())
+                return
             if self._splitk_bytes:
                 hip.call('sn_conv_fwd_splitk', x, w, b, None if res is None else res.t, dst, *geom, relu, ex.ws.get(self._splitk_bytes),
                          self._splitk_bytes, hip.stream())

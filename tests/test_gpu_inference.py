@@ -453,6 +453,83 @@ def test_inference_batchnorm_folds_into_the_producing_convolution():
     assert np.abs(u - v).max() / max(np.abs(v).max(), 1e-6) < 4e-3 and not np.allclose(u, a[0])
 
 
+def test_inference_unit_opening_batchnorm_is_the_second_output_of_the_residual_convolution():
+    """Test-time pre-activation units: the BatchNorm + ReLU that opens unit k + 1 reads the residual sum unit k's last convolution
+    writes (two readers: it cannot fold) and is that convolution's SECOND output (sn_conv_fwd_dual).  Two chained units with an
+    identity and a projection shortcut, a large batch (plain launch) and a 2-chip batch (split-K launch + dual reduce): bit-equal
+    to the separate sn_bn_apply (SNIPER_INFER_DUAL_BN=0) on the eager, capturing and replaying calls, and after set_params."""
+    import os
+    import sniper_amd.mx as mx
+
+    def bn_relu(x, name):
+        return mx.sym.Activation(data=mx.sym.BatchNorm(data=x, fix_gamma=False, eps=2e-5, use_global_stats=True, name=name + '_bn'),
+                                 act_type='relu', name=name + '_relu')
+
+    def unit(x, nf, name, match):
+        a1 = bn_relu(x, name + '1')
+        c1 = mx.sym.Convolution(data=a1, kernel=(1, 1), num_filter=nf // 4, no_bias=True, name=name + '_c1')
+        c2 = mx.sym.Convolution(data=bn_relu(c1, name + '2'), kernel=(3, 3), pad=(1, 1), num_filter=nf // 4, no_bias=True, name=name + '_c2')
+        c3 = mx.sym.Convolution(data=bn_relu(c2, name + '3'), kernel=(1, 1), num_filter=nf, no_bias=True, name=name + '_c3')
+        sc = x if match else mx.sym.Convolution(data=a1, kernel=(1, 1), num_filter=nf, no_bias=True, name=name + '_sc')
+        return c3 + sc
+    d = mx.sym.Variable('data')
+    u1 = unit(d, 512, 'u1', False)
+    u2 = unit(u1, 512, 'u2', True)
+    u3 = unit(u2, 512, 'u3', True)
+    out = mx.sym.Group([bn_relu(u3, 'top'), u3])
+    rs = np.random.RandomState(6)
+    for shape in ((8, 256, 32, 40), (2, 256, 12, 20)):
+        shapes = [('data', shape)]
+
+        def run(dual):
+            old = os.environ.get('SNIPER_INFER_DUAL_BN')
+            os.environ['SNIPER_INFER_DUAL_BN'] = '1' if dual else '0'
+            try:
+                mod = mx.mod.Module(symbol=out, context=[mx.gpu(0)], data_names=['data'], label_names=None)
+                mod.bind(shapes, None, for_training=False)
+            finally:
+                if old is None:
+                    del os.environ['SNIPER_INFER_DUAL_BN']
+                else:
+                    os.environ['SNIPER_INFER_DUAL_BN'] = old
+            return mod
+        fused, plain = run(True), run(False)
+        exe = next(iter(fused._exes.values()))
+        arg, aux = {}, {}
+        for name, p in exe.params.items():
+            shp = p.ref_shape
+            v = rs.uniform(0.5, 1.5, shp) if name.endswith('_gamma') else \
+                (rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:])) if name.endswith('_weight') else rs.standard_normal(shp) * 0.3)
+            arg[name] = mx.nd.array(v.astype(np.float32))
+        for name, t in exe.aux.items():
+            aux[name] = mx.nd.array((rs.uniform(0.5, 2.0, tuple(t.shape)) if name.endswith('_var') else
+                                     rs.standard_normal(tuple(t.shape)) * 0.2).astype(np.float32))
+        for m in (fused, plain):
+            m.init_params(arg_params=arg, aux_params=aux)
+        dual = sorted(s.node.name for s in exe.steps if type(s).__name__ == 'BatchNormStep' and getattr(s, 'dual_from', None) is not None)
+        # the BatchNorm that opens u2, u3 and the one on top read a residual sum; u1's reads the graph input (no producing convolution)
+        assert dual == ['top_bn', 'u21_bn', 'u31_bn'], dual
+        assert not any(getattr(s, 'dual_from', None) is not None for s in next(iter(plain._exes.values())).steps
+                       if type(s).__name__ == 'BatchNormStep')
+        for call in range(3):            # eager, capture, replay
+            x = mx.nd.array(rs.standard_normal(shape).astype(np.float32))
+            batch = mx.io.DataBatch(data=[x], label=None, pad=0, index=None, provide_data=shapes, provide_label=None)
+            fused.forward(batch, is_train=False)
+            a = [o.asnumpy() for o in fused.get_outputs()]
+            plain.forward(batch, is_train=False)
+            b = [o.asnumpy() for o in plain.get_outputs()]
+            for u, v in zip(a, b):
+                assert np.isfinite(u).all() and np.array_equal(u, v), (shape, call, float(np.abs(u - v).max()))
+            assert (a[0] > 0).mean() > 0.2
+        arg2 = {k: mx.nd.array(v.asnumpy() * 0.5) if k.endswith('_gamma') else v for k, v in arg.items()}
+        for m in (fused, plain):
+            m.set_params(arg2, aux)
+        fused.forward(batch, is_train=False)
+        plain.forward(batch, is_train=False)
+        u, v = fused.get_outputs()[0].asnumpy(), plain.get_outputs()[0].asnumpy()
+        assert np.array_equal(u, v) and not np.allclose(u, a[0])
+
+
 def test_set_params_after_capture_reaches_unfolded_batch_statistics_layers():
     """a test-time executor normalises use_global_stats=False layers with the moving statistics too; when such a
     layer is NOT folded into its producer (here: its input has a second reader), its scale / shift used to be recomputed
