@@ -157,22 +157,17 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned 
       for (int u = 0; u < kSelRegKeys; ++u)
         if (u < iters) count(kreg[u], u * kSelThreads + tid < n);       // (u < iters is wave-uniform: the ballots see whole waves)
     }
-    for (int i = tid; !REG && i < n; i += kSelThreads) {
-      const unsigned long long key = k[i];
-      const bool in = (key & mask) == prefix;
-      const unsigned d = (unsigned)(key >> shift) & 255u;
-      // scores cluster in a few exponent buckets: when the whole wave agrees, one atomic instead of 64 serialised ones
-      const unsigned long long act = __ballot(in);
-      if (act) {
-        const int leader = __ffsll((long long)act) - 1;
-        const unsigned d0 = (unsigned)__shfl((int)d, leader, 64);
-        const bool same = __ballot(in && d == d0) == act;
-        if (same) {
-          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d0], (unsigned)__popcll(act));
-        } else if (in) {
-          atomicAdd(&hist[d], 1u);
-        }
+    // streaming form (maps beyond the register budget: 74 k - 231 k anchors at the finer test scales): eight independent loads
+    // in flight per thread and pass -- one dependent L2 load per iteration left a pass latency-bound (424 us for 74 k keys)
+    for (int base = 0; !REG && base < n; base += kSelThreads * 8) {
+      unsigned long long kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * kSelThreads + tid;
+        kk[u] = i < n ? k[i] : 0ull;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) count(kk[u], base + u * kSelThreads + tid < n);
     }
     __syncthreads();
     if (tid == 0) {
@@ -205,12 +200,19 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_sort_kernel(unsigned 
         if (pos < P2) sel_buf[pos] = kreg[u];
       }
   }
-  for (int i = tid; !REG && i < n; i += kSelThreads) {
-    const unsigned long long key = k[i];
-    if (key <= kth) {
-      const int pos = atomicAdd(&s_cnt, 1);
-      if (pos < P2) sel_buf[pos] = key;
+  for (int base = 0; !REG && base < n; base += kSelThreads * 8) {
+    unsigned long long kk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * kSelThreads + tid;
+      kk[u] = i < n ? k[i] : ~0ull;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + u * kSelThreads + tid < n && kk[u] <= kth) {
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < P2) sel_buf[pos] = kk[u];
+      }
   }
   __syncthreads();
   for (int size = 2; size <= P2; size <<= 1) {

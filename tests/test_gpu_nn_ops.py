@@ -866,11 +866,12 @@ def test_multi_proposal_target_at_the_c2_launch_shape_vs_oracle(min_size):
 
 
 @pytest.mark.parametrize('A,Fh,Fw,pre,quant', [(21, 32, 32, 6000, 0), (21, 32, 32, 6000, 64), (15, 16, 16, 6000, 8), (21, 40, 56, 6000, 0),
-                                                (3, 4, 5, 20, 4)])
+                                                (3, 4, 5, 20, 4), (21, 50, 80, 6000, 16), (21, 88, 125, 6000, 0)])
 def test_proposal_topk_select_equals_full_sort(A, Fh, Fw, pre, quant, monkeypatch):
     """The proposal ordering (radix select of the pre_nms_top_n best keys + LDS sort) must produce exactly the RoIs of the
     full sort: R101 training size, heavily tied scores (quantised probabilities, min_size rejections -> score -1),
-    pre >= total (MobileNetV2: every anchor selected), a non-square test-image map, a tiny map."""
+    pre >= total (MobileNetV2: every anchor selected), a non-square test-image map, a tiny map, and the 84 k / 231 k-anchor maps of the
+    800 x 1280 and 1400 x 2000 test scales (streaming form of the select: eight loads in flight per thread, ragged last group)."""
     hip = _hip()
     rs = np.random.RandomState(A * Fh + quant)
     B, stride, post = 3, 16, 300
