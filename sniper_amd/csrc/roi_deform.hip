@@ -692,60 +692,6 @@ struct BinWinD {
   int x_lo, nx, y_lo, ny, slow;
   float kx, ky;     // trans_std / count * roi_w, ... * roi_h
 };
-// The two rare / one-off parts -- the per-bin geometry (once per bin, 49 threads) and the on-the-fly path of an oversized window
-// (never taken at training sizes: a bin of a 512-pixel RoI on a stride-16 map spans < 8 cells) -- are kept OUT OF LINE (round 5):
-// inlined, their sample lists and tent sums set the kernel's register demand (110 VGPRs), and under the 8-waves cap below the
-// gather loop spilled 168 B per lane (530 MB fetched / 123 MB written per launch for a 2.35 MB output, profiles/r04_pmc_kernels.json).
-__device__ __noinline__ int trans_bin_setup(BinWinD *bp, const float *__restrict__ rois, const float *__restrict__ trans, int r, int bin,
-                                            int P, int S, float scale, float trans_std, int H, int W) {
-  const int ph = bin / P, pw = bin - ph * P;
-  const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-  const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
-  BinWinD &b = *bp;
-  const int count = ax.n * ay.n;
-  const float k = count ? trans_std / (float)count : 0.f;
-  b.kx = k * g.roi_w;
-  b.ky = k * g.roi_h;
-  b.x_lo = ax.lo; b.nx = count ? ax.hi - ax.lo + 1 : 0;
-  b.y_lo = ay.lo; b.ny = count ? ay.hi - ay.lo + 1 : 0;
-  b.slow = (b.nx > kWinMax || b.ny > kWinMax) ? 1 : 0;
-  if (!b.slow) {
-#pragma unroll
-    for (int q = 0; q < kWinMax; ++q) {
-      b.wx[q] = q < b.nx ? tent_sum(ax, ax.lo + q) : 0.f;
-      b.dwx[q] = q < b.nx ? tent_dsum(ax, ax.lo + q) : 0.f;
-      b.wy[q] = q < b.ny ? tent_sum(ay, ay.lo + q) : 0.f;
-      b.dwy[q] = q < b.ny ? tent_dsum(ay, ay.lo + q) : 0.f;
-    }
-  }
-  return g.b;
-}
-
-__device__ __noinline__ void trans_bin_slow(const half_t *__restrict__ img, half8 go, const float *__restrict__ rois,
-                                            const float *__restrict__ trans, int r, int bin, int P, int S, float scale, float trans_std,
-                                            int H, int W, int C, float *gtx_io, float *gty_io) {
-  const int ph = bin / P, pw = bin - ph * P;
-  const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-  const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
-  float gtx = *gtx_io, gty = *gty_io;
-  for (int y = ay.lo; y <= ay.hi; ++y) {
-    const float wy = tent_sum(ay, y), dwy = tent_dsum(ay, y);
-    if (wy == 0.f && dwy == 0.f) continue;
-    for (int x = ax.lo; x <= ax.hi; ++x) {
-      const float kx = wy * tent_dsum(ax, x), ky = dwy * tent_sum(ax, x);
-      if (kx == 0.f && ky == 0.f) continue;
-      const half8 u = *reinterpret_cast<const half8 *>(img + ((size_t)y * W + x) * C);
-      float dot = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
-      gtx += kx * dot;
-      gty += ky * dot;
-    }
-  }
-  *gtx_io = gtx;
-  *gty_io = gty;
-}
-
 // Occupancy (round 4, profiles/r04_kab_roi_occupancy.txt): both per-RoI gather kernels compile to 110 - 120 VGPRs = 4 waves per
 // SIMD.  Capped at 64 VGPRs (8 waves, ~170 B of scratch per lane) this kernel runs 253 -> 211 us; the forward gets SLOWER
 // (154 -> 211 / 267 us at 6 / 8 waves: its 4 x 4 window of loads spills; with only two window rows in flight it needs 108 VGPRs and
@@ -758,8 +704,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ int s_b;
   const int r = blockIdx.x, cpr = C >> 3, nb = P * P;   // host: cpr is a power of two <= 64
   if (threadIdx.x < nb) {
-    const int img_b = trans_bin_setup(&win[threadIdx.x], rois, trans, r, threadIdx.x, P, S, scale, trans_std, H, W);
-    if (threadIdx.x == 0) s_b = img_b;
+    const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
+    const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+    const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+    BinWinD &b = win[threadIdx.x];
+    const int count = ax.n * ay.n;
+    const float k = count ? trans_std / (float)count : 0.f;
+    b.kx = k * g.roi_w;
+    b.ky = k * g.roi_h;
+    b.x_lo = ax.lo; b.nx = count ? ax.hi - ax.lo + 1 : 0;
+    b.y_lo = ay.lo; b.ny = count ? ay.hi - ay.lo + 1 : 0;
+    b.slow = (b.nx > kWinMax || b.ny > kWinMax) ? 1 : 0;
+    if (!b.slow) {
+#pragma unroll
+      for (int q = 0; q < kWinMax; ++q) {
+        b.wx[q] = q < b.nx ? tent_sum(ax, ax.lo + q) : 0.f;
+        b.dwx[q] = q < b.nx ? tent_dsum(ax, ax.lo + q) : 0.f;
+        b.wy[q] = q < b.ny ? tent_sum(ay, ay.lo + q) : 0.f;
+        b.dwy[q] = q < b.ny ? tent_dsum(ay, ay.lo + q) : 0.f;
+      }
+    }
+    if (threadIdx.x == 0) s_b = g.b;
   }
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
@@ -791,8 +756,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             gty += ky * dot;
           }
         }
-      } else {             // oversized window: weights on the fly, as dpsroi_bwd_trans_kernel (out of line: see trans_bin_setup)
-        trans_bin_slow(img, go, rois, trans, r, bin, P, S, scale, trans_std, H, W, C, &gtx, &gty);
+      } else {             // oversized window: weights on the fly, as dpsroi_bwd_trans_kernel
+        const int ph = bin / P, pw = bin - ph * P;
+        const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+        const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+        for (int y = ay.lo; y <= ay.hi; ++y) {
+          const float wy = tent_sum(ay, y), dwy = tent_dsum(ay, y);
+          if (wy == 0.f && dwy == 0.f) continue;
+          for (int x = ax.lo; x <= ax.hi; ++x) {
+            const float kx = wy * tent_dsum(ax, x), ky = dwy * tent_sum(ax, x);
+            if (kx == 0.f && ky == 0.f) continue;
+            const half8 u = *reinterpret_cast<const half8 *>(img + ((size_t)y * W + x) * C);
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
+            gtx += kx * dot;
+            gty += ky * dot;
+          }
+        }
       }
       gtx *= b.kx;
       gty *= b.ky;
