@@ -506,19 +506,31 @@ def bench_inference(passes=5, jobs=None):
             blobs[key] = focus_map_blobs(scale_i, image, chip, net_map)
         return blobs[key]
 
+    def one_pass(base, scale_dets=False):
+        roidb = [dict(r) for r in base]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache,
+                                     focus_map_fn=fmap, return_scale_dets=scale_dets, concurrent_jobs=jobs, lanes=lanes)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res
+
     def run(base, n_passes):
-        dt = chips_by_scale = dets = None
+        # the timed passes are the product's default path: every chip's rows stay in HBM, aggregation on the device, one copy of the
+        # final boxes (Tester.aggregate_device); one more pass, untimed, brings the per-scale detection lists to the host for the
+        # chip counts and the CPU baseline of the aggregation
+        dt = None
         for _ in range(n_passes):
-            roidb = [dict(r) for r in base]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _, dets = imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, Imdb(), roidb, [mx.gpu(0)], None, None, module_cache=cache,
-                                             focus_map_fn=fmap, return_scale_dets=True, concurrent_jobs=jobs, lanes=lanes)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            # chips per image at every scale: scale 0 is the whole image; the per-scale detection lists record how many chips ran
-            chips_by_scale = [[len(d[1][i]) for i in range(len(base))] for d in dets]
+            dt, _ = one_pass(base)
+        _, (_, dets) = one_pass(base, scale_dets=True)
+        # chips per image at every scale: scale 0 is the whole image; the per-scale detection lists record how many chips ran
+        chips_by_scale = [[len(d[1][i]) for i in range(len(base))] for d in dets]
         return dt, dets, chips_by_scale
+
+    def bound_executors():
+        mods = [m for k, m in cache.items() if hasattr(m, '_exes')] + \
+               [m for k, v in cache.items() if isinstance(k, tuple) and k and k[0] == '__lanes__' for m in v]
+        return sum(len(m._exes) for m in mods)
     # one batch of 8 images (rounds 2-4 reported this pass as the value; kept beside it): 1 + 1 + ~9 batches, and between the
     # scales the host phases nothing overlaps -- collect, FocusChips, new iterator, first image preparation: ~10 ms of its 44
     sdt, _, schips = run(images[:n_short], passes)
@@ -544,6 +556,26 @@ def bench_inference(passes=5, jobs=None):
                                  'what': 'the first %d of the images as a pass of their own -- the pass rounds 2-4 quoted (96, 160 - 175, '
                                          '170 - 180 images/s): one batch at the coarsest scale, so the per-scale host phases '
                                          '(collect, FocusChips, iterator, first image preparation) are not amortised' % n_short}}
+    # ---- what a batch shape the service has NOT met costs: 32 images of the other COCO aspect ratios of the
+    # SURVEY 8(d) roidb through the same warm Modules -- their chips land in (H/64, W/64) buckets the passes above never bound.
+    # Pass 1 binds and runs them eagerly, pass 2 captures, pass 3 replays: cold_shape_ms = the extra time of passes 1 and 2 over
+    # pass 3 per newly bound executor; value_unseen_shapes = images/s of pass 1 (every shape new).
+    try:
+        sizes = [(480, 640), (427, 640), (375, 500), (640, 427)]             # (h, w): not the 640 x 480 of the passes above
+        rs2 = np.random.RandomState(1)
+        odd = [{'image': rs2.randint(0, 256, (h, w, 3)).astype(np.uint8), 'width': w, 'height': h, 'flipped': False,
+                'gt_overlaps': np.zeros((1, 81), np.float32)} for h, w in (sizes[i % len(sizes)] for i in range(32))]
+        e0 = bound_executors()
+        t1, _ = one_pass(odd)
+        t2, _ = one_pass(odd)
+        t3, _ = one_pass(odd)
+        new = bound_executors() - e0
+        out['unseen_shapes'] = {'images': len(odd), 'new_executors': new, 'seconds_pass1_bind': round(t1, 3),
+                                'seconds_pass2_capture': round(t2, 3), 'seconds_pass3_replay': round(t3, 3)}
+        out['value_unseen_shapes'] = round(len(odd) / t1, 2)
+        out['cold_shape_ms'] = round(((t1 - t3) + (t2 - t3)) / max(new, 1) * 1e3, 1)
+    except Exception as e:      # noqa: BLE001 -- a report
+        out['unseen_shapes'] = {'failed': repr(e)}
     # ---- roofline of the pass (untimed, after the measurement): one more pass on ONE lane with the executors running eagerly
     # (a replayed hipGraph cannot be bracketed), every conv-family entry and the other device entries of the pass between HIP
     # events on their stream.  FLOPs from the entries' arguments (as the training roofline), so it is what these chips cost.
