@@ -157,6 +157,9 @@ def run(sym, params, aux, inputs, is_train=True, want_grads=True, overrides=None
     device's instead of flipping wherever a pre-activation lies within fp16 rounding of the kink, which is what
     an end-to-end GRADIENT comparison needs.  Returns (list of output arrays, {param name: gradient array or None})."""
     overrides = overrides or {}
+    # (denormal gradients cost the CPU's slow path in every convolution they reach -- a third of the evaluation's time -- and are
+    # 30 orders of magnitude below anything a comparison here resolves)
+    torch.set_flush_denormal(True)
     # force: {node name: value} -- teacher forcing.  The node is evaluated by the oracle on its (forced) inputs, the
     # mismatch with the given value is recorded in run.local_err[name] (relative L2), and the given value replaces the
     # oracle's downstream while the GRADIENT still flows through the oracle's operator (y + (forced - y).detach()).

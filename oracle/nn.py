@@ -413,7 +413,82 @@ def _deform_sample(py, px, H, W):
     return ok, y0, y1, x0, x1, ly, lx
 
 
+def _deform_positions(offset, n, g, T, KW, Ho, Wo, stride, pad, dil, H, W):
+    """Sampling geometry of image n, deformable group g, all (tap, oy, ox) at once -- the branches of _deform_sample on arrays.
+    -> ok (T,Ho,Wo) bool, y0, y1, x0, x1 (int, in range everywhere), ly, lx (float64)."""
+    t = np.arange(T)
+    kh, kw = t // KW, t % KW
+    by = (np.arange(Ho)[None, :] * stride - pad + kh[:, None] * dil).astype(np.float32)          # (T, Ho)
+    bx = (np.arange(Wo)[None, :] * stride - pad + kw[:, None] * dil).astype(np.float32)          # (T, Wo)
+    off = np.asarray(offset[n, g * 2 * T:(g + 1) * 2 * T]).reshape(T, 2, Ho, Wo)
+    # the sampling position is a float32 sum (the operator's DType; the border test `p < dim` is a discontinuity: 32 - 1e-6 is
+    # 32.0 in float32 and inside the map in double)
+    py = (by[:, :, None] + off[:, 0].astype(np.float32)).astype(np.float64)
+    px = (bx[:, None, :] + off[:, 1].astype(np.float32)).astype(np.float64)
+    ok = (py >= 0) & (px >= 0) & (py < H) & (px < W)
+    y0 = np.floor(py).astype(np.int64)
+    x0 = np.floor(px).astype(np.int64)
+    top, right = y0 >= H - 1, x0 >= W - 1
+    ly = np.where(top, 0.0, py - y0)
+    lx = np.where(right, 0.0, px - x0)
+    y0 = np.where(top, H - 1, y0)
+    x0 = np.where(right, W - 1, x0)
+    y1 = np.where(top, H - 1, y0 + 1)
+    x1 = np.where(right, W - 1, x0 + 1)
+    clip = lambda a, hi: np.clip(a, 0, hi)                     # (positions outside the map are masked by `ok`; keep them indexable)
+    return ok, clip(y0, H - 1), clip(y1, H - 1), clip(x0, W - 1), clip(x1, W - 1), ly, lx
+
+
 def deform_im2col(data, offset, KH, KW, stride, pad, dil, DG):
+    """data (N,C,H,W), offset (N, 2*T*DG, Ho, Wo) -> col (N,Ho,Wo,T,C).  Array form of deform_im2col_loops (the statement the
+    array form is checked against in tests/test_oracle_golden.py): same positions, same four-corner weights."""
+    N, C, H, W = data.shape
+    Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    T, cg = KH * KW, C // DG
+    col = np.zeros((N, Ho, Wo, T, C), np.float64)
+    for n in range(N):
+        for g in range(DG):
+            ok, y0, y1, x0, x1, ly, lx = _deform_positions(offset, n, g, T, KW, Ho, Wo, stride, pad, dil, H, W)
+            d = np.asarray(data[n, g * cg:(g + 1) * cg], np.float64).transpose(1, 2, 0)          # (H, W, cg)
+            w = [(1 - ly) * (1 - lx), (1 - ly) * lx, ly * (1 - lx), ly * lx]
+            v = ((w[0] * ok)[..., None] * d[y0, x0] + (w[1] * ok)[..., None] * d[y0, x1] +
+                 (w[2] * ok)[..., None] * d[y1, x0] + (w[3] * ok)[..., None] * d[y1, x1])         # (T, Ho, Wo, cg)
+            col[n, :, :, :, g * cg:(g + 1) * cg] = v.transpose(1, 2, 0, 3)
+    return col
+
+
+def deform_col2im(dcol, data, offset, KH, KW, stride, pad, dil, DG):
+    """Gradients of deform_im2col w.r.t. data and offset; array form of deform_col2im_loops (the four-corner scatter as a sparse
+    (pixels x samples) product, float64: the sums differ from the loop's order of addition by rounding only)."""
+    import scipy.sparse as sp
+    N, C, H, W = data.shape
+    _, Ho, Wo, T, _ = dcol.shape
+    cg = C // DG
+    d_data = np.zeros(data.shape, np.float64)
+    d_off = np.zeros(offset.shape, np.float64)
+    S = T * Ho * Wo
+    for n in range(N):
+        for g in range(DG):
+            ok, y0, y1, x0, x1, ly, lx = _deform_positions(offset, n, g, T, KW, Ho, Wo, stride, pad, dil, H, W)
+            cs = slice(g * cg, (g + 1) * cg)
+            dd = np.asarray(dcol[n, :, :, :, cs], np.float64).transpose(2, 0, 1, 3).reshape(S, cg)     # samples (t, oy, ox) x channels
+            okf = ok.reshape(S).astype(np.float64)
+            w = [((1 - ly) * (1 - lx)).reshape(S) * okf, ((1 - ly) * lx).reshape(S) * okf, (ly * (1 - lx)).reshape(S) * okf,
+                 (ly * lx).reshape(S) * okf]
+            pix = [(y0 * W + x0).reshape(S), (y0 * W + x1).reshape(S), (y1 * W + x0).reshape(S), (y1 * W + x1).reshape(S)]
+            M = sp.coo_matrix((np.concatenate(w), (np.concatenate(pix), np.tile(np.arange(S), 4))), shape=(H * W, S)).tocsr()
+            d_data[n, cs] = (M @ dd).reshape(H, W, cg).transpose(2, 0, 1)
+            d = np.asarray(data[n, cs], np.float64).transpose(1, 2, 0)
+            a, b, c, e = d[y0, x0].reshape(S, cg), d[y0, x1].reshape(S, cg), d[y1, x0].reshape(S, cg), d[y1, x1].reshape(S, cg)
+            lyf, lxf = ly.reshape(S, 1), lx.reshape(S, 1)
+            gy = (dd * ((1 - lxf) * (c - a) + lxf * (e - b))).sum(1) * okf
+            gx = (dd * ((1 - lyf) * (b - a) + lyf * (e - c))).sum(1) * okf
+            d_off[n, g * 2 * T:(g + 1) * 2 * T] = np.stack((gy.reshape(T, Ho, Wo), gx.reshape(T, Ho, Wo)), 1).reshape(2 * T, Ho, Wo)
+    return d_data, d_off
+
+
+def deform_im2col_loops(data, offset, KH, KW, stride, pad, dil, DG):
     """data (N,C,H,W), offset (N, 2*T*DG, Ho, Wo) -> col (N,Ho,Wo,T,C)."""
     N, C, H, W = data.shape
     Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
@@ -439,7 +514,7 @@ def deform_im2col(data, offset, KH, KW, stride, pad, dil, DG):
     return col
 
 
-def deform_col2im(dcol, data, offset, KH, KW, stride, pad, dil, DG):
+def deform_col2im_loops(dcol, data, offset, KH, KW, stride, pad, dil, DG):
     N, C, H, W = data.shape
     _, Ho, Wo, T, _ = dcol.shape
     cg = C // DG

@@ -131,3 +131,26 @@ def test_dpsroi_sparse_operator_form_equals_the_loop_definition():
             assert np.abs(d1 - d2).max() <= 1e-6 * max(1.0, np.abs(d1).max())
             if tr is not None:
                 assert np.abs(t1 - t2).max() <= 1e-5 * max(1.0, np.abs(t1).max())
+
+
+def test_deformable_sampling_array_form_equals_the_loop_statement():
+    """oracle/nn.py: deform_im2col / deform_col2im walk (image, group) with array operations; the per-sample loops they replace stay
+    as deform_*_loops -- the statement (one sample at a time, the branches of _deform_sample spelled out).  Equal on dilated,
+    strided and 1 x 1 kernels, offsets that leave the map, positions that land exactly on the border."""
+    import numpy as np
+    from oracle import nn
+    rs = np.random.RandomState(0)
+    for (N, C, H, W, K, stride, pad, dil, DG) in ((2, 8, 9, 11, 3, 1, 2, 2, 4), (1, 4, 7, 7, 3, 2, 1, 1, 1), (2, 12, 6, 10, 1, 1, 0, 1, 2)):
+        T = K * K
+        Ho = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        data = rs.standard_normal((N, C, H, W))
+        off = (rs.standard_normal((N, 2 * T * DG, Ho, Wo)) * 2.5).astype(np.float32)
+        off[0, 0, 0, 0] = np.float32(H)                       # far outside
+        off[0, 1, 0, 0] = np.float32(W - 1 + pad)             # exactly on the last column for tap 0
+        a, b = nn.deform_im2col(data, off, K, K, stride, pad, dil, DG), nn.deform_im2col_loops(data, off, K, K, stride, pad, dil, DG)
+        assert np.array_equal(a, b)
+        dcol = rs.standard_normal(a.shape)
+        a1, a2 = nn.deform_col2im(dcol, data, off, K, K, stride, pad, dil, DG)
+        b1, b2 = nn.deform_col2im_loops(dcol, data, off, K, K, stride, pad, dil, DG)
+        assert np.abs(a1 - b1).max() < 1e-12 and np.abs(a2 - b2).max() < 1e-12
