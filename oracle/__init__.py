@@ -12,6 +12,9 @@ Pinning status (see DESIGN.md section "Oracle"):
   ``oracle/ref_py.py``) and against committed golden vectors (``tests/golden``).
 * soft-NMS, cpu_nms: restated line by line from ``lib/nms/cpu_nms.pyx`` (which does not build
   under Cython 3); pinned by hand-derived known-answer cases only.
+* cv2.resize(uint8, INTER_LINEAR) (im_worker): ``oracle/cv_resize.py`` + ``sniper_oracle.c::orc_cv_resize_linear_u8c3``, two
+  independent restatements of OpenCV's published fixed-point algorithm (OpenCV is a third-party dependency absent from
+  the reference tree and from this image): pinned to the published algorithm, no cv2-minted vectors.
 * network ops whose source lives in the un-vendored SNIPER-mxnet submodule (Convolution,
   BatchNorm, MultiProposalTarget, DeformablePSROIPooling, ...): **parity unpinned** -- the
   restatements in ``oracle/nn.py`` follow the published definitions and are cross-checked

@@ -26,6 +26,8 @@ never touch the GPU."""
 import multiprocessing.pool
 import os
 
+import numpy as np
+
 
 class _Done(object):
     """AsyncResult of a routed map (the batched call already ran)."""
@@ -77,12 +79,166 @@ def route(func):
             return owner.extract_batch if name == 'chip_extractor' else owner.assign_batch
         mirror = _mirror_of(owner)
         return mirror.extract_batch if name == 'chip_extractor' else mirror.assign_batch
+    if kind == 'anchor_worker' and name == 'worker' and os.environ.get('SNIPER_POOL_ROUTE_BATCH', '1') != '0' and \
+            all(hasattr(owner, a) for a in ('scales', 'ratios', 'feat_stride', 'feat_height', 'batch_size', 'num_fg', 'pos_thresh',
+                                            'neg_thresh', 'auto_focus')):
+        return lambda items: _anchor_batch(owner, items, func)
+    if kind == 'im_worker' and name == 'worker' and os.environ.get('SNIPER_POOL_ROUTE_BATCH', '1') != '0' and \
+            getattr(owner, 'crop_size', None) and hasattr(owner, 'cfg'):
+        return lambda items: _image_batch(owner, items, func)
     if kind == 'nms_worker' and name == 'worker' and hasattr(owner, 'nms_wrapper') and \
             all(hasattr(owner.nms_wrapper, a) for a in ('thresh', 'sigma')):
         from ..inference import nms_wrapper
         w = nms_wrapper(owner.nms_wrapper.thresh, owner.nms_wrapper.sigma)
         return w.process_many
     return None
+
+
+# ---- per-batch workers of MNIteratorE2E._get_batch (lib/iterators/MNIteratorE2E.py:147,173) --------------------------------------
+# `pool.map(anchor_worker.worker, worker_data)` and `thread_pool.map_async(im_worker.worker, ims)` run, in the reference, one chip
+# per work item on the CPU (numpy IoU / labelling, cv2 decode + resize), return host arrays, and `_get_batch` stacks them into
+# `mx.nd.zeros` tensors that the Module then uploads: 63 MB of pixels + 15 MB of labels from pageable memory every step.  Routed,
+# the whole map is the mirror's batched GPU work (one sn_anchor_assign launch; one sn_im_prepare per chip from the device image
+# cache) and the results STAY in HBM: the work items come back as handles to the batch tensors, and the shim's unplaced
+# `mx.nd.zeros` (sniper_amd/mx/ndarray.py) is placed on the device by the first such write -- `_get_batch`'s own lines then move
+# device memory.  What `_get_batch` reads in any other way still sees the reference's values: a handle materialises them
+# (np.asarray / asnumpy: a copy to the host, and for the sparse (values, pids) pair the `np.where(bbox_weights == 1)` the reference
+# worker returns).  Sub-sampling of the 256 RPN labels: the reference draws with numpy's global RNG per chip; the batched launch
+# draws with the kernel's hash of (seed, chip, anchor) -- same rule, different draws (replaying numpy's needs the labels on the
+# host first: AnchorAssigner.numpy_replay_keys, used by the parity tests).  SNIPER_POOL_ROUTE_BATCH=0: per item on threads.
+class _Dense(object):
+    """dense device tensor a sparse reference value stands for: writes itself into a destination row"""
+    _device_resident = True
+
+    def __init__(self, t):
+        self.t = t
+        self.device = t.device
+
+    def write_dense_into(self, dst):
+        dst.copy_(self.t.reshape(dst.shape))
+
+
+class _SparseVals(object):
+    """`bbox_targets[pids]` of anchor_worker.worker (data_workers.py:354-357): the values at the positive anchors"""
+    _device_resident = True
+
+    def __init__(self, batch, i):
+        self.batch, self.i = batch, i
+
+    def __array__(self, dtype=None, copy=None):
+        pid = self.batch.pids(self.i)
+        v = self.batch.host('bbox_target')[self.i][pid[0], pid[1], pid[2]]
+        return v if dtype is None else v.astype(dtype)
+
+
+class _PidAxis(object):
+    _device_resident = True
+
+    def __init__(self, batch, i, axis):
+        self.batch, self.i, self.axis = batch, i, axis
+
+    def __len__(self):                      # (`if len(pids[0]) > 0`, MNIteratorE2E.py:190: an empty chip copies zeros)
+        return 1
+
+    def __array__(self, dtype=None, copy=None):
+        return self.batch.pids(self.i)[self.axis]
+
+    def dense_source(self, value):
+        """`row[pids[0], pids[1], pids[2]] = value`: the sparse values -> the dense targets; the scalar 1.0 -> the dense weights"""
+        key = 'bbox_target' if isinstance(value, _SparseVals) else 'bbox_weight'
+        return _Dense(self.batch.out[key][self.i])
+
+
+class _SparsePids(object):
+    """`pids = np.where(bbox_weights == 1)` as the (3, n) array of anchor_worker.worker (data_workers.py:356,365)"""
+    _device_resident = True
+
+    def __init__(self, batch, i):
+        self.batch, self.i = batch, i
+
+    def __getitem__(self, axis):
+        return _PidAxis(self.batch, self.i, axis)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.stack(self.batch.pids(self.i)).astype(np.float32 if dtype is None else dtype)
+
+    def asnumpy(self):
+        return np.asarray(self)
+
+
+class _AnchorBatch(object):
+    def __init__(self, out):
+        self.out, self._host, self._pids = out, {}, {}
+
+    def host(self, key):
+        if key not in self._host:
+            self._host[key] = self.out[key].cpu().numpy()
+        return self._host[key]
+
+    def pids(self, i):
+        if i not in self._pids:
+            self._pids[i] = np.where(self.host('bbox_weight')[i] == 1)
+        return self._pids[i]
+
+
+def _anchor_batch(owner, items, func):
+    import torch
+    from .. import mx
+    items = list(items)
+    if not items or not torch.cuda.is_available() or any(len(d) > 8 for d in items):      # mask polygons: per item on the CPU
+        return [func(d) for d in items]
+    aa = getattr(owner, '_sniper_anchor_mirror', None)
+    if aa is None:
+        from ..config import AttrDict
+        from ..data.anchors import AnchorAssigner
+        cfg = AttrDict(network=AttrDict(RPN_FEAT_STRIDE=int(owner.feat_stride), ANCHOR_RATIOS=list(owner.ratios),
+                                        ANCHOR_SCALES=[float(x) for x in owner.scales]),
+                       TRAIN=AttrDict(RPN_BATCH_SIZE=int(owner.batch_size), RPN_FG_FRACTION=float(owner.num_fg) / float(owner.batch_size),
+                                      RPN_POSITIVE_OVERLAP=float(owner.pos_thresh), RPN_NEGATIVE_OVERLAP=float(owner.neg_thresh),
+                                      AUTO_FOCUS=bool(owner.auto_focus), AUTO_FOCUS_DC_LOW=getattr(owner, 'auto_focus_dontcare_low', 0),
+                                      AUTO_FOCUS_DC_HIGH=getattr(owner, 'auto_focus_dontcare_high', 0),
+                                      AUTO_FOCUS_SMALL_THRESH=getattr(owner, 'auto_focus_small_thresh', 0)))
+        aa = AnchorAssigner(cfg, int(owner.feat_height) * int(owner.feat_stride))
+        assert aa.num_fg == int(owner.num_fg) and aa.A == int(owner.num_anchors)
+        aa._seed = 0
+        try:
+            owner._sniper_anchor_mirror = aa
+        except AttributeError:
+            pass
+    out = aa.assign(items, seed=aa._seed)
+    aa._seed += 1
+    batch = _AnchorBatch(out)
+    focus = aa.focus_mask(items) if owner.auto_focus else None
+    res = []
+    for i in range(len(items)):
+        r = [mx.nd.NDArray(out['label'][i:i + 1]), _SparseVals(batch, i), _SparsePids(batch, i), mx.nd.NDArray(out['gt_boxes'][i])]
+        if focus is not None:
+            r.append(mx.nd.NDArray(focus[i]))
+        res.append(r)
+    return res
+
+
+def _image_batch(owner, items, func):
+    import torch
+    from .. import mx
+    items = list(items)
+    if not items or not torch.cuda.is_available():
+        return [func(d) for d in items]
+    iw = getattr(owner, '_sniper_im_mirror', None)
+    if iw is None:
+        from ..data.im_worker import im_worker as mirror_cls
+        iw = mirror_cls(owner.cfg, crop_size=owner.crop_size)
+        try:
+            owner._sniper_im_mirror = iw
+        except AttributeError:
+            pass
+    from ..data.im_worker import decode_ahead
+    decode_ahead(iw, [d[0] for d in items])
+    n, cs = len(items), int(owner.crop_size)
+    ims = torch.zeros((n, 3, cs, cs), dtype=torch.float32, device=torch.device('cuda', torch.cuda.current_device()))
+    for k, d in enumerate(items):
+        iw.worker(d, ims[k])
+    return [mx.nd.NDArray(ims[k]) for k in range(n)]
 
 
 class Pool(multiprocessing.pool.ThreadPool):

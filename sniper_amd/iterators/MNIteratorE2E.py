@@ -213,30 +213,8 @@ class MNIteratorE2E(mx.io.DataIter):
 
 
     def _decode_ahead(self, images, dev):
-        """Decode + upload the distinct images of a batch that the device cache does not hold yet, on `threads` threads (JPEG /
-        PNG decoding releases the interpreter lock; one image is 3-10 ms, a batch of 20 chips meets ~3-20 new ones)."""
-        if self.threads <= 1:
-            return
-        cache = getattr(self.im_worker, '_cache', None)
-        need, seen = [], set()
-        for im in images:
-            key = im if isinstance(im, str) else id(im)
-            if key in seen or (cache is not None and cache.holds(im)):
-                continue
-            seen.add(key)
-            need.append(im)
-        if len(need) < 2:
-            return
-        if self._decode_pool is None:
-            from multiprocessing.pool import ThreadPool
-            st = torch.cuda.current_stream()       # uploads on the assembling thread's stream (the prefetch worker's own), not on
-            #                                        the default stream the training step occupies
-
-            def init():
-                torch.cuda.set_device(dev)
-                torch.cuda.set_stream(st)
-            self._decode_pool = ThreadPool(self.threads, initializer=init)
-        self._decode_pool.map(self.im_worker._device_image, need, chunksize=1)
+        from ..data.im_worker import decode_ahead
+        decode_ahead(self.im_worker, images, self.threads)
 
 
 # data parallel, one process per GPU: rank r assembles chips [cur_i + r B, cur_i + (r + 1) B) of every global batch

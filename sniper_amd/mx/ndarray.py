@@ -43,21 +43,62 @@ def _dtype(d):
     return np.dtype(d).type
 
 
+def _is_device(v):
+    """a value that lives in HBM: a CUDA tensor, an NDArray backed by one, or a routed worker's marker (ext/pool.py)"""
+    if getattr(v, '_device_resident', False):
+        return True
+    t = v._store if isinstance(v, NDArray) else v
+    return torch is not None and isinstance(t, torch.Tensor) and t.is_cuda
+
+
 class NDArray(object):
-    """Array handle.  ``_data`` is a numpy array (cpu context) or a torch tensor (gpu context)."""
+    """Array handle.  ``_data`` is a numpy array (cpu context) or a torch tensor (gpu context).
+
+    UNPLACED arrays: ``zeros`` / ``ones`` (and their negation) allocate nothing.  The first write decides where the array lives: a
+    value that is resident in HBM (a batch tensor a routed worker produced, sniper_amd/ext/pool.py) places it on the device and the
+    write is a device copy; anything else -- and any read -- materialises the host array MXNet would have made.  The reference's
+    ``MNIteratorE2E._get_batch`` (lib/iterators/MNIteratorE2E.py:175-201) builds its batch as ``mx.nd.zeros(...)`` + per-chip
+    writes: with GPU-resident worker results the 63 MB image tensor and the dense labels are then born in HBM instead of being
+    assembled on the host and uploaded from pageable memory every step."""
     __array_priority__ = 100.0
 
-    def __init__(self, data, ctx=None):
-        self._data = data
-        self.context = ctx or (cpu() if isinstance(data, np.ndarray) else gpu(0))
+    def __init__(self, data, ctx=None, lazy=None):
+        self._store = data
+        self._lazy = lazy                        # (shape, numpy dtype, fill) while unplaced
+        self.context = ctx or (cpu() if data is None or isinstance(data, np.ndarray) else gpu(0))
+
+    @property
+    def _data(self):
+        if self._store is None:
+            shape, dt, fill = self._lazy
+            self._store = np.full(shape, fill, dtype=dt) if fill else np.zeros(shape, dtype=dt)
+            self._lazy = None
+        return self._store
+
+    @_data.setter
+    def _data(self, v):
+        self._store, self._lazy = v, None
+
+    def _place_on(self, device):
+        """an unplaced array becomes a device array (filled on the caller's current stream)"""
+        shape, dt, fill = self._lazy
+        tdt = getattr(torch, np.dtype(dt).name)
+        self._store = torch.full(tuple(shape), float(fill), dtype=tdt, device=device) if fill else \
+            torch.zeros(tuple(shape), dtype=tdt, device=device)
+        self._lazy = None
+        self.context = gpu(device.index or 0)
 
     # ---- basics
     @property
     def shape(self):
-        return tuple(self._data.shape)
+        if self._store is None:
+            return tuple(self._lazy[0])
+        return tuple(self._store.shape)
 
     @property
     def dtype(self):
+        if self._store is None:
+            return np.dtype(self._lazy[1]).type
         if isinstance(self._data, np.ndarray):
             return self._data.dtype.type
         return np.dtype(str(self._data.dtype).replace('torch.', '')).type
@@ -123,6 +164,8 @@ class NDArray(object):
         return i
 
     def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)) and (self._store is None or _is_device(self)):
+            return _RowView(self, int(i))          # row of an unplaced / device array: writes through (and may place the parent)
         a = self.asnumpy()[self._idx(i)]
         if isinstance(self._data, np.ndarray) and isinstance(a, np.ndarray) and a.base is not None and not isinstance(
                 self._idx(i), tuple):
@@ -130,13 +173,25 @@ class NDArray(object):
         return NDArray(np.asarray(a))
 
     def __setitem__(self, i, v):
+        if self._store is None and _is_device(v):
+            dev = v.device if hasattr(v, 'device') and not isinstance(v, NDArray) else (v._store.device if isinstance(v, NDArray) else None)
+            self._place_on(dev if dev is not None else torch.device('cuda', torch.cuda.current_device()))
+        if _is_device(self):
+            dst = self._store[self._idx(i)] if not (isinstance(i, slice) and i == slice(None)) else self._store
+            if hasattr(v, 'write_dense_into'):                 # a routed worker's marker: the dense device tensor it stands for
+                v.write_dense_into(dst)
+                return
+            src = v._store if isinstance(v, NDArray) else v
+            if isinstance(src, torch.Tensor):
+                dst.copy_(src.reshape(dst.shape) if src.numel() == dst.numel() else src)
+            else:
+                dst.copy_(torch.as_tensor(np.asarray(v.asnumpy() if isinstance(v, NDArray) else v)).to(dst.dtype))
+            return
         if isinstance(v, NDArray):
             v = v.asnumpy()
-        if isinstance(self._data, np.ndarray):
-            self._data[self._idx(i)] = v
-        else:
-            t = torch.as_tensor(np.asarray(v), device=self._data.device).to(self._data.dtype)
-            self._data[self._idx(i)] = t
+        elif hasattr(v, '__array__') and not isinstance(v, np.ndarray):
+            v = np.asarray(v)
+        self._data[self._idx(i)] = v
 
     # ---- arithmetic
     def _bin(self, o, f):
@@ -152,7 +207,11 @@ class NDArray(object):
     def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
     def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
     __div__ = __truediv__
-    def __neg__(self): return NDArray(-self.asnumpy())
+    def __neg__(self):
+        if self._store is None and not isinstance(self, _RowView):          # -mx.nd.ones(...) stays unplaced (MNIteratorE2E.py:180)
+            shape, dt, fill = self._lazy
+            return NDArray(None, None, lazy=(shape, dt, -fill))
+        return NDArray(-self.asnumpy())
 
     def __iadd__(self, o):
         self[:] = self + o
@@ -161,6 +220,58 @@ class NDArray(object):
     def __imul__(self, o):
         self[:] = self * o
         return self
+
+
+class _RowView(NDArray):
+    """``a[i]`` of an unplaced or device-resident array: a handle that writes through to row i (MNIteratorE2E.py:189-194 writes
+    ``bbox_targets[i][pids[0], pids[1], pids[2]] = values`` and ``labels[i] = ...``).  A write of an HBM-resident value / marker
+    into a row of an unplaced parent places the PARENT on the device."""
+
+    def __init__(self, parent, index):
+        self._parent, self._index = parent, index
+        self._lazy = None
+        self.context = parent.context
+
+    @property
+    def _store(self):
+        p = self._parent
+        return None if p._store is None else p._store[self._index]
+
+    @_store.setter
+    def _store(self, v):       # (never rebound)
+        raise AttributeError('a row view has no storage of its own')
+
+    @property
+    def _data(self):
+        return self._parent._data[self._index]
+
+    @property
+    def shape(self):
+        return tuple(self._parent.shape[1:])
+
+    @property
+    def dtype(self):
+        return self._parent.dtype
+
+    def __setitem__(self, i, v):
+        p = self._parent
+        marker = v if hasattr(v, 'write_dense_into') else None
+        if marker is None and isinstance(i, tuple) and i and all(hasattr(j, 'dense_source') for j in i):
+            marker = i[0].dense_source(v)              # `row[pids[0], pids[1], pids[2]] = values | 1.0` of a routed anchor worker
+        if p._store is None and (marker is not None or _is_device(v)):
+            dev = marker.device if marker is not None else (v._store.device if isinstance(v, NDArray) else v.device)
+            p._place_on(dev)
+        if marker is not None and _is_device(p):
+            marker.write_dense_into(p._store[self._index])
+            return
+        if marker is not None:                         # host parent: the marker's real sparse values
+            i, v = tuple(np.asarray(j) for j in i), np.asarray(v) if hasattr(v, '__array__') else v
+        if _is_device(p):
+            NDArray(p._store[self._index]).__setitem__(i, v)
+            return
+        if isinstance(v, NDArray):
+            v = v.asnumpy()
+        p._data[self._index][self._idx(i)] = v
 
 
 def array(source, ctx=None, dtype=None):
@@ -172,12 +283,16 @@ def array(source, ctx=None, dtype=None):
     return NDArray(a, ctx)
 
 
+def _shape(shape):
+    return (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(x) for x in shape)
+
+
 def zeros(shape, ctx=None, dtype=None, **kw):
-    return NDArray(np.zeros(shape, dtype=_dtype(dtype)), ctx)
+    return NDArray(None, ctx, lazy=(_shape(shape), _dtype(dtype), 0.0))          # unplaced: see NDArray
 
 
 def ones(shape, ctx=None, dtype=None, **kw):
-    return NDArray(np.ones(shape, dtype=_dtype(dtype)), ctx)
+    return NDArray(None, ctx, lazy=(_shape(shape), _dtype(dtype), 1.0))
 
 
 def empty(shape, ctx=None, dtype=None):
