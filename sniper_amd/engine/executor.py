@@ -729,6 +729,23 @@ class Executor(object):
                     src = src.asnumpy()
                 if isinstance(src, np.ndarray):
                     src = torch.from_numpy(np.ascontiguousarray(src, np.float32))
+                    if self.device.type == 'cuda':
+                        # host inputs (the reference iterator's small arrays -- valid ranges, im_info -- or whole host batches) go
+                        # through a ring of pinned buffers: a copy from PAGEABLE memory is synchronous, i.e. the host would wait
+                        # for the step in flight before it could enqueue this one (13 ms per batch, profiles/r05_fit_path.txt)
+                        ring = self.__dict__.setdefault('_pinned_inputs', {}).setdefault(node.name, {'k': 0, 'bufs': [], 'evs': []})
+                        if len(ring['bufs']) < 3:
+                            ring['bufs'].append(torch.empty(tuple(src.shape), dtype=torch.float32, pin_memory=True))
+                            ring['evs'].append(None)
+                        k = ring['k'] % len(ring['bufs'])
+                        ring['k'] += 1
+                        if tuple(ring['bufs'][k].shape) != tuple(src.shape):
+                            ring['bufs'][k] = torch.empty(tuple(src.shape), dtype=torch.float32, pin_memory=True)
+                        elif ring['evs'][k] is not None:
+                            ring['evs'][k].synchronize()              # (three steps old: long complete)
+                        ring['bufs'][k].copy_(src)
+                        src = ring['bufs'][k]
+                        ring['pending'] = k
                 elif hasattr(src, '_data'):
                     src = src._data
                 if tuple(src.shape) != v.shape:
@@ -743,6 +760,11 @@ class Executor(object):
                     hip.call('sn_copy2d', src, v.t, 1, n, n, n, 1, 1, hip.stream())
                 else:
                     v.t.copy_(src, non_blocking=True)
+                    ring = getattr(self, '_pinned_inputs', {}).get(node.name)
+                    if ring is not None and ring.pop('pending', None) is not None and src.is_pinned():
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        ring['evs'][(ring['k'] - 1) % len(ring['bufs'])] = ev
 
     def _forward_body(self):
         for v in self.vals.values():

@@ -56,9 +56,57 @@ def patch_iterator_class(cls):
                 crop_idx[inds[i]] = crop_idx[inds[i]] + 1
         self.rank_sliced = True            # Module.fit reads this: the batches are rank-local already
         return True
-    cls.get_batch = get_batch
+    sliced = get_batch
+
+    def get_batch_on_worker_stream(self):
+        """The reference's PrefetchingIter calls the iterator from a worker thread (lib/iterators/PrefetchingIter.py:53-67).  Its
+        batch assembly here is uploads and kernel launches (routed pool maps, sniper_amd/ext/pool.py): on the consumer's stream every
+        synchronous upload waits for the training step in flight.  A batch assembled OFF the main thread is therefore assembled on
+        that thread's own HIP stream and carries `ready_event`; the consumer adopts it (iterators/PrefetchingIter.py::adopt_batch)."""
+        st = _worker_stream()
+        if st is None:
+            return sliced(self)
+        import torch
+        with torch.cuda.stream(st):
+            ok = sliced(self)
+            batch = getattr(self, 'batch', None)
+            if ok and batch is not None:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                try:
+                    batch.ready_event = ev
+                except AttributeError:
+                    st.synchronize()
+        return ok
+    cls.get_batch = get_batch_on_worker_stream
     cls._rank_slice_wrapped = True
     return cls
+
+
+_TLS = None
+
+
+def _worker_stream():
+    """This thread's own stream when it is NOT the main thread, has a GPU bound and still sits on the default stream (a thread that
+    already switched streams -- sniper_amd's PrefetchingIter worker -- keeps its own).  SNIPER_PREFETCH_STREAM=0: never."""
+    import threading
+    if threading.current_thread() is threading.main_thread() or os.environ.get('SNIPER_PREFETCH_STREAM', '1') == '0':
+        return None
+    try:
+        import torch
+    except ImportError:            # pragma: no cover
+        return None
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return None
+    global _TLS
+    if _TLS is None:
+        _TLS = threading.local()
+    st = getattr(_TLS, 'stream', None)
+    if st is None:
+        if torch.cuda.current_stream() != torch.cuda.default_stream():
+            return None
+        st = _TLS.stream = torch.cuda.Stream()
+    return st
 
 
 def _patch_iterator_module(module, base):
