@@ -296,10 +296,20 @@ def _patch_module(module, base):
         module.Pool = Pool
 
 
+def _patch_thread_pool(module, base):
+    """`from multiprocessing.pool import ThreadPool` inside lib/iterators/MNIteratorBase.py (:3,18: `self.thread_pool`, the pool
+    `_get_batch` maps `im_worker.worker` over) -> this Pool: the same threads for everything it does not recognise, the routed
+    batched form for the per-chip image workers."""
+    cur = getattr(module, 'ThreadPool', None)
+    if cur is multiprocessing.pool.ThreadPool and hasattr(module, 'MNIteratorBase'):
+        module.ThreadPool = Pool
+
+
 def install():
     """Scoped (idempotent): the reference modules that create GPU-work pools get this Pool as their `Pool`;
     `multiprocessing.Pool` is not touched."""
     from . import rank_slice
     for base in ('MNIteratorE2E', 'inference'):
         rank_slice.register_post_import(base, _patch_module)
+    rank_slice.register_post_import('MNIteratorBase', _patch_thread_pool)
     rank_slice.install_import_hook()
