@@ -918,6 +918,17 @@ def main():
             fit_path = json.loads(lines[-1]) if lines else {'value': None, 'sample': 'failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
             if fit_path.get('value'):
                 fit_path['ratio_to_value'] = round(fit_path['value'] / value, 3)
+            # the same main_train.py with the reference's OWN lib/iterators + lib/data_utils on the drop-in pool (per-batch worker maps
+            # routed to batched GPU work, batches born in HBM through the shim's unplaced mx.nd.zeros)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fit_path_bench.py'), 'reference', str(args.batch), '40'], cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420,
+                               env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            ref_it = json.loads(lines[-1]) if lines else {'value': None, 'sample': 'failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
+            fit_path['reference_iterator'] = ref_it
+            if ref_it.get('value'):
+                fit_path['reference_iterator_value'] = ref_it['value']
+                fit_path['reference_iterator_ratio'] = round(ref_it['value'] / value, 3)
         except Exception as e:   # noqa: BLE001 -- a report
             fit_path = {'value': None, 'sample': 'failed: %r' % (e,)}
     if rank == 0:

@@ -205,3 +205,32 @@ def test_reference_epoch_chip_database_through_the_routed_pool():
     # (the yml splits the roidb into TRAIN.CHIPS_DB_PARTS = 20 parts: two maps per part)
     assert res['routed_maps'] == 40 and res['unrouted']['routed_maps'] == 0, res
     assert res['routed_equals_unrouted'] and res['chips'] > 300, res
+
+
+def test_reference_get_batch_through_the_routed_per_batch_maps():
+    """The reference's unchanged MNIteratorE2E._get_batch (lib/iterators/MNIteratorE2E.py:112-220): its two per-batch maps --
+    `pool.map(anchor_worker.worker, ...)` and `thread_pool.map_async(im_worker.worker, ...)` -- run as the mirrors' batched GPU work
+    and its own assembly lines (`mx.nd.zeros` + per-chip writes) then build the batch IN HBM (sniper_amd/ext/pool.py, the shim's
+    unplaced arrays).  Against the same call with the routing off (the reference's numpy workers): ground-truth rows, valid ranges
+    and im_info equal; foreground anchors, box weights and targets equal wherever no random draw is involved; pixels of the same
+    crops (cv2-exact resize vs the harness's PIL stand-in: close, not equal)."""
+    if not os.path.isfile(os.path.join(ROOT, 'oracle', '_ref', 'py3', 'main_train.py')):
+        pytest.skip('oracle/_ref/py3 not built (python -m oracle.build where the reference checkout exists)')
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'routed_batch_check.py'), '24', '8'], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert res['pool'] == 'sniper_amd.ext.pool.Pool' and res['thread_pool'] == 'sniper_amd.ext.pool.Pool', res
+    checked = 0
+    for b in res['batches']:
+        assert b['routed_maps'] == [1, 1], b                      # one anchor map, one image map per batch
+        assert all(b['routed_on_device']) and not any(b['unrouted_on_device']), b
+        assert b['gt_equal'] and b['valid_ranges_equal'] and b['im_info_equal'], b
+        assert b['pixels_corr'] > 0.98 and b['pixels_mean_abs_diff'] < 6.0, b
+        for c in b['chips']:
+            assert c['bg'][0] == 256 - c['fg'][0] or c['fg'][0] + c['bg'][0] <= 256, c
+            if c['fg_equal'] is not None:
+                assert c['fg_equal'] and c['weights_equal'] and c['targets_maxdiff'] <= 1e-5, c
+                checked += 1
+    assert checked >= 12
