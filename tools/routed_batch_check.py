@@ -91,7 +91,7 @@ def main():
         rec['pixels_mean_abs_diff'] = float(np.abs(dr - du).mean())
         rec['pixels_corr'] = float(np.corrcoef(dr.reshape(-1)[::97], du.reshape(-1)[::97])[0, 1])
         out['batches'].append(rec)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     os._exit(0)
 
 
