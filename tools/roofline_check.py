@@ -23,7 +23,9 @@ def main():
                 e = rows.setdefault(fam, [0, 0.0])
                 e[0] += int(r['Calls'])
                 e[1] += float(r['TotalDurationNs'])
-    line = [ln for ln in open(bench) if ln.startswith('{"metric"')][-1]
+    lines = list(open(bench))
+    full = [ln[len('BENCH_DETAIL '):] for ln in lines if ln.startswith('BENCH_DETAIL {')]        # the full record (the final line is compact)
+    line = full[-1] if full else [ln for ln in lines if ln.startswith('{"metric"')][-1]
     d = json.loads(line)
     gflop = d['roofline']['gflop_per_step']
     ms = tot_ns / steps / 1e6
