@@ -157,6 +157,11 @@ class Symbol(object):
         return self._heads[0][0].name if len(self._heads) == 1 else None
 
     def _topo(self):
+        # (a Symbol is immutable once built -- every operator call returns a new one -- so the order is computed once; an executor
+        # bind asks for it four times, and a test-time Module binds one executor per batch shape)
+        cached = self.__dict__.get('_topo_cache')
+        if cached is not None:
+            return list(cached)
         order, seen = [], set()
         stack = [(h[0], False) for h in reversed(self._heads)]
         while stack:
@@ -171,6 +176,7 @@ class Symbol(object):
             for inp, _ in reversed(node.inputs):
                 if id(inp) not in seen:
                     stack.append((inp, False))
+        self.__dict__['_topo_cache'] = tuple(order)
         return order
 
     def list_arguments(self):
