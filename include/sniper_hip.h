@@ -145,6 +145,11 @@ int sn_im_prepare(const uint8_t *d_src_bgr, int src_h, int src_w, int crop_x1, i
  * rois (B*R,5) f32 with rows of chip b contiguous, deltas (B,R,4) f32, im_info (B,3) f32 -> boxes (B,R,4) f64. */
 int sn_bbox_decode(const float *d_rois, const float *d_deltas, const float *d_im_info, double *d_boxes, int B, int R,
                    sn_stream_t stream);
+/* Bounding rectangles (x, y, w, h) of the contours cv2.findContours(mask, RETR_LIST) reports for a 0 / non-zero HOST mask, with
+ * cv2.boundingRect: mode 0 = border following (Suzuki & Abe 1985, OpenCV contours.cpp), in cv2's order (newest contour first) --
+ * what sn_focus_chips_host walks; mode 1 = 8-connected components + enclosed 4-connected background components grown by one cell,
+ * raster order (the independent cross-check: same rectangles).  rects_xywh (cap,4) i32. */
+int sn_focus_rects_host(const uint8_t *mask_hw, int H, int W, int mode, int32_t *rects_xywh, int cap, int32_t *n_rects);
 /* `gmask` of lib/chips/chips_inference.py:12-89 on the HOST (no device work, no stream): FocusPixel map (H,W) f32 -> FocusChips.
  * threshold (>= thresh), cv2.dilate d x d, bounding rectangles of the RETR_LIST contours (8-connected components + holes), minimum
  * side ms cells, paint-and-repeat until the chip count is stable, x16, clamp to (im_width, im_height), / cscale.

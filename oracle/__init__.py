@@ -15,6 +15,9 @@ Pinning status (see DESIGN.md section "Oracle"):
 * cv2.resize(uint8, INTER_LINEAR) (im_worker): ``oracle/cv_resize.py`` + ``sniper_oracle.c::orc_cv_resize_linear_u8c3``, two
   independent restatements of OpenCV's published fixed-point algorithm (OpenCV is a third-party dependency absent from
   the reference tree and from this image): pinned to the published algorithm, no cv2-minted vectors.
+* cv2.dilate / cv2.findContours(RETR_LIST) / cv2.boundingRect (gmask, FocusChip generation): ``oracle/cv_contours.py`` -- the
+  published algorithms (Suzuki & Abe border following), held against the product's border following AND its connected-component
+  form: pinned to the published algorithm, no cv2-minted vectors.
 * network ops whose source lives in the un-vendored SNIPER-mxnet submodule (Convolution,
   BatchNorm, MultiProposalTarget, DeformablePSROIPooling, ...): **parity unpinned** -- the
   restatements in ``oracle/nn.py`` follow the published definitions and are cross-checked

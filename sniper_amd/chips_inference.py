@@ -2,7 +2,10 @@
 
 The reference does this on the host with OpenCV (threshold -> cv2.dilate -> cv2.findContours(RETR_LIST) ->
 cv2.boundingRect, iterated until the chip count is stable); the maps are tiny (<= 125 x 88 cells).  OpenCV is not part
-of this image, so the three cv2 calls are restated with scipy.ndimage -- PARITY UNPINNED:
+of this image.  `gmask` runs sn_focus_chips_host (csrc/host_inference.cpp), which follows borders like OpenCV's contours.cpp
+(Suzuki & Abe 1985) and returns the chips in cv2's order (newest contour first); it is held -- rectangles and order -- against
+oracle/cv_contours.py, the restatement of the three cv2 calls from their published algorithms (tests/test_oracle_cv_contours.py).
+`gmask_reference` below is the SECOND route to the same rectangles, with scipy.ndimage (raster order of the components, holes last):
 
   * cv2.dilate(mask, ones(d, d)) : anchor at the kernel centre (d // 2, d // 2), borders ignored
         -> ndimage.maximum_filter(size=d, mode='constant', cval=0) (same window for odd and even d);
@@ -64,7 +67,7 @@ def _place(rect, ms, iw, ih):
 
 def gmask(mask, d, thresh_value=0.5, ms=16, im_width=0, im_height=0, cscale=1):
     """The FocusChips of one FocusPixel map: sn_focus_chips_host (csrc/host_inference.cpp), the native form of gmask_reference below
-    (same steps, same order of the chips; tests/test_focus_chips.py holds the two against each other).  250 us -> ~10 us per
+    (same chips; the native code reports them in cv2's order; tests/test_focus_chips.py holds the two against each other).  250 us -> ~10 us per
     map: FocusChip generation sits between two scales of a test pass, where nothing overlaps it."""
     from . import hip
     m = np.ascontiguousarray(mask, np.float32)

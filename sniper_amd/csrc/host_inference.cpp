@@ -65,6 +65,63 @@ void component_rects(const unsigned char *mp, int H, int W, unsigned char want, 
     }
 }
 
+// The same rectangles in the ORDER cv2.findContours(RETR_LIST) reports them (round 5): border following of Suzuki & Abe (CVGIP 30,
+// 1985, Algorithm 1; OpenCV's contours.cpp) on the framed map -- an outer border starts at a foreground cell whose left neighbour is
+// background, a hole border at a (not yet right-edge-marked) foreground cell whose right neighbour is background; borders are
+// followed with the 8-neighbourhood, cells marked NBD / -NBD; every border's bounding rectangle is recorded and the list is returned
+// newest first (OpenCV links each finished contour in front of the earlier ones).  f: int scratch of (H + 2) * (W + 2).
+// Restated and tested against the component form above and against oracle/cv_contours.py (rectangles AND order).
+void border_rects(const unsigned char *mp, int H, int W, int *f, CellRect *out, int cap, int *n) {
+  const int Wp = W + 2;
+  static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1}, DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};     // counter-clockwise on the screen from east
+  for (int y = 0; y < H + 2; ++y)
+    for (int x = 0; x < Wp; ++x) f[y * Wp + x] = (y >= 1 && y <= H && x >= 1 && x <= W && mp[y * Wp + x] == 255) ? 1 : 0;
+  *n = 0;
+  int nbd = 1;
+  for (int i = 1; i <= H; ++i)
+    for (int j = 1; j <= W; ++j) {
+      const int v = f[i * Wp + j];
+      if (v == 0) continue;
+      int k0;
+      if (v == 1 && f[i * Wp + j - 1] == 0) k0 = 4;             // outer border: start the clockwise search at the west neighbour
+      else if (v >= 1 && f[i * Wp + j + 1] == 0) k0 = 0;        // hole border: at the east neighbour
+      else continue;
+      ++nbd;
+      int x0 = j, x1 = j, y0 = i, y1 = i;
+      int i1 = -1, j1 = -1;
+      for (int s = 0; s < 8; ++s) {
+        const int k = (k0 - s + 8) & 7;
+        if (f[(i + DY[k]) * Wp + j + DX[k]] != 0) { i1 = i + DY[k]; j1 = j + DX[k]; break; }
+      }
+      if (i1 < 0) {
+        f[i * Wp + j] = -nbd;
+      } else {
+        int i2 = i1, j2 = j1, i3 = i, j3 = j;
+        for (;;) {
+          int k = 0;
+          for (; k < 8; ++k)
+            if (DY[k] == i2 - i3 && DX[k] == j2 - j3) break;
+          bool east_zero = false;
+          int i4 = i3, j4 = j3;
+          for (int s = 1; s <= 8; ++s) {
+            const int kk = (k + s) & 7;
+            if (f[(i3 + DY[kk]) * Wp + j3 + DX[kk]] != 0) { i4 = i3 + DY[kk]; j4 = j3 + DX[kk]; break; }
+            if (kk == 0) east_zero = true;
+          }
+          if (east_zero) f[i3 * Wp + j3] = -nbd;
+          else if (f[i3 * Wp + j3] == 1) f[i3 * Wp + j3] = nbd;
+          if (i4 == i && j4 == j && i3 == i1 && j3 == j1) break;
+          i2 = i3; j2 = j3; i3 = i4; j3 = j4;
+          x0 = j3 < x0 ? j3 : x0; x1 = j3 > x1 ? j3 : x1; y0 = i3 < y0 ? i3 : y0; y1 = i3 > y1 ? i3 : y1;
+        }
+      }
+      if (*n < cap) out[*n] = CellRect{x0 - 1, y0 - 1, x1 - x0 + 1, y1 - y0 + 1};
+      ++*n;
+    }
+  const int m = *n < cap ? *n : cap;
+  for (int a = 0, b = m - 1; a < b; ++a, --b) { const CellRect t = out[a]; out[a] = out[b]; out[b] = t; }      // newest first
+}
+
 CellRect place_rect(CellRect r, int ms, int iw, int ih) {
   const int cx = (r.x + r.x + r.w) / 2, cy = (r.y + r.y + r.h) / 2;
   const int w = r.w > ms ? r.w : ms, h = r.h > ms ? r.h : ms;
@@ -78,6 +135,34 @@ CellRect place_rect(CellRect r, int ms, int iw, int ih) {
   return CellRect{x, y, w, h};
 }
 }  // namespace
+
+// Bounding rectangles of the contours of a 0 / 255 mask, as cv2.findContours(RETR_LIST) + cv2.boundingRect give them.
+// mode 0: border following, cv2's order (what sn_focus_chips_host uses); mode 1: connected components + enclosed holes, raster order
+// of their first cells (the round 2-4 form; kept as the independent cross-check).  rects_xywh (cap, 4) int32.
+SN_EXPORT int sn_focus_rects_host(const uint8_t *mask_hw, int H, int W, int mode, int32_t *rects_xywh, int cap, int32_t *n_rects) {
+  SN_REQUIRE(mask_hw && rects_xywh && n_rects && H > 0 && W > 0 && H * W <= (1 << 20) && cap > 0, "sn_focus_rects_host: bad arguments");
+  const int Wp = W + 2;
+  const size_t cells = (size_t)(H + 2) * Wp;
+  std::vector<unsigned char> m(cells, 1), seen(cells);
+  std::vector<int> stack(cells * 2);
+  std::vector<CellRect> rects((size_t)cap);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) m[(y + 1) * Wp + x + 1] = mask_hw[y * W + x] ? 255 : 0;
+  int n = 0;
+  if (mode == 0) {
+    border_rects(m.data(), H, W, stack.data(), rects.data(), cap, &n);
+  } else {
+    component_rects(m.data(), H, W, 255, true, false, seen.data(), stack.data(), rects.data(), cap, &n, 0, H - 1, 0, W - 1);
+    if (n > 0 && n <= cap)
+      component_rects(m.data(), H, W, 0, false, true, seen.data(), stack.data(), rects.data(), cap, &n, 0, H - 1, 0, W - 1);
+  }
+  SN_REQUIRE(n <= cap, "sn_focus_rects_host: more contours than the caller's capacity");
+  for (int k = 0; k < n; ++k) {
+    rects_xywh[4 * k] = rects[k].x; rects_xywh[4 * k + 1] = rects[k].y; rects_xywh[4 * k + 2] = rects[k].w; rects_xywh[4 * k + 3] = rects[k].h;
+  }
+  *n_rects = n;
+  return SN_OK;
+}
 
 SN_EXPORT int sn_focus_chips_host(const float *map_hw, int H, int W, int d, float thresh, int ms, double im_width, double im_height,
                                   double cscale, double *chips_xyxy, int max_chips, int32_t *n_chips) {
@@ -112,19 +197,9 @@ SN_EXPORT int sn_focus_chips_host(const float *map_hw, int H, int W, int d, floa
       for (int y = (yy - hi < 0 ? 0 : yy - hi); y <= yy + lo && y < H; ++y)
         for (int x = (xx - hi < 0 ? 0 : xx - hi); x <= xx + lo && x < W; ++x) m[(y + 1) * Wp + x + 1] = 255;
     }
-  auto all_rects = [&](int *n) {
-    *n = 0;
-    component_rects(m, H, W, 255, true, false, seen, stack, rects, cap, n, 0, H - 1, 0, W - 1);   // 8-connected components
-    if (*n == 0 || *n > cap) return;
-    // holes lie inside the foreground's bounding box: label the background of that box and a one-cell ring around it only
-    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
-    for (int k = 0; k < *n; ++k) {
-      bx0 = rects[k].x < bx0 ? rects[k].x : bx0; bx1 = rects[k].x + rects[k].w - 1 > bx1 ? rects[k].x + rects[k].w - 1 : bx1;
-      by0 = rects[k].y < by0 ? rects[k].y : by0; by1 = rects[k].y + rects[k].h - 1 > by1 ? rects[k].y + rects[k].h - 1 : by1;
-    }
-    component_rects(m, H, W, 0, false, true, seen, stack, rects, cap, n, by0 > 0 ? by0 - 1 : 0, by1 < H - 1 ? by1 + 1 : H - 1,
-                    bx0 > 0 ? bx0 - 1 : 0, bx1 < W - 1 ? bx1 + 1 : W - 1);
-  };
+  // cv2's own procedure and order: border following (border_rects); sn_focus_rects_host(mode 1) keeps the component form of rounds
+  // 2 - 4 reachable as the cross-check (same rectangles, raster order)
+  auto all_rects = [&](int *n) { border_rects(m, H, W, stack, rects, cap, n); };
   int nr = 0, nchips = -1, nc = 0;
   all_rects(&nr);
   bool overflow = nr > cap;

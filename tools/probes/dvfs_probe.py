@@ -13,4 +13,4 @@ for iters in (10, 100, 1000, 5000, 20000):
     for _ in range(iters): run()
     e1.record(); torch.cuda.synchronize()
     print('iters %6d  %.2f us/launch' % (iters, e0.elapsed_time(e1) / iters * 1e3), flush=True)
-os.system('rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk" | head -4')
+os.system('rocm-smi --showclocks 2>/dev/null | grep -i -E "sclk|mclk" | head -4')
