@@ -732,7 +732,9 @@ class Executor(object):
                     src = src.asnumpy()
                 if isinstance(src, np.ndarray):
                     src = torch.from_numpy(np.ascontiguousarray(src, np.float32))
-                    if self.device.type == 'cuda':
+                    if self.device.type == 'cuda' and (self.for_training or src.numel() <= (1 << 18)):
+                        # (training executors and small arrays only: a test-time Module holds one executor per batch shape, and
+                        # three pinned copies of a 69 MB host image batch per shape would pin gigabytes of host memory)
                         # host inputs (the reference iterator's small arrays -- valid ranges, im_info -- or whole host batches) go
                         # through a ring of pinned buffers: a copy from PAGEABLE memory is synchronous, i.e. the host would wait
                         # for the step in flight before it could enqueue this one (13 ms per batch, profiles/r05_fit_path.txt)

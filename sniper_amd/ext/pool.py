@@ -106,6 +106,11 @@ def route(func):
 # worker returns).  Sub-sampling of the 256 RPN labels: the reference draws with numpy's global RNG per chip; the batched launch
 # draws with the kernel's hash of (seed, chip, anchor) -- same rule, different draws (replaying numpy's needs the labels on the
 # host first: AnchorAssigner.numpy_replay_keys, used by the parity tests).  SNIPER_POOL_ROUTE_BATCH=0: per item on threads.
+class _NotRouted(Exception):
+    """raised by a batched form that finds it cannot take this map after all (mask polygons, no GPU): the pool runs the work items
+    on its threads as it would have without the routing"""
+
+
 class _Dense(object):
     """dense device tensor a sparse reference value stands for: writes itself into a destination row"""
     _device_resident = True
@@ -185,8 +190,8 @@ def _anchor_batch(owner, items, func):
     import torch
     from .. import mx
     items = list(items)
-    if not items or not torch.cuda.is_available() or any(len(d) > 8 for d in items):      # mask polygons: per item on the CPU
-        return [func(d) for d in items]
+    if not items or not torch.cuda.is_available() or any(len(d) > 8 for d in items):      # mask polygons: per item, on the pool's threads
+        raise _NotRouted()
     aa = getattr(owner, '_sniper_anchor_mirror', None)
     if aa is None:
         from ..config import AttrDict
@@ -223,7 +228,7 @@ def _image_batch(owner, items, func):
     from .. import mx
     items = list(items)
     if not items or not torch.cuda.is_available():
-        return [func(d) for d in items]
+        raise _NotRouted()
     iw = getattr(owner, '_sniper_im_mirror', None)
     if iw is None:
         from ..data.im_worker import im_worker as mirror_cls
@@ -260,29 +265,38 @@ class Pool(multiprocessing.pool.ThreadPool):
         super(Pool, self).__init__(processes, init, initargs)
         self.routed_maps = 0          # maps that ran as batched GPU work instead of per-item (tests, reports)
 
-    def map(self, func, iterable, chunksize=None):
+    def _routed(self, func, iterable):
+        """-> (True, results) when the map ran as batched GPU work, (False, the work items) otherwise"""
         batched = route(func)
-        if batched is not None:
-            self.routed_maps += 1
-            return list(batched(list(iterable)))
-        return super(Pool, self).map(func, iterable, chunksize)
+        if batched is None:
+            return False, iterable
+        items = list(iterable)
+        try:
+            out = list(batched(items))
+        except _NotRouted:
+            return False, items
+        self.routed_maps += 1
+        return True, out
+
+    def map(self, func, iterable, chunksize=None):
+        done, out = self._routed(func, iterable)
+        if done:
+            return out
+        return super(Pool, self).map(func, out, chunksize)
 
     def map_async(self, func, iterable, chunksize=None, callback=None, error_callback=None):
-        batched = route(func)
-        if batched is not None:
-            self.routed_maps += 1
-            out = list(batched(list(iterable)))
+        done, out = self._routed(func, iterable)
+        if done:
             if callback is not None:
                 callback(out)
             return _Done(out)
-        return super(Pool, self).map_async(func, iterable, chunksize, callback, error_callback)
+        return super(Pool, self).map_async(func, out, chunksize, callback, error_callback)
 
     def imap(self, func, iterable, chunksize=1):
-        batched = route(func)
-        if batched is not None:
-            self.routed_maps += 1
-            return iter(list(batched(list(iterable))))
-        return super(Pool, self).imap(func, iterable, chunksize)
+        done, out = self._routed(func, iterable)
+        if done:
+            return iter(out)
+        return super(Pool, self).imap(func, out, chunksize)
 
 
 def _patch_module(module, base):
