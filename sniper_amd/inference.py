@@ -723,6 +723,21 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None,
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
+def _rows_to_host(dets, num_classes):
+    """The rows of every chip that so far live in HBM only (`device_parts`) -> the host lists and the `compact` form Tester.get_detections
+    fills when it copies rows per batch; the device buffers are released.  (The overflow path of the device aggregation's budget.)"""
+    nc = num_classes - 1
+    for (i, c), (rows, counts) in list(getattr(dets, 'device_parts', {}).items()):
+        lens = counts.cpu().numpy().astype(np.int64)
+        big = rows[:int(lens.sum())].cpu().numpy()
+        ends, start = np.cumsum(lens).tolist(), 0
+        for j in range(nc):
+            dets[j + 1][i][c] = big[start:ends[j]]
+            start = ends[j]
+        dets.compact[(i, c)] = (big, lens)
+    dets.device_parts = {}
+
+
 def shard_images(n_images, rank, world):
     """Images of rank `rank`: every world-th image (shard images across ranks).  Interleaved, not contiguous: a roidb is
     sorted by nothing in particular, but its tail may hold the large images."""
@@ -834,7 +849,22 @@ def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, a
     if os.environ.get('SNIPER_IMAGE_CACHE', '1') != '0' and torch.cuda.is_available():
         from .data.im_worker import DeviceImageCache
         image_cache = DeviceImageCache()
+    # rows kept in HBM for the device aggregation are CAPACITY buffers ((classes - 1) x RoIs x 40 B per chip: ~1 MB), whatever
+    # survives the threshold: a pass over a few hundred images holds a few GB, a 5000-image roidb at the finest scale would ask
+    # for more than the card has.  Budget (SNIPER_DEVICE_AGG_GB, default 24): the scale that would exceed it -- and every later
+    # one -- brings its rows to the host per batch as rounds 2-4 did, the earlier scales' rows are brought over once
+    # (_rows_to_host), and Tester.aggregate runs its host statement.
+    dev_budget = float(os.environ.get('SNIPER_DEVICE_AGG_GB', '24')) * (1 << 30)
+    dev_used = 0.0
     for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
+        if rows[0]:
+            per_chip = (imdb.num_classes - 1) * int(getattr(config.TEST, 'RPN_POST_NMS_TOP_N', 300)) * 40.0
+            dev_used += sum(len(r['inference_crops']) for r in roidb) * per_chip
+            if dev_used > dev_budget:
+                for d in detections:
+                    _rows_to_host(d, imdb.num_classes)
+                rows = (False, True)
+
         def job(j):
             was, _SLOT.job = getattr(_SLOT, 'job', 0), j
             try:

@@ -237,6 +237,20 @@ def test_lanes_and_device_compaction_equal_the_host_loops():
         for j in range(1, 81):
             for wi, gi in zip(want_final[j], got_final[j]):
                 assert np.array_equal(wi, gi)
+    # the device aggregation's HBM budget: the second scale would exceed it -> its rows come to the host per batch, the first
+    # scale's rows are brought over once (_rows_to_host), the host statement aggregates: same final boxes
+    import os
+    os.environ['SNIPER_DEVICE_AGG_GB'] = '0.003'           # 3.2 MB: the 6 chips of scale 1 (80 classes x 100 RoIs x 40 B each = 1.9 MB) fit, the 9 - 12 of scale 2 do not
+    try:
+        over_final = inference.imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, _Imdb(81), [dict(r) for r in base], [mx.gpu(0)], None, None,
+                                                      module_cache=cache, focus_map_fn=fmap, lanes=3)
+    finally:
+        del os.environ['SNIPER_DEVICE_AGG_GB']
+    plain_final = inference.imdb_detection_wrapper(rn.resnet_mx_101_e2e, cfg, _Imdb(81), [dict(r) for r in base], [mx.gpu(0)], None, None,
+                                                   module_cache=cache, focus_map_fn=fmap, lanes=3)
+    for j in range(1, 81):
+        for wi, oi, pi in zip(want_final[j], over_final[j], plain_final[j]):
+            assert np.array_equal(wi, oi) and np.array_equal(wi, pi)
 
 
 def test_device_aggregation_equals_the_host_statement():
