@@ -723,6 +723,23 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None,
                                  do_pruning=config.TEST.DO_PRUNING[scale_i], autofocus=config.TEST.AUTO_FOCUS)
 
 
+def default_lanes():
+    """Batches of a scale in flight at once when the caller does not say (SNIPER_LANES overrides).  A lane is a bound Module of its
+    own -- up to ~12 GB at the finest test scale (activation pool + parameters) -- and three of them are what the throughput numbers
+    are quoted on (bench.py, README): the default is 3 on a card with room for them (>= 96 GB free), else 1 (two batches in flight on
+    the one stream).  ADVICE r4: the shipped default used to be 1 while the benchmark asked for 3."""
+    env = os.environ.get('SNIPER_LANES')
+    if env:
+        return max(1, int(env))
+    try:
+        if torch.cuda.is_available():
+            free, _ = torch.cuda.mem_get_info()
+            return 3 if free >= 96 * (1 << 30) else 1
+    except Exception:      # noqa: BLE001 -- no figure: the conservative default
+        pass
+    return 1
+
+
 def _rows_to_host(dets, num_classes):
     """The rows of every chip that so far live in HBM only (`device_parts`) -> the host lists and the `compact` form Tester.get_detections
     fills when it copies rows per batch; the device buffers are released.  (The overflow path of the device aggregation's budget.)"""
@@ -764,7 +781,7 @@ def merge_rank_detections(gathered, n_images, num_classes, world):
 
 
 def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, aux_params, vis=False, module_cache=None,
-                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=1, rank=None, world=None,
+                           focus_map_fn=None, return_scale_dets=False, concurrent_jobs=1, lanes=None, rank=None, world=None,
                            group=None, device_aggregate=None):
     """Multi-scale inference + aggregation (lib/inference.py:439-529), see `_multi_scale_detections`.
     rank / world (default: the initialised torch.distributed group, else one process): rank r runs images r, r + world, ... through
@@ -774,6 +791,8 @@ def imdb_detection_wrapper(sym_def, config, imdb, roidb, context, arg_params, au
     device_aggregate (default: on, SNIPER_DEVICE_AGGREGATE=0 turns it off): the thresholded / pruned rows of every chip stay in HBM
     and the valid-range regrouping, the soft-NMS and the MAX_PER_IMAGE rule run on them there (Tester.aggregate_device); the
     rows come to the host per batch only when the per-scale detection lists are asked for (return_scale_dets, vis)."""
+    if lanes is None:
+        lanes = default_lanes()
     if device_aggregate is None:
         device_aggregate = os.environ.get('SNIPER_DEVICE_AGGREGATE', '1') != '0'
     device_aggregate = bool(device_aggregate) and torch.cuda.is_available() and Tester.device_compact and config.TEST.NMS <= 0
@@ -825,8 +844,8 @@ def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, a
     CUs idle; two streams fill them).  Results are merged in part order, as the reference does (:494-500).
     lanes: batches of one scale in flight at once, each on its own bound Module and HIP stream, driven by ONE host thread
     (detect_scale_worker / Tester.get_detections) -- the form of concurrency that measured faster here than threads.  Every
-    lane is a full bound Module (its own activations at every scale, 1400 x 2000 included), so the default is 1; a throughput
-    run on a 288 GB card asks for 3 (bench.py, tools/infer_profile.py).
+    lane is a full bound Module (its own activations at every scale, 1400 x 2000 included); default (None): `default_lanes()` -- 3 on a
+    card with >= 96 GB free (what bench.py and the README quote), else 1.
     focus_map_fn(scale_i, image, chip, net_map) -> map (benchmarks only): replaces the network's FocusPixel map before the
     FocusChips are cut -- a random-init network's maps select whole images, a trained one's ~10 % of the pixels in blobs
     (SURVEY 8(d)); return_scale_dets: also hand back the per-scale detections (what the CPU baseline of the aggregation reads)."""

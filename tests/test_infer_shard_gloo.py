@@ -123,3 +123,21 @@ def test_shard_images_is_a_partition():
             parts = [shard_images(n, r, world) for r in range(world)]
             assert sorted(i for p in parts for i in p) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_default_lanes(monkeypatch):
+    """SNIPER_LANES wins; without it the choice follows free HBM (3 lanes with >= 96 GiB free, else 1); no GPU -> 1."""
+    import torch
+    from sniper_amd import inference
+    monkeypatch.setenv('SNIPER_LANES', '2')
+    assert inference.default_lanes() == 2
+    monkeypatch.setenv('SNIPER_LANES', '0')
+    assert inference.default_lanes() == 1
+    monkeypatch.delenv('SNIPER_LANES')
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    assert inference.default_lanes() == 1
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda *a: (200 << 30, 288 << 30))
+    assert inference.default_lanes() == 3
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda *a: (40 << 30, 288 << 30))
+    assert inference.default_lanes() == 1
