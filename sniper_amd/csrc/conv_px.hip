@@ -25,6 +25,7 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef unsigned int px_u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void px_dma16(__amdgpu_buffer_rsrc_t rsrc, half_t *dst, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
@@ -46,15 +47,17 @@ constexpr int kPxChunk = 128;     // output channels per chunk (4 channel groups
 constexpr int kPxMaxChunks = 4;   // chunks per workgroup: up to 512 output channels
 
 // KC = Cin / 64.  LDS: two weight stages of KC x [128 rows][64 channels] fp16 (KC x 16 KB each) + the statistics exchange.
-template <int KC, bool BNX>
+template <int KC, bool BNX, bool STAG>
 __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int mtiles, int ntiles, int nchunks) {
   constexpr int BK = 64, MI = kPxBM / 2 / 16, KS = 2 * KC;
   constexpr int BLK = kPxChunk * BK;              // half_t elements of one 64-channel block of a stage
   constexpr int STAGE = KC * BLK;
   constexpr int PIECES = KC * 16 / 8;             // 1 KB DMA pieces per wave per stage
   constexpr int RED = kPxMaxChunks * 2 * 2 * kPxChunk;   // floats: [chunk][pixel half][sum | second moment][channel]
-  __shared__ __attribute__((aligned(1024))) half_t lds[2 * STAGE + RED * 2];
+  constexpr int CST = BNX ? 3 * kPxMaxChunks * kPxChunk : 0;   // floats: BatchNorm scale | shift | mean of this workgroup's channels
+  __shared__ __attribute__((aligned(1024))) half_t lds[2 * STAGE + (RED + CST) * 2];
   float *const red = reinterpret_cast<float *>(lds + 2 * STAGE);
+  float *const cst = red + RED;
 
   const int lin = blockIdx.x;
   const int xcd = lin & 7, j = lin >> 3;
@@ -67,8 +70,13 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   const int m0 = mt * kPxBM, n0 = nt * nchunks * kPxChunk;
 
   // ---- weight stage `c` -> buffer: wave w moves the 8-row groups w, w + 8, ... of the KC x 16 groups (block kb = g / 16, rows 8 (g % 16) ..)
+  // LDS row r of a block holds channel nc + perm(r), perm(r) = (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3) (conv_dma.hip: a
+  // lane's two accumulators of a fragment pair are then 8 consecutive channels).  With r = 8 rg + lrow the lane's share of the source
+  // address, 8 (lrow >> 2) + (lrow & 3) rows and its 16-byte chunk, is ONE register for the whole kernel; the group's share goes
+  // in the instruction's scalar offset.
   const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;
   const unsigned wrow_bytes = (unsigned)p.Cin * 2u;
+  const unsigned w_lane = (unsigned)(8 * (lrow >> 2) + (lrow & 3)) * wrow_bytes + (unsigned)gchunk * 16u;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
   auto issue = [&](int c, int buf) {
     half_t *const sb = lds + buf * STAGE;
@@ -76,23 +84,44 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int g = wave + 8 * i, kb = g >> 4, rg = g & 15;
-      // LDS row r holds channel nc + perm(r) (conv_dma.hip: a lane's two accumulators of a fragment pair are 8 consecutive channels)
-      const int r = 8 * rg + lrow;
-      const int n = nc + (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
-      px_dma16(rw, sb + kb * BLK + rg * 512, (unsigned)n * wrow_bytes + (unsigned)kb * 128u + (unsigned)gchunk * 16u);
+      const int nu = nc + 32 * (rg >> 2) + 16 * (rg & 1) + 4 * ((rg >> 1) & 1);       // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sb + kb * BLK + rg * 512), 16, w_lane,
+                                               (int)((unsigned)nu * wrow_bytes + (unsigned)kb * 128u), 0, 0);
     }
   };
   issue(0, 0);
+  if constexpr (BNX) {
+    // the per-channel constants of the fused BatchNorm-backward reduction, once per workgroup: read back from LDS in every chunk's
+    // epilogue, where a global load would have to wait behind the chunk's stores (no alias information) -- ten exposed round trips
+    for (int idx = tid; idx < nchunks * kPxChunk; idx += 512) {
+      cst[idx] = p.bn_scale[n0 + idx];
+      cst[kPxMaxChunks * kPxChunk + idx] = p.bn_shift[n0 + idx];
+      cst[2 * kPxMaxChunks * kPxChunk + idx] = p.bn_mean[n0 + idx];
+    }
+  }
 
   // ---- this wave's pixels, the whole contraction: fa[i][ks] = pixel m0 + 80 wm + 16 i + fr, channels 32 ks + 8 fq .. + 7
+  // Tensors are addressed through buffer descriptors: ONE 32-bit lane offset per tensor + a wave-uniform scalar offset per row
+  // fragment (the stationary pixels leave no registers for 64-bit addresses per fragment), and rows beyond M read zeros / are not
+  // written by the descriptor's bound (conv_px_ok keeps every tensor under 2 GB).
+  const unsigned kFlags = 0x00020000;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(p.x), 0, (int)p.x_bytes, kFlags);
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(((unsigned)(p.M - 1) * (unsigned)p.out_ps + (unsigned)p.Nout) * 2u), kFlags);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t *>(p.res), 0, p.res ? (int)(((unsigned)(p.M - 1) * (unsigned)p.res_ps + (unsigned)p.Nout) * 2u) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t *>(p.bn_x), 0, BNX ? (int)(((unsigned)(p.M - 1) * (unsigned)p.bn_x_ps + (unsigned)p.Nout) * 2u) : 0, kFlags);
+  const int mrow = m0 + wm * (kPxBM / 2) + fr;        // this lane's pixel of row fragment 0 (fragment i: + 16 i)
+
   half8 fa[MI][KS];
+  {
+    const unsigned a_off = ((unsigned)mrow * (unsigned)p.in_ps + (unsigned)fq * 8u) * 2u;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    // rows beyond M read row 0: their accumulators are never stored and never enter the statistics
-    const int mr = m0 + wm * (kPxBM / 2) + i * 16 + fr;
-    const half_t *src = p.x + (size_t)(mr < p.M ? mr : 0) * p.in_ps + fq * 8;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) fa[i][ks] = *reinterpret_cast<const half8 *>(src + ks * 32);
+      for (int ks = 0; ks < KS; ++ks)
+        fa[i][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rx, a_off + ks * 64, i * 16 * p.in_ps * 2, 0));
   }
   // The compiler must see these loads RETIRE here: its scoreboard does not read an inline-asm s_waitcnt, and a load it still
   // believes pending makes it drain the LDS-DMA queue (vmcnt(0)) in front of the first MFMA of EVERY chunk
@@ -101,30 +130,59 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa[i][ks]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (and this wave's pieces of weight stage 0)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (and this wave's pieces of weight stage 0, its constants in LDS)
   __builtin_amdgcn_s_barrier();
 
   const int sw = fq ^ (fr & 7);
   const int b_rd = (wn * 32 + fr) * BK;
   const bool has_stats = p.stats != nullptr;
+  const int a_none = p.bn_act == 0, a_relu = p.bn_act == 1, a_relu6 = p.bn_act == 2;
 
-  for (int c = 0; c < nchunks; ++c) {
-    // buffer (c + 1) & 1 was read by chunk c - 1, which every wave finished before the barrier that closed it
-    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
-    floatx4 acc[MI][2];
+  floatx4 acc[MI][2];
+  // The BatchNorm input the fused backward reduction reads (bn_x: HBM, 16 bytes per lane, row fragment and chunk) is needed AFTER the
+  // chunk's stores, where a load cannot be hoisted (no alias information) and five exposed HBM round trips per chunk would be the
+  // whole kernel.  Holding it in registers across the MFMAs (20 VGPRs) does not fit beside the stationary pixels -- hipcc spills
+  // pixel fragments and reloads them inside the MFMA stream, each reload a vmcnt(0) that also drains the weight DMA.  So the lines
+  // are only TOUCHED before the MFMAs (one dword per lane and row fragment: the whole 64-byte segment arrives in this XCD's L2) and
+  // read for real in the epilogue, from L2.
+  unsigned touch[BNX ? MI : 1];
+  auto prefetch = [&](int c) {
+    if constexpr (BNX) {
+      const int n = n0 + c * kPxChunk + wn * 32 + fq * 8;
+      const unsigned x_off = ((unsigned)mrow * (unsigned)p.bn_x_ps + (unsigned)n) * 2u;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) touch[i] = __builtin_amdgcn_raw_buffer_load_b32(rbx, x_off, i * 16 * p.bn_x_ps * 2, 0);
+    }
+  };
+  // (the touches retire where the hand-written vmcnt(0) already stands; the empty asm keeps them from being dropped as dead)
+  auto retire_prefetch = [&]() {
+    if constexpr (BNX) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(touch[i]));
+    }
+  };
+  auto compute = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[i][0] = acc[i][1] = floatx4{0.f, 0.f, 0.f, 0.f};
     const half_t *const sb = lds + (c & 1) * STAGE;
-    // weight fragments one K-step ahead, and no further: left alone hipcc hoists all 2 KS reads (64 VGPRs) above the first MFMA and
-    // spills the stationary pixels to make room
+    // The fragment reads run ONE K-step ahead where the registers allow it (not beside the 160 pixel registers of Cin = 256 in the
+    // BatchNorm-backward variant: there the SIMD's other wave covers the LDS latency), and never further: left alone hipcc hoists all
+    // 2 KS reads (64 VGPRs) above the first MFMA and spills the stationary pixels to make room.
+    constexpr bool kAhead = !(BNX && KC == 4);
     auto rd = [&](int ks, int half) {
       return *reinterpret_cast<const half8 *>(sb + (ks >> 1) * BLK + b_rd + half * 16 * BK + (sw ^ ((ks & 1) * 4)) * 8);
     };
-    half8 nb0 = rd(0, 0), nb1 = rd(0, 1);
+    half8 nb0, nb1;
+    if constexpr (kAhead) { nb0 = rd(0, 0); nb1 = rd(0, 1); }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const half8 fb0 = nb0, fb1 = nb1;
-      if (ks + 1 < KS) { nb0 = rd(ks + 1, 0); nb1 = rd(ks + 1, 1); }
+      half8 fb0, fb1;
+      if constexpr (kAhead) {
+        fb0 = nb0; fb1 = nb1;
+        if (ks + 1 < KS) { nb0 = rd(ks + 1, 0); nb1 = rd(ks + 1, 1); }
+      } else {
+        fb0 = rd(ks, 0); fb1 = rd(ks, 1);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0, fa[i][ks], acc[i][0], 0, 0, 0);
@@ -132,89 +190,146 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the next stage (issued a chunk's MFMAs ago) and the stores of the previous chunk: landed / drained before this chunk's stores go out
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- epilogue of the chunk: lane (fr, fq) holds pixel .. + fr, channels n .. n + 7 (conv_dma.hip, the 16-byte path).  Addresses are
-    // a wave-uniform 64-bit base + one 32-bit lane offset per tensor (conv_px_ok bounds the tensors to 2 GB): the pixel operand
-    // leaves no room for a 64-bit pointer per row fragment
+  };
+  auto epilogue = [&](int c) {
+    // ---- epilogue of the chunk: lane (fr, fq) holds pixel mrow + 16 i, channels n .. n + 7 (conv_dma.hip, the 16-byte path)
     const int n = n0 + c * kPxChunk + wn * 32 + fq * 8;
-    const int mrow = m0 + wm * (kPxBM / 2) + fr;
     const unsigned y_off = ((unsigned)mrow * (unsigned)p.out_ps + (unsigned)n) * 2u;
     const unsigned r_off = ((unsigned)mrow * (unsigned)p.res_ps + (unsigned)n) * 2u;
-    const unsigned x_off = ((unsigned)mrow * (unsigned)p.bn_x_ps + (unsigned)n) * 2u;
-    float st_s[8], st_q[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) st_s[r] = st_q[r] = 0.f;
+    // pass 1: convert and store (the 40 accumulator registers become 20 of fp16 output); pass 2: statistics of the STORED values.
+    // In one pass the accumulators, the prefetched BatchNorm input, the constants and the sums are all live at once: ~270 VGPRs,
+    // and what hipcc then spills is the stationary pixel operand, reloaded in the middle of the MFMA stream.
+    half8 o[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      if (mrow + i * 16 >= p.M) continue;
+      __builtin_amdgcn_sched_barrier(0);
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[i][0][r]; v[4 + r] = acc[i][1][r]; }
-      if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (p.res) {
-        const half8 rv = *reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(p.res) + (size_t)(i * 16) * p.res_ps * 2 + r_off);
+      if (mrow + i * 16 < p.M) {
+        if (p.bias) {
+          const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.res) {
+          const half8 rv = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rres, r_off, i * 16 * p.res_ps * 2, 0));
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-      }
-      if (p.relu) {
+          for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+        }
+        if (p.relu) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-      }
-      half8 o;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
-      *reinterpret_cast<half8 *>(reinterpret_cast<char *>(p.y) + (size_t)(i * 16) * p.out_ps * 2 + y_off) = o;
-      if (has_stats) {
-        if constexpr (BNX) {
-          const half8 xv = *reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(p.bn_x) + (size_t)(i * 16) * p.bn_x_ps * 2 + x_off);
-          // the per-channel constants four channels at a time (L1 hits): twelve registers instead of twenty-four held across the chunk
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + n + 4 * h), sh = *reinterpret_cast<const float4 *>(p.bn_shift + n + 4 * h);
-            const float4 mu = *reinterpret_cast<const float4 *>(p.bn_mean + n + 4 * h);
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float xf = (float)xv[4 * h + r], yv = xf * scv[r] + shv[r];
-              const bool pass = p.bn_act == 0 || (p.bn_act == 1 ? yv > 0.f : (yv >= 0.f && yv <= 6.f));
-              const float gf = pass ? (float)o[4 * h + r] : 0.f;
-              st_s[4 * h + r] += gf;
-              st_q[4 * h + r] += gf * (xf - muv[r]);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float f = (float)o[r];
-            st_s[r] += f;
-            st_q[r] += f * f;
-          }
+          for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[i][r] = (half_t)v[r];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(px_u4, o[i]), ry, y_off, i * 16 * p.out_ps * 2, 0);      // (rows >= M: out of bounds)
+    }
+    // pass 2, four channels at a time (twelve constant registers and eight sums live, not twenty-four and sixteen)
+    half8 xv[BNX ? MI : 1];
+    if constexpr (BNX) {
+      const unsigned x_off = ((unsigned)mrow * (unsigned)p.bn_x_ps + (unsigned)n) * 2u;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xv[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rbx, x_off, i * 16 * p.bn_x_ps * 2, 0));
     }
     if (has_stats) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        st_s[r] = px_row16_sum(st_s[r]);
-        st_q[r] = px_row16_sum(st_q[r]);
-      }
-      if (fr == 0) {
-        float *const rr = red + ((c * 2 + wm) * 2) * kPxChunk + wn * 32 + fq * 8;
+      for (int h = 0; h < 2; ++h) {
+        __builtin_amdgcn_sched_barrier(0);      // (one half's constants and conversions must not be hoisted into the other's)
+        float st_s[4], st_q[4];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          rr[r] = st_s[r];
-          rr[kPxChunk + r] = st_q[r];
+        for (int r = 0; r < 4; ++r) st_s[r] = st_q[r] = 0.f;
+        float scv[BNX ? 4 : 1], shv[BNX ? 4 : 1], muv[BNX ? 4 : 1];
+        if constexpr (BNX) {
+          const float *const cc = cst + (n - n0) + 4 * h;      // the per-channel constants from LDS (filled once per workgroup)
+          const float4 sc = *reinterpret_cast<const float4 *>(cc), sh = *reinterpret_cast<const float4 *>(cc + kPxMaxChunks * kPxChunk);
+          const float4 mu = *reinterpret_cast<const float4 *>(cc + 2 * kPxMaxChunks * kPxChunk);
+          scv[0] = sc.x; scv[1] = sc.y; scv[2] = sc.z; scv[3] = sc.w;
+          shv[0] = sh.x; shv[1] = sh.y; shv[2] = sh.z; shv[3] = sh.w;
+          muv[0] = mu.x; muv[1] = mu.y; muv[2] = mu.z; muv[3] = mu.w;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (mrow + i * 16 >= p.M) continue;
+          if constexpr (BNX) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float xf = (float)xv[i][4 * h + r], yv = xf * scv[r] + shv[r];
+              // bn_act_pass (nn_ops.hip: 0 none, 1 ReLU y > 0, 2 ReLU6 0 <= y <= 6) as mask arithmetic: with || and && hipcc builds a
+              // divergent exec-mask ladder per element (25 instructions)
+              const int pass = a_none | (a_relu & (int)(yv > 0.f)) | (a_relu6 & (int)(yv >= 0.f) & (int)(yv <= 6.f));
+              const float gf = pass ? (float)o[i][4 * h + r] : 0.f;
+              st_s[r] += gf;
+              st_q[r] += gf * (xf - muv[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float f = (float)o[i][4 * h + r];
+              st_s[r] += f;
+              st_q[r] += f * f;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st_s[r] = px_row16_sum(st_s[r]);
+          st_q[r] = px_row16_sum(st_q[r]);
+        }
+        if (fr == 0) {
+          float *const rr = red + ((c * 2 + wm) * 2) * kPxChunk + wn * 32 + fq * 8 + 4 * h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rr[r] = st_s[r];
+            rr[kPxChunk + r] = st_q[r];
+          }
         }
       }
     }
-    // every wave's pieces of the next stage have landed (its vmcnt(0) above), and every wave is done reading this chunk's buffer
+  };
+
+  // One barrier-delimited interval per chunk.  Plain: every wave multiplies chunk t, then stores it -- the two waves of a SIMD are in the
+  // same phase, the matrix pipe idles through both epilogues.  Staggered (STAG): the second pixel half (waves 4 .. 7, the SIMDs' second
+  // waves) stores chunk t - 1 FIRST and multiplies chunk t afterwards, so one wave's conversions, statistics and stores run under the
+  // other wave's MFMAs; one more interval at the end for its last epilogue.  Same buffers, same barriers, same sums.
+  auto landed = [&]() {
+    // this wave's pieces of the next stage (issued a chunk's MFMAs ago) have landed, and its earlier stores have drained
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    retire_prefetch();
+  };
+  auto close_interval = [&]() {
+    // every wave's pieces of the next stage have landed (its vmcnt(0)), and every wave is done reading this interval's buffer
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  };
+  // (buffer (t + 1) & 1 was read by chunk t - 1, which every wave finished before the barrier that closed interval t - 1)
+  if (!STAG || wm == 0) {
+    for (int t = 0; t < nchunks; ++t) {
+      if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
+      prefetch(t);
+      compute(t);
+      landed();
+      epilogue(t);
+      close_interval();
+    }
+    if constexpr (STAG) __builtin_amdgcn_s_barrier();      // the other half's last interval
+  } else {
+    if (1 < nchunks) issue(1, 1);
+    prefetch(0);
+    compute(0);
+    landed();
+    close_interval();
+    for (int t = 1; t < nchunks; ++t) {
+      if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
+      epilogue(t - 1);
+      __builtin_amdgcn_sched_barrier(0);      // (the next chunk's prefetch must not start while the previous one's registers are live)
+      prefetch(t);
+      compute(t);
+      landed();
+      close_interval();
+    }
+    epilogue(nchunks - 1);
+    close_interval();
   }
 
   if (has_stats) {
@@ -245,7 +360,7 @@ bool conv_px_ok(const ConvParams &p) {
   return true;
 }
 
-int conv_px_launch(const ConvParams &p, hipStream_t s) {
+int conv_px_launch(const ConvParams &p, bool stag, hipStream_t s) {
   const int mtiles = sn_div_up(p.M, kPxBM);
   const int nchunks = p.Nout > kPxMaxChunks * kPxChunk ? kPxMaxChunks : p.Nout / kPxChunk;
   const int ntiles = p.Nout / (nchunks * kPxChunk);
@@ -253,8 +368,10 @@ int conv_px_launch(const ConvParams &p, hipStream_t s) {
   const bool bnx = p.bn_x != nullptr;
 #define SN_PX_LAUNCH(KC)                                                                                       \
   do {                                                                                                         \
-    if (bnx) hipLaunchKernelGGL((conv_px_kernel<KC, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);  \
-    else hipLaunchKernelGGL((conv_px_kernel<KC, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);     \
+    if (bnx && stag) hipLaunchKernelGGL((conv_px_kernel<KC, true, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);        \
+    else if (bnx) hipLaunchKernelGGL((conv_px_kernel<KC, true, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);          \
+    else if (stag) hipLaunchKernelGGL((conv_px_kernel<KC, false, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);         \
+    else hipLaunchKernelGGL((conv_px_kernel<KC, false, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);                  \
   } while (0)
   switch (p.Cin / 64) {
     case 2: SN_PX_LAUNCH(2); break;

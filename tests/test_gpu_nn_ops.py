@@ -591,7 +591,7 @@ def test_conv_px_forward_equals_the_tile_kernel(N, H, C, O, extras):
     assert nblk == -(-M // 160)
     outs = []
     try:
-        for on in (0, 1):
+        for on in (0, 1, 2):              # tile kernel, pixel-stationary, pixel-stationary with the staggered pixel halves
             hip.call('sn_conv_px', on)
             assert hip.query('sn_conv_fwd_stats_blocks', *geom) == nblk
             y = torch.full((N, H, H, O), 3.0, dtype=torch.float16, device=dev())
@@ -603,9 +603,10 @@ def test_conv_px_forward_equals_the_tile_kernel(N, H, C, O, extras):
             outs.append((y, part, y2))
     finally:
         hip.call('sn_conv_px', PX_DEFAULT)
-    (y0, p0, z0), (y1, p1, z1) = outs
+    (y0, p0, z0), (y1, p1, z1), (y2, p2, z2) = outs
     assert torch.equal(y0, y1) and torch.equal(z0, z1) and torch.equal(y0, z0)
     assert torch.equal(p0, p1)
+    assert torch.equal(y0, y2) and torch.equal(z0, z2) and torch.equal(p0, p2)
     ref = (xd.float().reshape(M, C) @ wd.float().reshape(O, C).t())
     if bias is not None:
         ref = ref + bias
@@ -635,7 +636,7 @@ def test_conv_px_data_gradient_equals_the_tile_kernel(N, H, C, O, act, acc):
     assert nblk == -(-M // 160)
     outs = []
     try:
-        for on in (0, 1):
+        for on in (0, 1, 2):
             hip.call('sn_conv_px', on)
             dx = torch.full((N, H, H, C), 3.0, dtype=torch.float16, device=dev())
             part = torch.full((nblk, 2, C), 7.0, dtype=torch.float32, device=dev())
@@ -646,9 +647,10 @@ def test_conv_px_data_gradient_equals_the_tile_kernel(N, H, C, O, act, acc):
             outs.append((dx, part, dx2))
     finally:
         hip.call('sn_conv_px', PX_DEFAULT)
-    (a0, p0, b0), (a1, p1, b1) = outs
+    (a0, p0, b0), (a1, p1, b1), (a2, p2, b2) = outs
     assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(a0, b0)
     assert torch.equal(p0, p1)
+    assert torch.equal(a0, a2) and torch.equal(b0, b2) and torch.equal(p0, p2)
     assert float(p1[:, 0].abs().sum()) > 0 and float(p1[:, 1].abs().sum()) > 0
 
 

@@ -43,18 +43,19 @@ def fwd_case(N, H, C, O):
     geom = (N, H, H, C, C, O, O, 0, 1, 1, 1, 0, 1)
     nblk = hip.query('sn_conv_fwd_stats_blocks', *geom)
     res = {}
-    for on in (0, 1):
+    for on in (0, 1, 2):
         hip.call('sn_conv_px', on)
         ys = [torch.empty((N, H, H, O), dtype=torch.float16, device=dev) for _ in range(SETS)]
         ps = [torch.zeros((nblk, 2, O), dtype=torch.float32, device=dev) for _ in range(SETS)]
         us = timed(lambda k: hip.call('sn_conv_fwd_stats', xs[k], w, None, None, ys[k], *geom, 0, ps[k], hip.stream()))
         res[on] = (us, ys, ps)
-    same = all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1])) and all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    same = all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(res[0][1], res[1][1], res[2][1])) and \
+        all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(res[0][2], res[1][2], res[2][2]))
     flop = 2.0 * M * C * O
     mb = (M * C + M * O + O * C) * 2 / 1e6
-    print('sn_conv_fwd_stats N%d %dx%d C%d->%d: tile %.1f us, px %.1f us (%.2fx)  %.0f -> %.0f TFLOP/s, %.1f MB: %.2f -> %.2f TB/s  bit-equal %s'
-          % (N, H, H, C, O, res[0][0], res[1][0], res[0][0] / res[1][0], flop / res[0][0] / 1e6, flop / res[1][0] / 1e6, mb,
-             mb / res[0][0], mb / res[1][0], same), flush=True)
+    print('sn_conv_fwd_stats N%d %dx%d C%d->%d: tile %.1f us, px %.1f us (%.2fx), staggered %.1f us (%.2fx)  %.0f -> %.0f TFLOP/s, %.1f MB: %.2f -> %.2f TB/s  bit-equal %s'
+          % (N, H, H, C, O, res[0][0], res[1][0], res[0][0] / res[1][0], res[2][0], res[0][0] / res[2][0], flop / res[0][0] / 1e6,
+             flop / res[2][0] / 1e6, mb, mb / res[0][0], mb / res[2][0], same), flush=True)
 
 
 def dgrad_case(N, H, C, O):
@@ -69,18 +70,19 @@ def dgrad_case(N, H, C, O):
     geom = (N, H, H, C, C, O, O, 0, 1, 1, 1, 0, 1)
     nblk = hip.query('sn_conv_dgrad_bn_blocks', *geom)
     res = {}
-    for on in (0, 1):
+    for on in (0, 1, 2):
         hip.call('sn_conv_px', on)
         dxs = [torch.empty((N, H, H, C), dtype=torch.float16, device=dev) for _ in range(SETS)]
         ps = [torch.zeros((nblk, 2, C), dtype=torch.float32, device=dev) for _ in range(SETS)]
         us = timed(lambda k: hip.call('sn_conv_dgrad_bn', dys[k], wt, None, dxs[k], *geom, bnxs[k], C, scale, shift, mean, 1, ps[k], hip.stream()))
         res[on] = (us, dxs, ps)
-    same = all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1])) and all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    same = all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(res[0][1], res[1][1], res[2][1])) and \
+        all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(res[0][2], res[1][2], res[2][2]))
     flop = 2.0 * M * C * O
     mb = (M * O + 2 * M * C + O * C) * 2 / 1e6
-    print('sn_conv_dgrad_bn N%d %dx%d dx C%d <- dy C%d: tile %.1f us, px %.1f us (%.2fx)  %.0f -> %.0f TFLOP/s, %.1f MB: %.2f -> %.2f TB/s  bit-equal %s'
-          % (N, H, H, C, O, res[0][0], res[1][0], res[0][0] / res[1][0], flop / res[0][0] / 1e6, flop / res[1][0] / 1e6, mb,
-             mb / res[0][0], mb / res[1][0], same), flush=True)
+    print('sn_conv_dgrad_bn N%d %dx%d dx C%d <- dy C%d: tile %.1f us, px %.1f us (%.2fx), staggered %.1f us (%.2fx)  %.0f -> %.0f TFLOP/s, %.1f MB: %.2f -> %.2f TB/s  bit-equal %s'
+          % (N, H, H, C, O, res[0][0], res[1][0], res[0][0] / res[1][0], res[2][0], res[0][0] / res[2][0], flop / res[0][0] / 1e6,
+             flop / res[2][0] / 1e6, mb, mb / res[0][0], mb / res[2][0], same), flush=True)
 
 
 if __name__ == '__main__':

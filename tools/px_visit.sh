@@ -9,8 +9,8 @@ tail -5 gpurun_out/px_tests.log
 timeout 300 python tools/conv_px_ab.py 40 > gpurun_out/px_ab.log 2>&1
 echo "ab exit $?" >> gpurun_out/px_ab.log
 cat gpurun_out/px_ab.log | tail -8
-for PX in 0 1; do
-  SNIPER_CONV_PX=$PX timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-inference --no-fit-path > gpurun_out/px_bench_$PX.log 2>&1
+for PX in 0 2; do
+  SNIPER_CONV_PX=$PX timeout 400 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-inference --no-fit-path > gpurun_out/px_bench_$PX.log 2>&1
   echo "bench px=$PX exit $?"
   tail -1 gpurun_out/px_bench_$PX.log | python -c "
 import sys, json
