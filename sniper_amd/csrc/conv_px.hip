@@ -48,7 +48,7 @@ constexpr int kPxMaxChunks = 4;   // chunks per workgroup: up to 512 output chan
 
 // KC = Cin / 64.  LDS: two weight stages of KC x [128 rows][64 channels] fp16 (KC x 16 KB each) + the statistics exchange.
 template <int KC, bool BNX, bool STAG>
-__global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int mtiles, int ntiles, int nchunks) {
+__global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int mtiles, int ntiles, int nchunks, int dbg) {
   constexpr int BK = 64, MI = kPxBM / 2 / 16, KS = 2 * KC;
   constexpr int BLK = kPxChunk * BK;              // half_t elements of one 64-channel block of a stage
   constexpr int STAGE = KC * BLK;
@@ -64,6 +64,13 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   const int nt = j % ntiles, mt = (j / ntiles) * 8 + xcd;      // the column tiles of one row tile run on ONE XCD (they share the pixels)
   if (mt >= mtiles) return;
   const int tid = threadIdx.x, lane = tid & 63;
+  // diagnostics (tools/conv_px_trace.py): shader-clock stamps of wave 0 -- [0] entry, [1] pixels + first weight stage landed,
+  // [2 + 2c] chunk c multiplied, [3 + 2c] chunk c stored, [10] exit; dbg bits switch PARTS of the kernel off (wrong results,
+  // timing only): 1 output stores, 2 weight DMA after the first stage, 4 pixel loads, 8 MFMAs, 16 statistics
+  auto stamp = [&](int k) {
+    if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
@@ -121,7 +128,8 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        fa[i][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rx, a_off + ks * 64, i * 16 * p.in_ps * 2, 0));
+        fa[i][ks] = (dbg & 4) ? half8{1, 1, 1, 1, 1, 1, 1, 1}
+                              : __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rx, a_off + ks * 64, i * 16 * p.in_ps * 2, 0));
   }
   // The compiler must see these loads RETIRE here: its scoreboard does not read an inline-asm s_waitcnt, and a load it still
   // believes pending makes it drain the LDS-DMA queue (vmcnt(0)) in front of the first MFMA of EVERY chunk
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa[i][ks]));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (and this wave's pieces of weight stage 0, its constants in LDS)
   __builtin_amdgcn_s_barrier();
+  stamp(1);
 
   const int sw = fq ^ (fr & 7);
   const int b_rd = (wn * 32 + fr) * BK;
@@ -183,10 +192,14 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
       } else {
         fb0 = rd(ks, 0); fb1 = rd(ks, 1);
       }
+      if (!(dbg & 8)) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0, fa[i][ks], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1, fa[i][ks], acc[i][1], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0, fa[i][ks], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1, fa[i][ks], acc[i][1], 0, 0, 0);
+        }
+      } else {
+        acc[0][0][0] += (float)fb0[0] + (float)fb1[0];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[i][r] = (half_t)v[r];
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(px_u4, o[i]), ry, y_off, i * 16 * p.out_ps * 2, 0);      // (rows >= M: out of bounds)
+      if (!(dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(px_u4, o[i]), ry, y_off, i * 16 * p.out_ps * 2, 0);      // (rows >= M: out of bounds)
     }
     // pass 2, four channels at a time (twelve constant registers and eight sums live, not twenty-four and sixteen)
     half8 xv[BNX ? MI : 1];
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
 #pragma unroll
       for (int i = 0; i < MI; ++i) xv[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rbx, x_off, i * 16 * p.bn_x_ps * 2, 0));
     }
-    if (has_stats) {
+    if (has_stats && !(dbg & 16)) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         __builtin_amdgcn_sched_barrier(0);      // (one half's constants and conversions must not be hoisted into the other's)
@@ -305,22 +318,24 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   // (buffer (t + 1) & 1 was read by chunk t - 1, which every wave finished before the barrier that closed interval t - 1)
   if (!STAG || wm == 0) {
     for (int t = 0; t < nchunks; ++t) {
-      if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
+      if (t + 1 < nchunks && !(dbg & 2)) issue(t + 1, (t + 1) & 1);
       prefetch(t);
       compute(t);
+      stamp(2 + 2 * t);
       landed();
       epilogue(t);
+      stamp(3 + 2 * t);
       close_interval();
     }
     if constexpr (STAG) __builtin_amdgcn_s_barrier();      // the other half's last interval
   } else {
-    if (1 < nchunks) issue(1, 1);
+    if (1 < nchunks && !(dbg & 2)) issue(1, 1);
     prefetch(0);
     compute(0);
     landed();
     close_interval();
     for (int t = 1; t < nchunks; ++t) {
-      if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
+      if (t + 1 < nchunks && !(dbg & 2)) issue(t + 1, (t + 1) & 1);
       epilogue(t - 1);
       __builtin_amdgcn_sched_barrier(0);      // (the next chunk's prefetch must not start while the previous one's registers are live)
       prefetch(t);
@@ -343,6 +358,7 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
       p.stats[((size_t)mt * 2 + which) * p.Nout + n0 + c * kPxChunk + col] = a;
     }
   }
+  stamp(10);
 }
 
 }  // namespace
@@ -360,7 +376,7 @@ bool conv_px_ok(const ConvParams &p) {
   return true;
 }
 
-int conv_px_launch(const ConvParams &p, bool stag, hipStream_t s) {
+int conv_px_launch(const ConvParams &p, bool stag, int dbg, hipStream_t s) {
   const int mtiles = sn_div_up(p.M, kPxBM);
   const int nchunks = p.Nout > kPxMaxChunks * kPxChunk ? kPxMaxChunks : p.Nout / kPxChunk;
   const int ntiles = p.Nout / (nchunks * kPxChunk);
@@ -368,10 +384,10 @@ int conv_px_launch(const ConvParams &p, bool stag, hipStream_t s) {
   const bool bnx = p.bn_x != nullptr;
 #define SN_PX_LAUNCH(KC)                                                                                       \
   do {                                                                                                         \
-    if (bnx && stag) hipLaunchKernelGGL((conv_px_kernel<KC, true, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);        \
-    else if (bnx) hipLaunchKernelGGL((conv_px_kernel<KC, true, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);          \
-    else if (stag) hipLaunchKernelGGL((conv_px_kernel<KC, false, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);         \
-    else hipLaunchKernelGGL((conv_px_kernel<KC, false, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks);                  \
+    if (bnx && stag) hipLaunchKernelGGL((conv_px_kernel<KC, true, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks, dbg);        \
+    else if (bnx) hipLaunchKernelGGL((conv_px_kernel<KC, true, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks, dbg);          \
+    else if (stag) hipLaunchKernelGGL((conv_px_kernel<KC, false, true>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks, dbg);         \
+    else hipLaunchKernelGGL((conv_px_kernel<KC, false, false>), grid, dim3(512), 0, s, p, mtiles, ntiles, nchunks, dbg);                  \
   } while (0)
   switch (p.Cin / 64) {
     case 2: SN_PX_LAUNCH(2); break;
