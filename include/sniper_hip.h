@@ -255,13 +255,6 @@ int sn_conv_dgrad(const void *dy, const void *wt, const void *accumulate, void *
  * instead of 36 for a 3x3 kernel, 1 instead of 4 for a 1x1 shortcut; same sums in the same order per pixel); 0 = every tap for
  * every pixel.  Affects the row-tile count sn_conv_dgrad_bn_blocks reports: set it before that query. */
 int sn_conv_dgrad_by_class(int on);
-/* Test / A-B switch (process-wide, atomic; SNIPER_CONV_PX at load time): 1 or 2 = the 1x1, unit-stride layers with a short
- * contraction (Cin 128..256, Cout a multiple of 128: the bottleneck expansions of resnet_mx_101_e2e.py:43-66 and the data gradients
- * of the reductions) run on the pixel-stationary kernel (csrc/conv_px.hip: pixels in registers, weights streamed through LDS, one
- * workgroup per 160-pixel row tile; 2 = its two pixel halves staggered by half an interval, one half's epilogue under the other's
- * MFMAs) instead of the 160 x 128 tile kernel; results and statistics partials are identical bit for bit and the `blocks` of
- * sn_conv_fwd_stats_blocks / sn_conv_dgrad_bn_blocks do not change.  0 = the tile kernel everywhere. */
-int sn_conv_px(int on);
 /* sn_conv_dgrad that also emits the reduction of the BatchNorm(+activation) backward below it: dx is dL/dy of
  * y = act(BN(bn_x)) (bn_act: 0 none, 1 ReLU, 2 ReLU6), partials (blocks, 2, Cin) fp32 = per row tile sum g and sum g*(bn_x - mean)
  * with g = the stored dx masked by the activation; blocks = sn_conv_dgrad_bn_blocks(...) (0: the layer does not qualify).

@@ -227,14 +227,6 @@ SN_EXPORT int sn_conv_dgrad_by_class(int on) {
   return SN_OK;
 }
 
-// A/B and test switch: 1 = the 1 x 1 layers with a short contraction (Cin <= 256) that the plan gives 160-row tiles run on the
-// pixel-stationary kernel (conv_px.hip; bit-identical results and statistics blocks), 0 = on the tile kernel
-static std::atomic<int> g_conv_px{env_int("SNIPER_CONV_PX", 0)};
-SN_EXPORT int sn_conv_px(int on) {
-  g_conv_px.store(on < 0 ? 0 : on, std::memory_order_relaxed);      // bits 0-1: 0 off / 1 plain / 2 staggered; bits 4+: diagnostics (conv_px.hip)
-  return SN_OK;
-}
-
 static ConvPlan conv_plan(const ConvParams &p, bool dgrad, int use_cfg = -1) {
   // Layers whose taps are whole 64-channel K-steps and 16-byte addressable take a pipelined kernel; narrow outputs
   // (stage1 / RPN heads) and the packed stem stay on conv_igemm_kernel.
@@ -276,11 +268,6 @@ static int conv_launch(const ConvParams &p, hipStream_t s, int use_cfg = -1) {
     q.cls = pl.cls;
     q.cls_mc = pl.cls_mc;
     conv_fastdiv_fill(q);
-    const int px = g_conv_px.load(std::memory_order_relaxed);
-    if (pl.bm == 160 && use_cfg <= 0 && g_conv_cfg.load(std::memory_order_relaxed) < 0 && (px & 3) != 0 && conv_px_ok(q)) {
-      q.trace = conv_dma_get_trace();
-      return conv_px_launch(q, (px & 3) == 2, px >> 4, s);
-    }
     return conv_dma_launch(q, DGRAD, pl.dma, s);
   }
   SN_REQUIRE(!p.stats, "convolution statistics are emitted by the pipelined kernel only (query sn_conv_fwd_stats_blocks first)");

@@ -75,11 +75,6 @@ constexpr int kConvDmaConfigs = 18;    // highest configuration number (the tabl
 ConvDmaConfig conv_dma_config(int cfg);
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
 void conv_dma_set_trace(unsigned long long *buf);
-// Pixel-stationary kernel for 1 x 1 layers with a short contraction (conv_px.hip): same results and the same 160-row statistics
-// blocks as the 160 x 128 tile configurations, so it substitutes for them launch by launch.
-bool conv_px_ok(const ConvParams &p);
-int conv_px_launch(const ConvParams &p, bool staggered, int dbg, hipStream_t s);
-unsigned long long *conv_dma_get_trace();
 
 // ---- weight gradient (conv.hip: gather kernel for unaligned operands and the packed stem; conv_wgrad_ps.hip: everything else)
 struct WgradParams {

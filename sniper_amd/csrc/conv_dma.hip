@@ -669,7 +669,6 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
 // diagnostics: phase timeline of the next launches' workgroups into buf (>= 8 x grid 64-bit words; tools/conv_trace.py), NULL = off
 static std::atomic<unsigned long long *> g_conv_trace{nullptr};
 void conv_dma_set_trace(unsigned long long *buf) { g_conv_trace.store(buf, std::memory_order_relaxed); }
-unsigned long long *conv_dma_get_trace() { return g_conv_trace.load(std::memory_order_relaxed); }
 
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s) {
   unsigned long long *trace = g_conv_trace.load(std::memory_order_relaxed);

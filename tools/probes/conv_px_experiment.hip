@@ -1,3 +1,12 @@
+// EXPERIMENT, NOT BUILT (round 5; the library is sniper_amd/csrc/*.hip only).  This is csrc/conv_px.hip as of commit 190963f, kept for the
+// next round: a pixel-stationary 1 x 1 convolution for short contractions.  Bit-identical to the 160 x 128 tile kernel on every test
+// (outputs and BatchNorm partials), 1.08 - 1.34x faster than it in isolation on three of the four layer families, NO gain in the timed
+// step (profiles/r05_conv_px_experiment.txt): its phases serialise -- pixel loads 8.7 us (the four channel groups of a workgroup each
+// load the same 80 pixels: 320 KB through one CU's load path for 80 KB of data), 8.7 us of launch / first weight stage / barriers,
+// statistics 4.1, stores 3.1, MFMAs 2.8 -- and per CU it moves the same 576 KB through the vector-memory path as the four tile
+// workgroups it replaces.  What would make it pay: the pixel tile ONCE per workgroup through LDS-DMA (80 KB), then ~336 KB per CU.
+// To try it again: copy to sniper_amd/csrc/conv_px.hip, restore the hook in conv.hip (conv_launch: pl.bm == 160 && conv_px_ok(q) ->
+// conv_px_launch) and the declarations in conv_common.h from that commit.
 // conv_px.hip -- "pixel-stationary" 1 x 1 convolution for SHORT contractions (Cin = 128 .. 256): the bottleneck expansions
 // 256 -> 1024 / 128 -> 512 of resnetc4 (symbols/faster/resnet_mx_101_e2e.py:43-66, conv3 of every residual unit) forward, and the
 // data gradients of the reductions 1024 -> 256 / 512 -> 128 (the same GEMM on the transposed weights).
