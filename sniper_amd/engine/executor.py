@@ -14,7 +14,6 @@ runtime (component 10): executor, operator kernels, optimiz
 * torch provides device memory, streams and (elsewhere) torch.distributed; every byte of compute
   goes through the C ABI (sniper_amd.hip.call).  No CPU fallback.
 """
-import math
 import os
 import warnings
 
@@ -22,7 +21,6 @@ import numpy as np
 import torch
 
 from .. import hip
-from ..mx.symbol import _bool, _tup
 from .shapes import infer_shapes
 
 F16, F32 = torch.float16, torch.float32

@@ -20,7 +20,6 @@ be opened is an error, not noise.  The benchmark is defined on synthetic chips (
 ``im_source='synthetic'`` asks for the seeded N(0, 50^2) generator explicitly (bench.py, the smoke test, the GPU tests);
 a callable ``im_source(roidb_entry, crop, flipped) -> (3,H,W) float32`` is accepted too.
 """
-import math
 import zlib
 
 import numpy as np

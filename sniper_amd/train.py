@@ -6,7 +6,6 @@ import sniper_amd.mx as mx
 
 from . import config as cfgmod
 from .iterators.MNIteratorE2E import MNIteratorE2E
-from .symbols.faster import resnet_mx_101_e2e
 from .synthetic import make_roidb
 
 
