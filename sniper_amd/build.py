@@ -12,7 +12,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("SNIPER_BUILD_CSRC") or os.path.join(HERE, "csrc")   # (experiments: a patched COPY of csrc, tools/probes/conv_px_build.sh)
 OUT_DIR = os.path.join(HERE, "lib")
 # A/B builds of the whole library (tools/ab.sh loads them through SNIPER_HIP_LIB): SNIPER_BUILD_SUFFIX=_x SNIPER_BUILD_DEFS="-DSN_X=1"
 # compiles into lib/obj_x and links lib/libsniper_hip_x.so; without them this is the one library the package loads.

@@ -1,12 +1,15 @@
-// EXPERIMENT, NOT BUILT (round 5; the library is sniper_amd/csrc/*.hip only).  This is csrc/conv_px.hip as of commit 190963f, kept for the
-// next round: a pixel-stationary 1 x 1 convolution for short contractions.  Bit-identical to the 160 x 128 tile kernel on every test
-// (outputs and BatchNorm partials), 1.08 - 1.34x faster than it in isolation on three of the four layer families, NO gain in the timed
-// step (profiles/r05_conv_px_experiment.txt): its phases serialise -- pixel loads 8.7 us (the four channel groups of a workgroup each
-// load the same 80 pixels: 320 KB through one CU's load path for 80 KB of data), 8.7 us of launch / first weight stage / barriers,
-// statistics 4.1, stores 3.1, MFMAs 2.8 -- and per CU it moves the same 576 KB through the vector-memory path as the four tile
-// workgroups it replaces.  What would make it pay: the pixel tile ONCE per workgroup through LDS-DMA (80 KB), then ~336 KB per CU.
-// To try it again: copy to sniper_amd/csrc/conv_px.hip, restore the hook in conv.hip (conv_launch: pl.bm == 160 && conv_px_ok(q) ->
-// conv_px_launch) and the declarations in conv_common.h from that commit.
+// EXPERIMENT, NOT PART OF THE SHIPPED LIBRARY (round 5; the library is sniper_amd/csrc/*.hip only).  A pixel-stationary 1 x 1 convolution
+// for short contractions; tools/probes/conv_px_build.sh builds sniper_amd/lib/libsniper_hip_px.so from a scratch copy of csrc + this
+// file + the hook of conv_px_hook.patch, tools/probes/conv_px_trace.py measures it.  Bit-identical to the 160 x 128 tile kernel (outputs
+// and BatchNorm partials) on every case tried.  profiles/r05_conv_px_experiment.txt:
+//   first version (every wave loads its 80 pixels itself; commits 8661762 - 190963f): 28.3 us against the tile kernel's 28.5 on the
+//     stage-3 expansion, no gain in the timed step -- pixel loads 8.7 us (the four channel groups of a workgroup load the same pixels:
+//     320 KB through one CU's load path for 80 KB of data), 8.7 us of launch / first weight stage / barriers, statistics 4.1,
+//     stores 3.1, MFMAs 2.8, all serialised;
+//   this version (the pixel tile ONCE per workgroup by LDS-DMA, fragments copied LDS -> registers): 256 -> 1024 forward 28.6 -> 20.9 us
+//     (1.37x), 128 -> 512 forward 50.5 -> 36.1 (1.40x), the 1024 <- 256 data gradient with the fused BatchNorm-backward reduction
+//     42.7 -> 40.1 (its epilogue, not its prologue, is the cost).  Measured with 5 GPU-minutes of the round left: too late for the
+//     counter profiles and the full suite a change of the shipped kernels needs, so it stays an experiment.
 // conv_px.hip -- "pixel-stationary" 1 x 1 convolution for SHORT contractions (Cin = 128 .. 256): the bottleneck expansions
 // 256 -> 1024 / 128 -> 512 of resnetc4 (symbols/faster/resnet_mx_101_e2e.py:43-66, conv3 of every residual unit) forward, and the
 // data gradients of the reductions 1024 -> 256 / 512 -> 128 (the same GEMM on the transposed weights).
@@ -64,8 +67,14 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   constexpr int PIECES = KC * 16 / 8;             // 1 KB DMA pieces per wave per stage
   constexpr int RED = kPxMaxChunks * 2 * 2 * kPxChunk;   // floats: [chunk][pixel half][sum | second moment][channel]
   constexpr int CST = BNX ? 3 * kPxMaxChunks * kPxChunk : 0;   // floats: BatchNorm scale | shift | mean of this workgroup's channels
-  __shared__ __attribute__((aligned(1024))) half_t lds[2 * STAGE + (RED + CST) * 2];
-  float *const red = reinterpret_cast<float *>(lds + 2 * STAGE);
+  // the pixel tile (160 rows x Cin: KC blocks of [160 rows][64 channels], 20 KB each) passes through LDS ONCE per workgroup -- it lands
+  // in weight buffer 1 and the 4 KC KB behind it while weight stage 0 lands in buffer 0; every wave then copies ITS fragments to
+  // registers, and buffer 1 takes weight stage 1.  (First version: the four channel groups each loaded the same 80 pixels from
+  // global memory, 320 KB through the CU's load path for 80 KB of data: 8.7 us of a 28 us launch.)
+  constexpr int ABLK = kPxBM * BK;                 // half_t elements of one 64-channel block of the pixel tile
+  constexpr int AEXTRA = KC * ABLK - STAGE;        // what the tile needs beyond weight buffer 1
+  __shared__ __attribute__((aligned(1024))) half_t lds[2 * STAGE + AEXTRA + (RED + CST) * 2];
+  float *const red = reinterpret_cast<float *>(lds + 2 * STAGE + AEXTRA);
   float *const cst = red + RED;
 
   const int lin = blockIdx.x;
@@ -131,23 +140,37 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   const int mrow = m0 + wm * (kPxBM / 2) + fr;        // this lane's pixel of row fragment 0 (fragment i: + 16 i)
 
   half8 fa[MI][KS];
+  half_t *const atile = lds + STAGE;
+  if (!(dbg & 4)) {
+    // 8-row pieces of the tile: piece g = block kb = g / 20, rows 8 (g % 20) .. + 7; lane l supplies row (l >> 3), 16-byte chunk (l & 7) ^ (l >> 3)
+    // (the row goes in the LANE offset: a raw buffer's bound check does not see the scalar offset, and rows beyond M must read zeros)
+#pragma unroll
+    for (int i = 0; i < (KC * 20 + 7) / 8; ++i) {
+      const int g = wave + 8 * i;
+      if (g < KC * 20) {
+        const int kb = g / 20, rg = g - kb * 20;
+        const unsigned a_lane = ((unsigned)(m0 + 8 * rg + lrow) * (unsigned)p.in_ps) * 2u + (unsigned)gchunk * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(atile + kb * ABLK + rg * 512), 16, a_lane, kb * 128, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of the tile and of weight stage 0, its constants
+  __builtin_amdgcn_s_barrier();
   {
-    const unsigned a_off = ((unsigned)mrow * (unsigned)p.in_ps + (unsigned)fq * 8u) * 2u;
+    const int a_rd = (wm * (kPxBM / 2) + fr) * BK, asw = fq ^ (fr & 7);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         fa[i][ks] = (dbg & 4) ? half8{1, 1, 1, 1, 1, 1, 1, 1}
-                              : __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rx, a_off + ks * 64, i * 16 * p.in_ps * 2, 0));
+                              : *reinterpret_cast<const half8 *>(atile + (ks >> 1) * ABLK + a_rd + i * 16 * BK + (asw ^ ((ks & 1) * 4)) * 8);
   }
-  // The compiler must see these loads RETIRE here: its scoreboard does not read an inline-asm s_waitcnt, and a load it still
-  // believes pending makes it drain the LDS-DMA queue (vmcnt(0)) in front of the first MFMA of EVERY chunk
-  // (cdna_hip_programming.md, trap (b)).  An empty asm that "uses" each fragment puts the compiler's own wait here.
+  // every wave holds its fragments before weight stage 1 may overwrite the tile (the empty asm makes the compiler retire the reads here)
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa[i][ks]));
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (and this wave's pieces of weight stage 0, its constants in LDS)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp(1);
 
@@ -167,9 +190,11 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
   auto prefetch = [&](int c) {
     if constexpr (BNX) {
       const int n = n0 + c * kPxChunk + wn * 32 + fq * 8;
-      const unsigned x_off = ((unsigned)mrow * (unsigned)p.bn_x_ps + (unsigned)n) * 2u;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) touch[i] = __builtin_amdgcn_raw_buffer_load_b32(rbx, x_off, i * 16 * p.bn_x_ps * 2, 0);
+      for (int i = 0; i < MI; ++i) {
+        const int r = mrow + i * 16 < p.M ? mrow + i * 16 : 0;      // (in the lane offset: the bound check does not see a scalar offset)
+        touch[i] = __builtin_amdgcn_raw_buffer_load_b32(rbx, ((unsigned)r * (unsigned)p.bn_x_ps + (unsigned)n) * 2u, 0, 0);
+      }
     }
   };
   // (the touches retire where the hand-written vmcnt(0) already stands; the empty asm keeps them from being dropped as dead)
@@ -245,14 +270,17 @@ __global__ __launch_bounds__(512, 1) void conv_px_kernel(const ConvParams p, int
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[i][r] = (half_t)v[r];
-      if (!(dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(px_u4, o[i]), ry, y_off, i * 16 * p.out_ps * 2, 0);      // (rows >= M: out of bounds)
+      // (guarded: a raw buffer's bound check does not include the scalar offset)
+      if (!(dbg & 1) && mrow + i * 16 < p.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(px_u4, o[i]), ry, y_off, i * 16 * p.out_ps * 2, 0);
     }
     // pass 2, four channels at a time (twelve constant registers and eight sums live, not twenty-four and sixteen)
     half8 xv[BNX ? MI : 1];
     if constexpr (BNX) {
-      const unsigned x_off = ((unsigned)mrow * (unsigned)p.bn_x_ps + (unsigned)n) * 2u;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) xv[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rbx, x_off, i * 16 * p.bn_x_ps * 2, 0));
+      for (int i = 0; i < MI; ++i) {
+        const int r = mrow + i * 16 < p.M ? mrow + i * 16 : 0;
+        xv[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rbx, ((unsigned)r * (unsigned)p.bn_x_ps + (unsigned)n) * 2u, 0, 0));
+      }
     }
     if (has_stats && !(dbg & 16)) {
 #pragma unroll
