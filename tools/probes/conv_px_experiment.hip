@@ -8,8 +8,9 @@
 //     stores 3.1, MFMAs 2.8, all serialised;
 //   this version (the pixel tile ONCE per workgroup by LDS-DMA, fragments copied LDS -> registers): 256 -> 1024 forward 28.6 -> 20.9 us
 //     (1.37x), 128 -> 512 forward 50.5 -> 36.1 (1.40x), the 1024 <- 256 data gradient with the fused BatchNorm-backward reduction
-//     42.7 -> 40.1 (its epilogue, not its prologue, is the cost).  Measured with 5 GPU-minutes of the round left: too late for the
-//     counter profiles and the full suite a change of the shipped kernels needs, so it stays an experiment.
+//     42.7 -> 40.1 (its epilogue, not its prologue, is the cost).  In the timed step (tools/probes/conv_px_step_ab.sh): 945.6 -> 949.3
+//     chips/s with the forward layers on it, 0.4 % -- the tile kernel's operands come warm from the producing kernel there.  It stays
+//     an experiment.
 // conv_px.hip -- "pixel-stationary" 1 x 1 convolution for SHORT contractions (Cin = 128 .. 256): the bottleneck expansions
 // 256 -> 1024 / 128 -> 512 of resnetc4 (symbols/faster/resnet_mx_101_e2e.py:43-66, conv3 of every residual unit) forward, and the
 // data gradients of the reductions 1024 -> 256 / 512 -> 128 (the same GEMM on the transposed weights).
