@@ -328,7 +328,9 @@ def cpu_baseline(seconds_target=15.0):
     if not use_ref:
         obuild.build_restatement()
     fn = _cpu_image_chips_ref if use_ref else _cpu_image_chips
-    P = min(os.cpu_count() or 1, 64)   # TRAIN.NUM_PROCESS = 64 in the reference config
+    # BASELINE.md section 3 / SURVEY 8(d): P = os.cpu_count() of the benchmark node, P printed (until round 5: min(cores, 64), the
+    # reference config's TRAIN.NUM_PROCESS; SNIPER_CPU_BASELINE_PROCS restores any other pool size)
+    P = int(os.environ.get('SNIPER_CPU_BASELINE_PROCS', 0)) or (os.cpu_count() or 1)
     with mp.get_context('fork').Pool(P) as pool:
         pool.map(fn, range(P), chunksize=1)          # warm the workers (imports, anchor tables)
         # bounded sample: a pilot batch sizes the timed batch to about `seconds_target` of wall time
@@ -721,6 +723,7 @@ def compact_line(full):
     r = _pick(roof, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'gflop_per_step', 'conv_ms_per_step', 'step_tflops',
                      'entry_calls_per_step'))
     r['traffic'] = roof.get('traffic')
+    r['traffic_unit'] = 'HBM bytes per kernel LAUNCH of the family (rocprofv3 PMC passes); per step: traffic_bytes_per_step'
     r['kernel'] = 'conv_dma_kernel / wgrad_ps_kernel family (implicit-GEMM MFMA convolution: fwd + dgrad + wgrad)'
     xc = roof.get('rocprof_cross_check') or {}
     if xc.get('frac_rocprof') is not None:

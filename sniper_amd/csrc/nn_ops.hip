@@ -345,6 +345,199 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
          pa ? *reinterpret_cast<const half8 *>(pa + (size_t)r * ps_acc) : zero, (size_t)r);
 }
 
+// ---- finalize fused into its consumer (round 6) ------------------------------------------------------------------------------
+// bn_finalize_kernel / bn_bwd_finalize_kernel are launches that stream nothing: 8 - 32 blocks turning [nblk][2][C] partials into C
+// coefficients between the convolution that produced the partials and the pass that applies them -- 180 launches of 5 us per R101
+// step.  Here the CONSUMER does that reduction itself: a workgroup owns a 64-channel slab (its 128-byte share of every pixel row)
+// for its life, sums the slab's partials (nblk x 2 x 64 floats, L2-resident, every load independent) in double IN THE ORDER OF
+// bn_sum_partials -- lane rl takes k = rl, rl + 32, ..., the 32 lanes are added 0 .. 31 -- so the coefficients are bit-identical to
+// the separate kernel's, and then streams its rows.  The workgroups of row block 0 also write the per-channel outputs (scale /
+// shift / saved statistics / moving averages; dgamma / dbeta) that later launches read.  Taken when nblk <= kBnFusedMaxBlocks and
+// C % 64 == 0 (every train-mode BatchNorm of stages 3 - 4: 128 row tiles); otherwise the separate finalize launch stays.
+constexpr int kBnSlab = 64;              // channels per workgroup
+constexpr int kBnFusedMaxBlocks = 160;   // partial rows a workgroup re-reduces (64 independent loads per thread at 128)
+__device__ __forceinline__ void bn_slab_partials(const float *__restrict__ part, int nblk, int C, int c0, double (*red)[32][kBnSlab + 1],
+                                                 double &a, double &b) {
+  const int cl = threadIdx.x & 63, lg = threadIdx.x >> 6;     // channel of the slab, lane group 0 .. 3 (lanes rl = 8 lg .. 8 lg + 7)
+  double s0[8], s1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.0;
+  const float *p = part + c0 + cl;
+  for (int k0 = 0; k0 < nblk; k0 += 32) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + lg * 8 + j;
+      if (k < nblk) {
+        s0[j] += (double)p[(size_t)k * 2 * C];
+        s1[j] += (double)p[(size_t)k * 2 * C + C];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][lg * 8 + j][cl] = s0[j];
+    red[1][lg * 8 + j][cl] = s1[j];
+  }
+  __syncthreads();
+  a = b = 0.0;
+  if (threadIdx.x < kBnSlab)
+    for (int k = 0; k < 32; ++k) {
+      a += red[0][k][cl];
+      b += red[1][k][cl];
+    }
+}
+
+// y = act(x * scale + shift) with scale / shift from the partials: finalize + apply in one launch.  grid = (row blocks, C / 64)
+__global__ __launch_bounds__(256) void bn_apply_fin_kernel(const float *__restrict__ part, int nblk, const half_t *__restrict__ x,
+                                                           half_t *__restrict__ y, int M, int C, int ps_in, int ps_out, int rows_per_block,
+                                                           float eps, float momentum, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float *__restrict__ run_mean,
+                                                           float *__restrict__ run_var, float *__restrict__ scale,
+                                                           float *__restrict__ shift, float *__restrict__ save_mean,
+                                                           float *__restrict__ save_invstd, int relu) {
+  __shared__ double red[2][32][kBnSlab + 1];
+  __shared__ float coef[2][kBnSlab];
+  const int c0 = blockIdx.y * kBnSlab;
+  double sum, sumsq;
+  bn_slab_partials(part, nblk, C, c0, red, sum, sumsq);
+  if (threadIdx.x < kBnSlab) {
+    const int c = c0 + threadIdx.x;
+    const double mean = sum / M;
+    double var = sumsq / M - mean * mean;  // biased
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f;
+    const float sc = g * invstd, sh = beta[c] - (float)mean * g * invstd;
+    coef[0][threadIdx.x] = sc;
+    coef[1][threadIdx.x] = sh;
+    if (blockIdx.x == 0) {
+      scale[c] = sc;
+      shift[c] = sh;
+      save_mean[c] = (float)mean;
+      save_invstd[c] = invstd;
+      if (run_mean) {
+        run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
+        run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+      }
+    }
+  }
+  __syncthreads();
+  const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;       // 8-channel chunk of the slab, row lane 0 .. 31
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = coef[0][ch * 8 + j]; sh[j] = coef[1][ch * 8 + j]; }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  const half_t *px = x + c0 + ch * 8;
+  half_t *py = y + c0 + ch * 8;
+  auto body = [&](const half8 &v, size_t r) {
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * sc[j] + sh[j];
+      if (relu) f = f > 0.f ? f : 0.f;
+      if (relu == 2) f = f < 6.f ? f : 6.f;
+      o[j] = (half_t)f;
+    }
+    *reinterpret_cast<half8 *>(py + r * ps_out) = o;
+  };
+  int r = r0 + rl;
+  for (; r + (kBnUnroll - 1) * 32 < r1; r += kBnUnroll * 32) {
+    half8 v[kBnUnroll];
+#pragma unroll
+    for (int u = 0; u < kBnUnroll; ++u) v[u] = *reinterpret_cast<const half8 *>(px + (size_t)(r + u * 32) * ps_in);
+#pragma unroll
+    for (int u = 0; u < kBnUnroll; ++u) body(v[u], (size_t)(r + u * 32));
+  }
+  for (; r < r1; r += 32) body(*reinterpret_cast<const half8 *>(px + (size_t)r * ps_in), (size_t)r);
+}
+
+// dx of (act o BN_train) with dgamma / dbeta from the partials: backward finalize + dx in one launch, same decomposition
+__global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(const float *__restrict__ part, int nblk, const half_t *__restrict__ dy,
+                                                            const half_t *__restrict__ x, const half_t *__restrict__ acc,
+                                                            half_t *__restrict__ dx, int M, int C, int ps_dy, int ps_x, int ps_acc,
+                                                            int ps_dx, int rows_per_block, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, float *__restrict__ fin, int relu) {
+  __shared__ double red[2][32][kBnSlab + 1];
+  __shared__ float coef[4][kBnSlab];     // scale, shift, kb, kd
+  const int c0 = blockIdx.y * kBnSlab;
+  double sg, sgx;
+  bn_slab_partials(part, nblk, C, c0, red, sg, sgx);
+  if (threadIdx.x < kBnSlab) {
+    const int c = c0 + threadIdx.x;
+    const float db = (float)sg, dg = (float)(sgx * (double)invstd[c]);
+    const float invM = 1.f / (float)M;
+    const float scv = scale[c];
+    const float t = invstd[c] * dg * invM;   // xhat coefficient / scale
+    coef[0][threadIdx.x] = scv;
+    coef[1][threadIdx.x] = shift[c];
+    coef[2][threadIdx.x] = -scv * t;
+    coef[3][threadIdx.x] = scv * (mean[c] * t - db * invM);
+    if (blockIdx.x == 0) {
+      if (fin) { fin[c] = db; fin[C + c] = dg; }
+      if (dbeta) dbeta[c] += db;
+      if (dgamma) dgamma[c] += dg;
+    }
+  }
+  __syncthreads();
+  if (!dx) return;
+  const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  float sc[8], sh[8], kb[8], kd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = coef[0][ch * 8 + j]; sh[j] = coef[1][ch * 8 + j]; kb[j] = coef[2][ch * 8 + j]; kd[j] = coef[3][ch * 8 + j];
+  }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  const half_t *pg = dy + c0 + ch * 8, *px = x + c0 + ch * 8, *pa = acc ? acc + c0 + ch * 8 : nullptr;
+  half_t *po = dx + c0 + ch * 8;
+  auto body = [&](const half8 &g, const half8 &v, const half8 &a, size_t r) {
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = (float)v[j];
+      float gf = (float)g[j];
+      if (!bn_act_pass(xf * sc[j] + sh[j], relu)) gf = 0.f;
+      o[j] = (half_t)(sc[j] * gf + kb[j] * xf + kd[j] + (float)a[j]);
+    }
+    *reinterpret_cast<half8 *>(po + r * ps_dx) = o;
+  };
+  const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  int r = r0 + rl;
+  for (; r + (kBnUnroll - 1) * 32 < r1; r += kBnUnroll * 32) {
+    half8 g[kBnUnroll], v[kBnUnroll], a[kBnUnroll];
+#pragma unroll
+    for (int u = 0; u < kBnUnroll; ++u) {
+      const size_t rr = (size_t)(r + u * 32);
+      g[u] = *reinterpret_cast<const half8 *>(pg + rr * ps_dy);
+      v[u] = *reinterpret_cast<const half8 *>(px + rr * ps_x);
+      a[u] = pa ? *reinterpret_cast<const half8 *>(pa + rr * ps_acc) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < kBnUnroll; ++u) body(g[u], v[u], a[u], (size_t)(r + u * 32));
+  }
+  for (; r < r1; r += 32)
+    body(*reinterpret_cast<const half8 *>(pg + (size_t)r * ps_dy), *reinterpret_cast<const half8 *>(px + (size_t)r * ps_x),
+         pa ? *reinterpret_cast<const half8 *>(pa + (size_t)r * ps_acc) : zero, (size_t)r);
+}
+
+// A/B and test switch (sn_debug_option "bn_fused_finalize"): 0 = the separate finalize launches everywhere
+static std::atomic<int> g_bn_fused_finalize{1};
+void bn_set_fused_finalize(int on) { g_bn_fused_finalize.store(on ? 1 : 0, std::memory_order_relaxed); }
+static bool bn_fused_ok(int nblk, int M, int C) {
+  return g_bn_fused_finalize.load(std::memory_order_relaxed) != 0 && nblk <= kBnFusedMaxBlocks && C % kBnSlab == 0 && M >= 1024;
+}
+// grid of the slab-owning kernels: about 1024 workgroups, >= 128 rows each (one unrolled pass of the 32 row lanes)
+static dim3 bn_slab_grid(int M, int C, int *rows_per_block) {
+  const int slabs = C / kBnSlab;
+  int rb = 1024 / slabs;
+  if (rb < 1) rb = 1;
+  const int max_rb = sn_div_up(M, 128);
+  if (rb > max_rb) rb = max_rb;
+  *rows_per_block = sn_div_up(sn_div_up(M, rb), 32) * 32;
+  return dim3(sn_div_up(M, *rows_per_block), slabs);
+}
+
 static int bn_shape_ok(int C) { return C >= 8 && C % 8 == 0; }
 static int ew_blocks(long total) {
   long b = (total + 255) / 256;
@@ -424,6 +617,28 @@ SN_EXPORT int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int p
   return SN_OK;
 }
 
+// sn_bn_finalize_blocks + sn_bn_apply as ONE launch where the partials are few enough for the applying workgroups to reduce
+// themselves (bn_apply_fin_kernel), two launches otherwise: same outputs either way, bit for bit.
+SN_EXPORT int sn_bn_apply_blocks(const float *partials, int nblk, const void *x, void *y, int M, int C, int ps_in, int ps_out, float eps,
+                                 float momentum, const float *gamma, const float *beta, float *run_mean, float *run_var, float *scale,
+                                 float *shift, float *save_mean, float *save_invstd, int relu, sn_stream_t stream) {
+  SN_REQUIRE(partials && nblk > 0 && x && y && beta && scale && shift && save_mean && save_invstd && M > 0 && bn_shape_ok(C),
+             "sn_bn_apply_blocks: bad arguments (C=%d)", C);
+  if (!bn_fused_ok(nblk, M, C)) {
+    if (int rc = sn_bn_finalize_blocks(partials, nblk, M, C, eps, momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean,
+                                       save_invstd, stream))
+      return rc;
+    return sn_bn_apply(x, y, M, C, ps_in, ps_out, scale, shift, relu, stream);
+  }
+  int rows_per_block;
+  const dim3 grid = bn_slab_grid(M, C, &rows_per_block);
+  hipLaunchKernelGGL(bn_apply_fin_kernel, grid, dim3(256), 0, sn_stream(stream), partials, nblk, (const half_t *)x, (half_t *)y, M, C,
+                     ps_in, ps_out, rows_per_block, eps, momentum, gamma, beta, run_mean, run_var, scale, shift, save_mean, save_invstd,
+                     relu);
+  SN_CHECK_LAUNCH();
+  return SN_OK;
+}
+
 // Backward of y = relu?(BN_train(x)).  dgamma/dbeta (fp32, length C) are ACCUMULATED into (+=, the optimizer's
 // gradient arena is zeroed once per step); ws = sn_bn_workspace_bytes(M, C).  Three launches, no atomics, no memset:
 // partial reduce -> finalize -> dx.
@@ -462,6 +677,16 @@ SN_EXPORT int sn_bn_backward_blocks(const float *partials, int nblk, const void 
              "sn_bn_backward_blocks: bad arguments (C=%d)", C);
   hipStream_t s = sn_stream(stream);
   float *fin = (float *)ws;
+  if (bn_fused_ok(nblk, M, C)) {      // finalize inside the dx pass (bn_bwd_dx_fin_kernel): one launch
+    int rows_per_block;
+    dim3 grid = bn_slab_grid(M, C, &rows_per_block);
+    if (!dx) grid.x = 1;
+    hipLaunchKernelGGL(bn_bwd_dx_fin_kernel, grid, dim3(256), 0, s, partials, nblk, (const half_t *)dy, (const half_t *)x,
+                       (const half_t *)accumulate, (half_t *)dx, M, C, ps_dy, ps_x, ps_acc, ps_dx, rows_per_block, scale, shift, mean,
+                       invstd, dgamma, dbeta, fin, relu);
+    SN_CHECK_LAUNCH();
+    return SN_OK;
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sn_div_up(C, 32)), dim3(kBnFinThreads), 0, s, partials, nblk, C, invstd, fin, dgamma,
                      dbeta);
   SN_CHECK_LAUNCH();

@@ -104,8 +104,9 @@ def route(func):
 # device memory.  What `_get_batch` reads in any other way still sees the reference's values: a handle materialises them
 # (np.asarray / asnumpy: a copy to the host, and for the sparse (values, pids) pair the `np.where(bbox_weights == 1)` the reference
 # worker returns).  Sub-sampling of the 256 RPN labels: the reference draws with numpy's global RNG per chip; the batched launch
-# draws with the kernel's hash of (seed, chip, anchor) -- same rule, different draws (replaying numpy's needs the labels on the
-# host first: AnchorAssigner.numpy_replay_keys, used by the parity tests).  SNIPER_POOL_ROUTE_BATCH=0: per item on threads.
+# draws with the kernel's hash of (seed, chip, anchor) -- same rule, different draws; SNIPER_NUMPY_RNG=1 replays numpy's own draws
+# instead (the labels before sub-sampling come to the host first: AnchorAssigner.numpy_replay_keys) and the routed batch is then
+# bit-equal to the reference's serial map under np.random.seed.  SNIPER_POOL_ROUTE_BATCH=0: per item on threads.
 class _NotRouted(Exception):
     """raised by a batched form that finds it cannot take this map after all (mask polygons, no GPU): the pool runs the work items
     on its threads as it would have without the routing"""
@@ -210,8 +211,19 @@ def _anchor_batch(owner, items, func):
             owner._sniper_anchor_mirror = aa
         except AttributeError:
             pass
-    out = aa.assign(items, seed=aa._seed)
-    aa._seed += 1
+    if os.environ.get('SNIPER_NUMPY_RNG', '0') == '1':
+        # numpy's own draws (data_workers.py:327-338: npr.choice over the foreground, then the background candidates, chip by chip
+        # from the global generator): the labels before sub-sampling come to the host, numpy_replay_keys consumes np.random exactly
+        # as the reference's serial map would, and a second launch applies those draws -- under np.random.seed the routed batch is
+        # then bit-equal to the unrouted reference call (tools/routed_batch_check.py).  Opt-in: the read-back makes the host wait for
+        # the device once per batch, which the hashed draws of the default never do.
+        packed = aa.pack_device(items)
+        pre = aa.assign(keys=None, want_label_pre=True, packed=packed)
+        keys = aa.numpy_replay_keys(pre['label_pre'].cpu().numpy())
+        out = aa.assign(keys=keys, packed=packed)
+    else:
+        out = aa.assign(items, seed=aa._seed)
+        aa._seed += 1
     batch = _AnchorBatch(out)
     focus = aa.focus_mask(items) if owner.auto_focus else None
     res = []

@@ -164,7 +164,7 @@ class NDArray(object):
         return i
 
     def __getitem__(self, i):
-        if isinstance(i, (int, np.integer)) and (self._store is None or _is_device(self)):
+        if isinstance(i, (int, np.integer)) and len(self.shape) > 1 and (self._store is None or _is_device(self)):
             return _RowView(self, int(i))          # row of an unplaced / device array: writes through (and may place the parent)
         a = self.asnumpy()[self._idx(i)]
         if isinstance(self._data, np.ndarray) and isinstance(a, np.ndarray) and a.base is not None and not isinstance(
@@ -177,7 +177,20 @@ class NDArray(object):
             dev = v.device if hasattr(v, 'device') and not isinstance(v, NDArray) else (v._store.device if isinstance(v, NDArray) else None)
             self._place_on(dev if dev is not None else torch.device('cuda', torch.cuda.current_device()))
         if _is_device(self):
-            dst = self._store[self._idx(i)] if not (isinstance(i, slice) and i == slice(None)) else self._store
+            idx = self._idx(i)
+            if not _is_basic_index(idx):
+                # index arrays / masks: torch's advanced indexing returns a COPY, so `view.copy_` would write into a temporary --
+                # in-place index assignment instead (`row[pids0, pids1, pids2] = values` with plain numpy pids)
+                if hasattr(v, 'write_dense_into'):
+                    raise TypeError('a routed worker result cannot be written through an index array')
+                src = v._store if isinstance(v, NDArray) else v
+                if not isinstance(src, torch.Tensor):
+                    src = torch.as_tensor(np.asarray(src.asnumpy() if isinstance(src, NDArray) else src))
+                tidx = tuple(torch.as_tensor(np.asarray(j), device=self._store.device) if isinstance(j, (np.ndarray, list)) else j
+                             for j in (idx if isinstance(idx, tuple) else (idx,)))
+                self._store[tidx] = src.to(device=self._store.device, dtype=self._store.dtype)
+                return
+            dst = self._store[idx] if not (isinstance(i, slice) and i == slice(None)) else self._store
             if hasattr(v, 'write_dense_into'):                 # a routed worker's marker: the dense device tensor it stands for
                 v.write_dense_into(dst)
                 return
@@ -272,6 +285,14 @@ class _RowView(NDArray):
         if isinstance(v, NDArray):
             v = v.asnumpy()
         p._data[self._index][self._idx(i)] = v
+
+
+def _is_basic_index(idx):
+    """ints, slices, Ellipsis / None (and tuples of them) select a VIEW; anything else (index arrays, lists, masks) is advanced"""
+    basic = (int, np.integer, slice, type(Ellipsis), type(None))
+    if isinstance(idx, tuple):
+        return all(isinstance(j, basic) for j in idx)
+    return isinstance(idx, basic)
 
 
 def array(source, ctx=None, dtype=None):

@@ -234,3 +234,12 @@ def test_reference_get_batch_through_the_routed_per_batch_maps():
                 assert c['fg_equal'] and c['weights_equal'] and c['targets_maxdiff'] <= 1e-5, c
                 checked += 1
     assert checked >= 6          # (chips with 128+ foreground candidates involve a draw and are not compared anchor by anchor)
+    # SNIPER_NUMPY_RNG=1: numpy's own draws replayed (data_workers.py:327-338) -> under np.random.seed the routed batch equals the
+    # unrouted reference call on EVERY chip, the sub-sampled ones included (north_star: bit-exact index sets on fixed seeds)
+    drawn = 0
+    for b in res['batches']:
+        n = b['numpy_rng']
+        assert all(n['on_device']), n
+        assert n['labels_equal'] and n['weights_equal'] and n['gt_equal'] and n['targets_maxdiff'] <= 1e-5, n
+        drawn += n['chips_with_a_draw']
+    assert drawn >= 8 and any(b['numpy_rng']['differs_from_hashed_draws'] for b in res['batches']), res

@@ -90,6 +90,54 @@ def test_deformable_psroi_pooling_at_6000_rois(with_trans):
         assert_close(d_trans.cpu().numpy(), wtr, 1e-2, 1e-2 * np.abs(wtr).max(), 'dpsroi d_trans R=6000')
 
 
+@pytest.mark.parametrize('D', [81, 4])
+def test_position_sensitive_pool_at_c4_launch_shape(D):
+    """BASELINE configs[3] (C4, R-FCN head) at one GPU's share: 16 chips x 300 RoIs on the 32 x 32 maps of 7 * 7 * D channels (D = 81:
+    rfcn_cls, 3969 channels -> sixteen 256-channel chunks in the data gradient; D = 4: rfcn_bbox), group_size 7, pooled offsets --
+    sn_psroi_pool_fwd / _bwd against oracle/nn.py (sparse-operator form; position-sensitive variant spec ours, SURVEY 8(d) C4;
+    resnet_mx_101_e2e.py:286-293 is the group_size = 1 call it replaces).  The kernels run the full launch shape; the CPU oracle is
+    evaluated on every fourth RoI: forward rows of that subset, and the backward's output gradient is zero outside it (the data gradient
+    is linear in it, the other RoIs' windows are still scanned), which keeps the float64 operator products to seconds."""
+    from sniper_amd import hip
+    rs = np.random.RandomState(41 + D)
+    Bc, G, H, W, P, S, SC = 16, 7, 32, 32, 7, 4, 16
+    R, C = Bc * 300, D * G * G
+    data = rs.standard_normal((Bc, C, H, W)).astype(np.float32)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = np.repeat(np.arange(Bc), 300)
+    c = rs.uniform(0, 512, (R, 2))
+    wh = np.exp(rs.uniform(np.log(8), np.log(400), (R, 2)))
+    rois[:, 1:3], rois[:, 3:5] = np.clip(c - wh / 2, 0, 511), np.clip(c + wh / 2, 0, 511)
+    trans = (rs.standard_normal((R, 2, P, P)) * 0.5).astype(np.float32)
+    tstd = 0.1
+    sel = np.sort(rs.permutation(R)[:R // 4])
+    dd = torch.from_numpy(np.ascontiguousarray(data.transpose(0, 2, 3, 1))).to(dev()).half()
+    td = lambda z: torch.from_numpy(z).to(dev())
+    out = torch.full((R, P, P, D), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_psroi_pool_fwd', dd, td(rois), td(trans), out, R, H, W, D, G, P, S, 1.0 / SC, tstd, hip.stream())
+    want = onn.dpsroi_pool_fast(f16r(data), rois[sel], trans[sel], P, S, 1.0 / SC, tstd, group_size=G)
+    got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert_close(got[sel], want, 1e-2, 1e-2, 'psroi fwd C4 D=%d' % D)
+    assert np.isfinite(got).all() and not (got == 7.0).all(axis=(1, 2, 3)).any()       # every RoI's row was written
+    dout = np.zeros((R, D, P, P), np.float32)
+    dout[sel] = rs.standard_normal((len(sel), D, P, P))
+    dod = torch.from_numpy(np.ascontiguousarray(dout.transpose(0, 2, 3, 1))).to(dev()).half()
+    wd, wtr = onn.dpsroi_pool_backward_fast(f16r(dout[sel]), f16r(data), rois[sel], trans[sel], P, S, 1.0 / SC, tstd, group_size=G)
+    ws = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=dev())
+    d_data = torch.full((Bc, H, W, C), 7.0, dtype=torch.float16, device=dev())
+    d_trans = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
+    hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), td(trans), d_data, 0, d_trans, R, Bc, H, W, D, G, P, S, 1.0 / SC, tstd, ws,
+             hip.stream())
+    assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, 1e-2, 1e-2 * np.abs(wd).max(), 'psroi d_data C4 D=%d' % D)
+    gtr = d_trans.cpu().numpy()
+    assert_close(gtr[sel], wtr, 1e-2, 1e-2 * np.abs(wtr).max(), 'psroi d_trans C4 D=%d' % D)
+    rest = np.setdiff1d(np.arange(R), sel)
+    assert not gtr[rest].any()                                                         # zero output gradient -> zero offset gradient
+    d2 = torch.empty_like(d_data)
+    hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), td(trans), d2, 0, d_trans, R, Bc, H, W, D, G, P, S, 1.0 / SC, tstd, ws, hip.stream())
+    assert torch.equal(d2, d_data)                                                     # fixed summation order
+
+
 def _fused_case(name):
     N, C, H, W, O, K, s, p, d, hb, hr, relu = C2_CONV_SHAPES[name]
     Ho = (H + 2 * p - d * (K - 1) - 1) // s + 1

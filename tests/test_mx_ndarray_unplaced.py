@@ -64,3 +64,35 @@ def test_a_routed_workers_handles_materialise_the_reference_values_on_the_host()
         assert np.array_equal(np.asarray(pids).astype(int), np.stack(np.where(w[i] == 1)))
         assert np.array_equal(np.asarray(vals), t[i][np.where(w[i] == 1)])
     assert np.array_equal(tgt.asnumpy(), t) and np.array_equal(wgt.asnumpy(), w)
+
+
+def test_index_array_writes_into_device_arrays_land_in_the_array(monkeypatch):
+    """Fancy-index writes into a device NDArray (`row[pids0, pids1, pids2] = values` with plain numpy pids; tuple-of-array and mask
+    indices on the array itself): torch's advanced indexing returns a copy, so the write must be an in-place index assignment.
+    Simulated on CPU tensors: `_is_device` patched to accept them (the GPU twin: tests/test_gpu_acceptance.py)."""
+    import torch
+    from sniper_amd.mx import ndarray as nd
+    monkeypatch.setattr(nd, '_is_device', lambda v: getattr(v, '_device_resident', False) or
+                        isinstance(v._store if isinstance(v, nd.NDArray) else v, torch.Tensor))
+    a = nd.NDArray(torch.zeros((2, 4, 3, 3)))
+    i0, i1, i2 = np.array([0, 1, 3]), np.array([2, 2, 0]), np.array([0, 1, 2])
+    a[1][i0, i1, i2] = np.array([5.0, 6.0, 7.0], np.float32)
+    out = a._store.numpy()
+    assert out[1, 0, 2, 0] == 5 and out[1, 1, 2, 1] == 6 and out[1, 3, 0, 2] == 7 and out.sum() == 18 and out[0].sum() == 0
+    a[1][i0, i1, i2] = 1.0                                   # the scalar form (`bbox_weights[i][pids...] = 1.0`)
+    assert a._store.numpy().sum() == 3
+    b = nd.NDArray(torch.zeros((4, 5)))
+    b[(np.array([0, 3]), np.array([1, 4]))] = 7
+    assert b._store.numpy()[0, 1] == 7 and b._store.numpy()[3, 4] == 7 and b._store.numpy().sum() == 14
+    b[nd.array(np.array([1, 2]))] = torch.ones(5)            # an NDArray of row indices, a tensor value
+    assert b._store.numpy()[1:3].sum() == 10
+    b[1] = np.arange(5)                                       # the basic-index fast path still writes through a view
+    b[2, 1:3] = np.array([9.0, 9.0])
+    assert b._store.numpy()[1].tolist() == [0, 1, 2, 3, 4] and b._store.numpy()[2].tolist() == [1, 9, 9, 1, 1]
+
+
+def test_integer_index_of_a_one_dimensional_unplaced_array():
+    z = mx.nd.zeros(5)
+    assert float(z[2].asnumpy()) == 0.0 and z[2].shape == ()
+    z[3] = 4.0
+    assert z.asnumpy().tolist() == [0, 0, 0, 4, 0]

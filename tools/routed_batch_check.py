@@ -38,7 +38,8 @@ def main():
     from configs.faster.default_configs import config, update_config
     update_config(os.path.join('configs', 'faster', 'sniper_res101_e2e.yml'))
     config.TRAIN.USE_NEG_CHIPS = False
-    config.TRAIN.NUM_PROCESS, config.TRAIN.NUM_THREAD, config.TRAIN.CHIPS_DB_PARTS = 4, 4, 1
+    # (one pool thread: the unrouted map then draws from numpy's global generator chip by chip IN ORDER, like a serial run of the reference)
+    config.TRAIN.NUM_PROCESS, config.TRAIN.NUM_THREAD, config.TRAIN.CHIPS_DB_PARTS = 1, 4, 1
     roidb = _jpeg_roidb(work, n_images)
     for r in roidb:
         r['flipped'] = False
@@ -65,7 +66,14 @@ def main():
         np.random.seed(100 + k)
         bu = it._get_batch()
         os.environ['SNIPER_POOL_ROUTE_BATCH'] = '1'
+        # third call: routed again, with numpy's own sub-sampling draws replayed (SNIPER_NUMPY_RNG=1) under the seed of the unrouted call
+        it.cur_i, it.crop_idx = state[0], copy.deepcopy(state[1])
+        os.environ['SNIPER_NUMPY_RNG'] = '1'
+        np.random.seed(100 + k)
+        bn = it._get_batch()
+        os.environ['SNIPER_NUMPY_RNG'] = '0'
         it.cur_i = state[0] + B
+        n_lab, n_tgt, n_w, n_gt = [host(a) for a in bn.label[:4]]
         r_lab, r_tgt, r_w, r_gt = [host(a) for a in br.label[:4]]
         u_lab, u_tgt, u_w, u_gt = [host(a) for a in bu.label[:4]]
         rec = {'routed_maps': [routed1[0] - routed0[0], routed1[1] - routed0[1]],
@@ -85,6 +93,15 @@ def main():
                              'weights_equal': bool(np.array_equal(r_w[i], u_w[i])) if undrawn else None,
                              'targets_maxdiff': float(np.abs(r_tgt[i] - u_tgt[i]).max()) if undrawn else None})
         rec['chips'] = per_chip
+        # with numpy's draws replayed every chip is comparable, drawn or not: labels (incl. the sub-sampled -1s), weights, targets
+        ub_lab, ub_tgt, ub_w = [host(a) for a in bu.label[:3]]
+        rec['numpy_rng'] = {'on_device': [bool(on_device(a)) for a in list(bn.label[:4])],
+                            'labels_equal': bool(np.array_equal(n_lab, ub_lab)), 'weights_equal': bool(np.array_equal(n_w, ub_w)),
+                            'gt_equal': bool(np.array_equal(n_gt, u_gt)),
+                            'targets_maxdiff': float(np.abs(n_tgt - ub_tgt).max()),
+                            'chips_with_a_draw': int(sum(1 for i in range(B) if (ub_lab[i] == -1).any() and
+                                                         ((ub_lab[i] == 1).sum() + (ub_lab[i] == 0).sum()) == 256)),
+                            'differs_from_hashed_draws': bool(not np.array_equal(n_lab, r_lab))}
         # pixels: the routed path resizes with OpenCV's fixed-point arithmetic, the unrouted one with the harness's PIL stand-in for
         # cv2 -- compared loosely (same crop, same scale, same mean subtraction: a shifted or mis-scaled chip would be far off)
         dr, du = host(br.data[0]), host(bu.data[0])
