@@ -317,6 +317,15 @@ int sn_bn_global_scale_shift(const float *gamma, const float *beta, const float 
                              float *scale, float *shift, sn_stream_t stream);
 int sn_bn_apply(const void *x, void *y, int M, int C, int ps_in, int ps_out, const float *scale, const float *shift, int relu,
                 sn_stream_t stream); /* relu: 0 none, 1 ReLU, 2 ReLU6 = clip(0,6); same code in sn_bn_backward */
+/* sn_bn_finalize_blocks + sn_bn_apply, optionally in ONE launch: with few partial rows (nblk <= 160, C % 64 == 0 -- the convolution row tiles
+ * of a 20-chip stage-3 / stage-4 map) every applying workgroup owns a 64-channel slab and reduces the slab's partials itself, in
+ * sn_bn_finalize_blocks' summation order (same scale / shift / saved statistics / moving averages, bit for bit); otherwise the two
+ * launches.  sn_bn_backward_blocks folds its finalize into the dx pass under the same condition.
+ * OPT-IN: sn_debug_option("bn_fused_finalize", 1) (SNIPER_BN_FUSED_FINALIZE); by default both entries issue the separate launches --
+ * in the training step the fused form measured 1.1 ms per step SLOWER (profiles/r06_ab_bn_fused.txt). */
+int sn_bn_apply_blocks(const float *partials, int nblk, const void *x, void *y, int M, int C, int ps_in, int ps_out, float eps,
+                       float momentum, const float *gamma, const float *beta, float *run_mean, float *run_var, float *scale,
+                       float *shift, float *save_mean, float *save_invstd, int relu, sn_stream_t stream);
 int sn_bn_backward(const void *dy, const void *x, const void *accumulate, void *dx, int M, int C, int ps_dy, int ps_x, int ps_acc,
                    int ps_dx, const float *scale, const float *shift, const float *mean, const float *invstd, int relu, void *ws,
                    float *dgamma, float *dbeta, sn_stream_t stream);

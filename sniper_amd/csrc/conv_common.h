@@ -50,6 +50,7 @@ struct ConvParams {
   half_t *out2 = nullptr;
   const float *o2_scale = nullptr, *o2_shift = nullptr;
   int out2_ps = 0, o2_relu = 0;
+  int tiles_per_wg = 1;    // persistent configurations (24, 26): output tiles a workgroup walks (conv_dma.hip PERSIST; set by the launcher)
   float *stats = nullptr;  // optional BatchNorm statistics of the output: per row tile [mt][2][Nout] = sum, sum of squares of the
                        // STORED fp16 values (what bn_stats_kernel would read back), or null
 };
@@ -71,7 +72,16 @@ __device__ __forceinline__ int conv_fastdiv(int n, unsigned mul, unsigned sh) { 
 
 // LDS-DMA pipelined implicit-GEMM kernels (conv_dma.hip).  cfg: see conv_dma_config().
 struct ConvDmaConfig { int bm, bn, threads, stages, lds_bytes; };
-constexpr int kConvDmaConfigs = 18;    // highest configuration number (the table has holes: conv_dma_config(c).bm == 0)
+// persistent twins of the 160 x 128 configurations (24 of 14, 26 of 16): a launch qualifies when its tiles divide over the resident
+// workgroups -- whole tiles only (M % bm == 0, Nout % bn == 0, row tiles a multiple of 8), no parity classes, no split
+constexpr int kConvPersistWgs = 512;      // 2 workgroups per CU x 256 CUs
+static inline int conv_persist_tiles_per_wg(int M, int Nout, int bm, int bn) {
+  if (M % bm || Nout % bn) return 0;
+  const long mt = M / bm, nt = Nout / bn, tiles = mt * nt;
+  if (mt % 8 || tiles < 2 * kConvPersistWgs || tiles % kConvPersistWgs) return 0;
+  return (int)(tiles / kConvPersistWgs);
+}
+constexpr int kConvDmaConfigs = 26;    // highest configuration number (the table has holes: conv_dma_config(c).bm == 0)
 ConvDmaConfig conv_dma_config(int cfg);
 int conv_dma_launch(const ConvParams &p, bool dgrad, int cfg, hipStream_t s);
 void conv_dma_set_trace(unsigned long long *buf);

@@ -19,7 +19,7 @@
 //     round 1's attempt a no-gain.
 //
 // The tile shape is a template parameter set (BM x BN outputs, WMW x WNW waves, S stages); conv_plan() in conv.hip picks
-// one per layer from the measured table (tools/conv_tune.py).  Seven configurations are instantiated (kCfg below).
+// one per layer from the measured table (tools/conv_tune.py).  Nine configurations are instantiated (kCfg below).
 #include "conv_common.h"
 #include <type_traits>
 
@@ -56,9 +56,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 // costs the longer of the two (the same split made the weight gradient's K loop 2x faster: conv_wgrad_ps.hip).  The consumers keep
 // the two 32-channel halves of a K-step in two register sets; the step's barrier sits between the two MFMA blocks and every set is
 // re-read for the next half right behind the block that used it, so no step begins with barrier -> ds_read -> wait.
-template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false>
+//
+// PERSIST (round 6): the workgroup walks `tpw` output tiles (tile b, b + G, b + 2 G, ... of the XCD-ordered list, G = the grid) as ONE
+// pipeline: the stage ring does not drain at a tile boundary -- the last K-step of tile k issues the first stage of tile k + 1, which
+// lands under that step's MFMAs, and the residual / BatchNorm-input tile of k + 1 is requested from inside the epilogue of k (each
+// register group right after the epilogue consumed it), so the fill that every workgroup of the one-tile-per-workgroup launch pays
+// in front of its first MFMA (profiles/r05_conv_trace_s3.txt: 8 of a workgroup's 28 thousand cycles on the 4-K-step layers, more
+// with a cold residual) is paid once per workgroup instead of once per tile.  Taken for launches of >= 4 tiles per CU whose tile
+// count divides over the 512 resident workgroups (conv_dma_choice: the stage-3 expansions forward, the reductions' data gradients,
+// stages 2 and 4).  The statistics scratch sits behind the ring (the ring is live while a tile's statistics are reduced).
+template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false, bool PERSIST = false>
 __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dma_kernel(const ConvParams p, int mtiles, int ntiles) {
   constexpr int NW = WMW * WNW, T = 64 * (NW + (PS ? 4 : 0)), BK = 64;
+  static_assert(!PERSIST || (!PS && S == 2), "the persistent tile loop is written for the two-stage unspecialised pipeline");
   constexpr int NL = PS ? 4 : NW;                       // waves that stage the tiles
   constexpr int WTM = BM / WMW, WTN = BN / WNW;   // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;
@@ -74,23 +84,32 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   static_assert(PA >= NL * (AGW - 1) + 1 && PB >= NL * (BGW - 1) + 1 && (AGW == 1 ? PA >= NL : true) && (BGW == 1 ? PB >= NL : true),
                 "a wave's repeated piece must exist");
   static_assert((S - 1) * L < 64, "vmcnt is a 6-bit counter");
-  __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE];
+  constexpr int RED = PERSIST ? WMW * 2 * BN * 2 : 0;   // half_t elements of the statistics scratch behind the ring ([wm][2][BN] floats)
+  __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE + RED];
 
   // split-K forward: grid copy z of the tile grid walks its own K range into its own fp32 slab (ConvParams::ksplit)
-  constexpr bool kSplitOk = !DGRAD && BM * BN <= 160 * 128;      // (few-tile launches never take the 8-fragment-wide tiles)
+  constexpr bool kSplitOk = !PERSIST && !DGRAD && BM * BN <= 160 * 128;      // (few-tile launches never take the 8-fragment-wide tiles)
   int kz = 0;
   int lin = blockIdx.x;
   if (kSplitOk && p.ksplit > 1) {
     kz = lin / p.ksplit_grid;
     lin -= kz * p.ksplit_grid;
   }
-  const int xcd = lin & 7, j = lin >> 3;
-  const int nt = j % ntiles, mt = (j / ntiles) * 8 + xcd;
-  if (mt >= mtiles) return;
+  // tile `lin` of the XCD-ordered list -> (row tile, column tile): hardware block b runs on XCD b & 7, and the column tiles that
+  // share a row tile's A panel are neighbours on ONE XCD's L2
+  auto tile_of = [&](int l, int &mt_, int &nt_) {
+    const int xcd = l & 7, j = l >> 3;
+    nt_ = j % ntiles;
+    mt_ = (j / ntiles) * 8 + xcd;
+  };
+  int nt, mt;
+  tile_of(lin, mt, nt);
+  if (!PERSIST && mt >= mtiles) return;     // (a persistent launch has no surplus tiles: launch_one)
+  const int tpw = PERSIST ? p.tiles_per_wg : 1;
   void *const ybase = (kSplitOk && p.ksplit > 1) ? (void *)(reinterpret_cast<float *>(p.y) + (size_t)kz * p.ksplit_stride) : p.y;
   // stride-2 data gradient by parity class (ConvParams::cls): row tile mt = (class, tile of the class's rows)
   // (not instantiated for the 8-fragment-wide tiles: their epilogue has no register to spare, and no stride-2 layer takes them)
-  constexpr bool kClassOk = DGRAD && BM * BN <= 160 * 128;
+  constexpr bool kClassOk = !PERSIST && DGRAD && BM * BN <= 160 * 128;
   const bool by_class = kClassOk && p.cls != 0;
   int mt_l = mt, cls_ph = 0, cls_pw = 0;
   if (by_class) {
@@ -125,10 +144,10 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   const int lw = PS ? (producer ? wave - NW : 0) : wave;   // index among the staging waves
   const int cw = producer ? 0 : wave;                      // index among the multiplying waves
   const int wm = cw / WNW, wn = cw % WNW;
-  const int m0 = mt_l * BM, n0 = nt * BN;
+  int m0 = mt_l * BM, n0 = nt * BN;       // the tile being MULTIPLIED / stored (PERSIST: advanced per tile; the gather state below runs ahead)
   const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;   // row inside an 8-row group, global 16-byte chunk
 
-  // ---- per-lane gather state: A rows m0 + 8 (wave + NW i) + lrow
+  // ---- per-lane gather state of the tile being FETCHED: A rows m0 + 8 (wave + NW i) + lrow
   int a_base[AGW], a_h[AGW], a_w[AGW];
   bool a_ok[AGW];
   int a_grp[AGW], b_grp[BGW];          // wave-uniform group index of this wave's i-th piece
@@ -136,16 +155,19 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   for (int i = 0; i < AGW; ++i) a_grp[i] = (lw + NL * i < PA) ? lw + NL * i : lw + NL * (i - 1);
 #pragma unroll
   for (int i = 0; i < BGW; ++i) b_grp[i] = (lw + NL * i < PB) ? lw + NL * i : lw + NL * (i - 1);
+  auto gather_rows = [&](int gm0) {
 #pragma unroll
-  for (int i = 0; i < AGW; ++i) {
-    const int m = m0 + 8 * a_grp[i] + lrow;
-    a_ok[i] = m < Mrows;
-    int img, oy, ox;
-    row_decompose(a_ok[i] ? m : 0, img, oy, ox);
-    a_base[i] = img * p.H * p.W;
-    if (DGRAD) { a_h[i] = oy + p.pad; a_w[i] = ox + p.pad; }
-    else { a_h[i] = oy * p.stride - p.pad; a_w[i] = ox * p.stride - p.pad; }
-  }
+    for (int i = 0; i < AGW; ++i) {
+      const int m = gm0 + 8 * a_grp[i] + lrow;
+      a_ok[i] = m < Mrows;
+      int img, oy, ox;
+      row_decompose(a_ok[i] ? m : 0, img, oy, ox);
+      a_base[i] = img * p.H * p.W;
+      if (DGRAD) { a_h[i] = oy + p.pad; a_w[i] = ox + p.pad; }
+      else { a_h[i] = oy * p.stride - p.pad; a_w[i] = ox * p.stride - p.pad; }
+    }
+  };
+  gather_rows(m0);
   const int taps = p.KH * p.KW;
   const int kpt = p.Cin / BK;          // host guarantees Cin % 64 == 0
   // taps this workgroup walks: all of them, or (by class, stride 2, dilation 1) those of its parity: kh = kh0, kh0 + 2, ...
@@ -163,15 +185,18 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   const unsigned in_ps_bytes = (unsigned)p.in_ps * 2u;
   constexpr unsigned kOob = 0xFFFFFF00u;
   unsigned w_voff[BGW];
+  auto gather_cols = [&](int gn0) {
 #pragma unroll
-  for (int i = 0; i < BGW; ++i) {
-    // LDS row r of the weight tile holds output channel n0 + perm(r): fragment pair (2j, 2j+1), MFMA row ii = 4 fq + rr
-    // -> channel 32 j + 8 (ii >> 2) + 4 (jn & 1) + (ii & 3), so that a lane's two accumulators of a pair are EIGHT consecutive
-    // channels of its pixel (16-byte epilogue loads / stores).  The permutation lives in the DMA source address only.
-    const int r = 8 * b_grp[i] + lrow;
-    const int n = n0 + (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
-    w_voff[i] = n < p.Nout ? (unsigned)n * wrow_bytes + (unsigned)gchunk * 16u : kOob;
-  }
+    for (int i = 0; i < BGW; ++i) {
+      // LDS row r of the weight tile holds output channel n0 + perm(r): fragment pair (2j, 2j+1), MFMA row ii = 4 fq + rr
+      // -> channel 32 j + 8 (ii >> 2) + 4 (jn & 1) + (ii & 3), so that a lane's two accumulators of a pair are EIGHT consecutive
+      // channels of its pixel (16-byte epilogue loads / stores).  The permutation lives in the DMA source address only.
+      const int r = 8 * b_grp[i] + lrow;
+      const int n = gn0 + (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
+      w_voff[i] = n < p.Nout ? (unsigned)n * wrow_bytes + (unsigned)gchunk * 16u : kOob;
+    }
+  };
+  gather_cols(n0);
   int g_kh = kh0, g_kw = kw0, g_kc = 0;   // next stage to issue: tap (g_kh, g_kw), channel block g_kc
   if (kSplitOk && t_begin > 0) {            // (split-K: start in the middle of the walk; forward launches are never by class)
     const int tap = t_begin / kpt;
@@ -220,11 +245,28 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     }
   };
 
+  // (PERSIST) position the fetch side at K-step `step` of tile l.  The gather registers are re-derived at every tile boundary and
+  // again behind the epilogue, so that they are dead while the epilogue runs (its own pressure is the kernel's peak)
+  auto fetch_seek = [&](int l, int step) {
+    int fmt, fnt;
+    tile_of(l, fmt, fnt);
+    gather_rows(fmt * BM);
+    gather_cols(fnt * BN);
+    const int tap = step / kpt;
+    g_kc = step - tap * kpt;
+    g_kh = tap / p.KW;
+    g_kw = tap - g_kh * p.KW;
+    tap_setup();
+  };
+
   floatx4 acc[MI][NI];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int jn = 0; jn < NI; ++jn) acc[i][jn] = floatx4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
 
   const int fr = lane & 15, fq = lane >> 4;
   const int sw = fq ^ (fr & 7);
@@ -262,20 +304,20 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   const bool pre_res = kPre && p.res != nullptr && vec8;
   // the BatchNorm input a fused backward reduction reads (sn_conv_dgrad_bn) takes the same slot when there is no residual
   const bool pre_bnx = kPre && p.res == nullptr && p.bn_x != nullptr && p.stats != nullptr && vec8 && p.bn_x_ps % 8 == 0;
+  const half_t *const pre_src = pre_res ? p.res : p.bn_x;
+  const int pre_ps = pre_res ? p.res_ps : p.bn_x_ps;
+  // group (i, jp) of the tile at (pm0, pn0)
+  auto pre_load = [&](int pm0, int pn0, int i, int jp) {
+    const int mr = pm0 + wm * WTM + i * 16 + (lane & 15);
+    const int m = row_pixel(mr < Mrows ? mr : 0);
+    const int n = pn0 + wn * WTN + jp * 32 + (lane >> 4) * 8;
+    return (mr < Mrows && n < p.Nout) ? *reinterpret_cast<const half8 *>(pre_src + (size_t)m * pre_ps + n) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+  };
   if constexpr (kPre) if ((pre_res || pre_bnx) && !producer) {
-    const half_t *src = pre_res ? p.res : p.bn_x;
-    const int src_ps = pre_res ? p.res_ps : p.bn_x_ps;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int mr = m0 + wm * WTM + i * 16 + (lane & 15);
-      const int m = row_pixel(mr < Mrows ? mr : 0);
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) {
-        const int n = n0 + wn * WTN + jp * 32 + (lane >> 4) * 8;
-        rpre[i][jp] = (mr < Mrows && n < p.Nout) ? *reinterpret_cast<const half8 *>(src + (size_t)m * src_ps + n)
-                                              : half8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    }
+      for (int jp = 0; jp < NP; ++jp) rpre[i][jp] = pre_load(m0, n0, i, jp);
   }
 
   if constexpr (PS) {
@@ -354,7 +396,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
         mma(fa1, fb1);
       }
     }
-  } else {
+  } else if constexpr (!PERSIST) {
     // ---- pipeline: stages t+1 .. t+S-1 in flight under compute(t); one barrier per K-step
   #pragma unroll
     for (int s = 0; s < S - 1; ++s)
@@ -390,6 +432,9 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     }
   }
 
+  // ---- everything behind a tile's last MFMA: epilogue stores and the statistics partials.  PERSIST: `has_next` -- the workgroup
+  // has another tile, at (nm0, nn0): its residual / BatchNorm-input groups are requested as the epilogue releases their registers
+  auto finish_tile = [&](bool has_next, int nm0, int nn0) {
   stamp(2);
   // ---- epilogue: lane (fr, fq) holds, for each (i, jp), pixel m = ..+fr and the 8 channels n = ..+fq*8 .. +7 (first four in
   // the accumulator of fragment 2 jp, last four in that of 2 jp + 1: the weight-row permutation above)
@@ -528,6 +573,9 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
               }
             }
           }
+          if constexpr (PERSIST && kPre) {   // this group's registers are free: the same group of the workgroup's NEXT tile
+            if (has_next && (pre_res || pre_bnx)) rpre[i][jp] = pre_load(nm0, nn0, i, jp);
+          }
         } else if constexpr (PATH == 1) {   // 8-byte groups, each with its own bound (Nout = 84, ...)
   #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -591,8 +639,18 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
         st_s[jp][r] = row16_sum(st_s[jp][r]);
         st_q[jp][r] = row16_sum(st_q[jp][r]);
       }
-    float *red = reinterpret_cast<float *>(lds);   // [wm][2][BN]
-    __syncthreads();
+    // [wm][2][BN]; PERSIST: behind the ring (the next tile's first stage already sits in it) and between raw barriers (a
+    // __syncthreads would also wait for the epilogue's stores and the next tile's residual requests)
+    float *red = reinterpret_cast<float *>(lds + (PERSIST ? S * STAGE : 0));
+    auto sync = [&]() {
+      if constexpr (PERSIST) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      } else {
+        __syncthreads();
+      }
+    };
+    sync();
     if (fr == 0 && !producer) {
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp)
@@ -603,7 +661,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
           red[(wm * 2 + 1) * BN + c] = st_q[jp][r];
         }
     }
-    __syncthreads();
+    sync();
     for (int idx = tid; idx < 2 * BN; idx += T) {
       const int which = idx / BN, col = idx - which * BN;
       const int n = n0 + col;
@@ -616,6 +674,41 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     }
   }
   stamp(4);
+  };   // finish_tile
+
+  if constexpr (PERSIST) {
+    // ---- the workgroup's tiles as ONE two-stage pipeline: g counts K-steps across tiles; stage g + 1 (possibly the next tile's first)
+    // is issued behind barrier g and lands under compute(g)
+    const int total = tpw * nk;
+    issue(0);
+    int cur = 0, g = 0;
+    for (int seq = 0; seq < tpw; ++seq) {
+      for (int t = 0; t < nk; ++t, ++g) {
+        if (t > 0 || seq == 0) wait_vmcnt<0>();   // stage g has landed (this wave's part; a tile's first stage was waited for in front of the epilogue before it)
+        __builtin_amdgcn_s_barrier();     // ... everybody's part has, and everybody is done with stage g - 1 (and its tile's statistics scratch)
+        if (g == 0) stamp(1);
+        if (g + 1 < total) {
+          if (t == nk - 1) fetch_seek(lin + (seq + 1) * (int)gridDim.x, 0);    // the next tile's first stage
+          issue(cur ^ 1);
+        }
+        compute(cur);
+        cur ^= 1;
+      }
+      // the next tile's first stage was issued one compute phase ago: wait for it HERE, so that nothing the epilogue issues (stores,
+      // the next residual tile) stands between that stage and the first barrier of the next tile's loop
+      wait_vmcnt<0>();
+      const bool has_next = seq + 1 < tpw;
+      int nmt = mt, nnt = nt;
+      if (has_next) tile_of(lin + (seq + 1) * (int)gridDim.x, nmt, nnt);
+      finish_tile(has_next, nmt * BM, nnt * BN);
+      mt = nmt; nt = nnt;
+      m0 = mt * BM; n0 = nt * BN;
+      zero_acc();
+      if (has_next && nk > 1) fetch_seek(lin + (seq + 1) * (int)gridDim.x, 1);
+    }
+  } else {
+    finish_tile(false, 0, 0);
+  }
 }
 
 // cfg -> tile shape.  LDS = stages * (bm + bn) * 128 B.  The numbers are those of round 2's seventeen-entry table (profiles/r02_conv_tune*.txt
@@ -636,16 +729,28 @@ static const ConvDmaConfig kCfg[kConvDmaConfigs + 1] = {
     {0, 0, 0, 0, 0},
     // producer / consumer specialised (round 3): 4 multiplying waves (2 x 2) + 4 staging waves, one workgroup per CU
     {160, 128, 512, 4, 4 * 288 * 128},   // 18: 144 KB, wave tile 80 x 64: long contractions with about one tile per CU
+    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
+    // persistent tile loop (round 6; PERSIST in conv_dma_kernel): 512 workgroups walk tiles / 512 tiles each as one pipeline
+    {160, 128, 256, 2, 2 * 288 * 128 + 2048},   // 24: 14's shape (forward)
+    {0, 0, 0, 0, 0},
+    {160, 128, 512, 2, 2 * 288 * 128 + 2048},   // 26: 16's shape (data gradient)
 };
 
 ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConfigs) ? kCfg[cfg] : kCfg[0]; }
 
-template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false>
+template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false, bool PERSIST = false>
 static void launch_one(const ConvParams &p, hipStream_t s) {
   const int mtiles = (DGRAD && p.cls && BM * BN <= 160 * 128) ? 4 * sn_div_up(p.cls_mc, BM) : sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
   const int base = sn_div_up(mtiles, 8) * 8 * ntiles;
   ConvParams q = p;
   q.ksplit_grid = base;
+  if constexpr (PERSIST) {
+    q.tiles_per_wg = conv_persist_tiles_per_wg(p.M, p.Nout, BM, BN);      // (conv_plan chose this configuration only where it is > 0)
+    q.ksplit = 1;
+    hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS, true>), dim3((unsigned)(base / q.tiles_per_wg)),
+                       dim3(64 * WMW * WNW), 0, s, q, mtiles, ntiles);
+    return;
+  }
   const dim3 grid((unsigned)base * (unsigned)((!DGRAD && p.ksplit > 1 && BM * BN <= 160 * 128) ? p.ksplit : 1));
   hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, q, mtiles, ntiles);
 }
@@ -660,6 +765,8 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
     case 14: launch_one<DGRAD, 160, 128, 2, 2, 2, 2>(p, s); break;
     case 16: launch_one<DGRAD, 160, 128, 2, 4, 2, 2>(p, s); break;
     case 18: launch_one<DGRAD, 160, 128, 2, 2, 4, 1, true>(p, s); break;
+    case 24: launch_one<DGRAD, 160, 128, 2, 2, 2, 2, false, true>(p, s); break;
+    case 26: launch_one<DGRAD, 160, 128, 2, 4, 2, 2, false, true>(p, s); break;
     default: SN_REQUIRE(false, "conv_dma_launch: unknown configuration %d", cfg);
   }
   SN_CHECK_LAUNCH();

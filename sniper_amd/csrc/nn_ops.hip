@@ -72,6 +72,28 @@ __device__ __forceinline__ bool bn_act_pass(float y, int act) {
   return act == 0 || (act == 1 ? y > 0.f : (y >= 0.f && y <= 6.f));
 }
 
+// The per-channel coefficients and the per-element forms, spelled with explicit roundings: the same values come out of the separate
+// finalize kernels and out of the consumers that fold the finalize into themselves (bn_apply_fin_kernel / bn_bwd_dx_fin_kernel),
+// whatever the compiler would contract in either context.
+__device__ __forceinline__ void bn_fwd_coefs(double mean, double var, float eps, float g, float beta, float &sc, float &sh, float &invstd) {
+  invstd = (float)(1.0 / sqrt(var + (double)eps));
+  sc = __fmul_rn(g, invstd);
+  sh = __fsub_rn(beta, __fmul_rn(__fmul_rn((float)mean, g), invstd));
+}
+__device__ __forceinline__ float bn_running(float run, float stat, float momentum) {
+  return __fmaf_rn(run, momentum, __fmul_rn(stat, 1.f - momentum));
+}
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return __fmaf_rn(x, sc, sh); }
+// dx = scale * (g - dbeta/M - xhat*dgamma/M) [+ acc] = sc*g + kb*x + kd
+__device__ __forceinline__ void bn_dx_coefs(float sc, float invstd, float mean, float dgamma, float dbeta, float invM, float &kb, float &kd) {
+  const float t = __fmul_rn(__fmul_rn(invstd, dgamma), invM);   // xhat coefficient / scale
+  kb = -__fmul_rn(sc, t);
+  kd = __fmul_rn(sc, __fmaf_rn(mean, t, -__fmul_rn(dbeta, invM)));
+}
+__device__ __forceinline__ float bn_dx_value(float sc, float gf, float kb, float xf, float kd, float a) {
+  return __fadd_rn(__fmaf_rn(sc, gf, __fmaf_rn(kb, xf, kd)), a);
+}
+
 struct BnMap {
   int cb, rpp, chunk, rl;
   bool on;
@@ -183,15 +205,16 @@ __global__ __launch_bounds__(kBnFinThreads) void bn_finalize_kernel(const float 
   const double mean = sum / M;
   double var = sumsq / M - mean * mean;  // biased
   if (var < 0) var = 0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f;
-  scale[c] = g * invstd;
-  shift[c] = beta[c] - (float)mean * g * invstd;
+  float sc, sh, invstd;
+  bn_fwd_coefs(mean, var, eps, g, beta[c], sc, sh, invstd);
+  scale[c] = sc;
+  shift[c] = sh;
   save_mean[c] = (float)mean;
   save_invstd[c] = invstd;
   if (run_mean) {
-    run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
-    run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+    run_mean[c] = bn_running(run_mean[c], (float)mean, momentum);
+    run_var[c] = bn_running(run_var[c], (float)var, momentum);
   }
 }
 
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const half_t *__restrict_
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float f = (float)v[j] * scale[chunk * 8 + j] + shift[chunk * 8 + j];
+      float f = bn_affine((float)v[j], scale[chunk * 8 + j], shift[chunk * 8 + j]);
       if (relu) f = f > 0.f ? f : 0.f;
       if (relu == 2) f = f < 6.f ? f : 6.f;   // relu6 = clip(0, 6) (mobilenetv2_e2e.py:18-19)
       o[j] = (half_t)f;
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
       for (int j = 0; j < 8; ++j) {
         const float xf = (float)v[j];
         float gf = (float)g[j];
-        if (!bn_act_pass(xf * sc[j] + sh[j], relu)) gf = 0.f;
+        if (!bn_act_pass(bn_affine(xf, sc[j], sh[j]), relu)) gf = 0.f;
         s[j] += gf;
         q[j] += gf * (xf - mu[j]);
       }
@@ -309,9 +332,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
   for (int j = 0; j < 8; ++j) {
     const int c = m.chunk * 8 + j;
     sc[j] = scale[c]; sh[j] = shift[c];
-    const float t = invstd[c] * dgamma[c] * invM;   // xhat coefficient / scale
-    kb[j] = -sc[j] * t;
-    kd[j] = sc[j] * (mean[c] * t - dbeta[c] * invM);
+    bn_dx_coefs(sc[j], invstd[c], mean[c], dgamma[c], dbeta[c], invM, kb[j], kd[j]);
   }
   const half_t *pg = dy + m.chunk * 8, *px = x + m.chunk * 8, *pa = acc ? acc + m.chunk * 8 : nullptr;
   half_t *po = dx + m.chunk * 8;
@@ -321,8 +342,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
     for (int j = 0; j < 8; ++j) {
       const float xf = (float)v[j];
       float gf = (float)g[j];
-      if (!bn_act_pass(xf * sc[j] + sh[j], relu)) gf = 0.f;
-      o[j] = (half_t)(sc[j] * gf + kb[j] * xf + kd[j] + (float)a[j]);
+      if (!bn_act_pass(bn_affine(xf, sc[j], sh[j]), relu)) gf = 0.f;
+      o[j] = (half_t)bn_dx_value(sc[j], gf, kb[j], xf, kd[j], (float)a[j]);
     }
     *reinterpret_cast<half8 *>(po + r * ps_dx) = o;
   };
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dx_kernel(const half_t *__r
 // bn_sum_partials -- lane rl takes k = rl, rl + 32, ..., the 32 lanes are added 0 .. 31 -- so the coefficients are bit-identical to
 // the separate kernel's, and then streams its rows.  The workgroups of row block 0 also write the per-channel outputs (scale /
 // shift / saved statistics / moving averages; dgamma / dbeta) that later launches read.  Taken when nblk <= kBnFusedMaxBlocks and
-// C % 64 == 0 (every train-mode BatchNorm of stages 3 - 4: 128 row tiles); otherwise the separate finalize launch stays.
+// C % 64 == 0 (every train-mode BatchNorm of stages 3 - 4: 128 row tiles) AND the option is on; otherwise the separate finalize launch stays.
 constexpr int kBnSlab = 64;              // channels per workgroup
 constexpr int kBnFusedMaxBlocks = 160;   // partial rows a workgroup re-reduces (64 independent loads per thread at 128)
 __device__ __forceinline__ void bn_slab_partials(const float *__restrict__ part, int nblk, int C, int c0, double (*red)[32][kBnSlab + 1],
@@ -405,9 +426,9 @@ __global__ __launch_bounds__(256) void bn_apply_fin_kernel(const float *__restri
     const double mean = sum / M;
     double var = sumsq / M - mean * mean;  // biased
     if (var < 0) var = 0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f;
-    const float sc = g * invstd, sh = beta[c] - (float)mean * g * invstd;
+    float sc, sh, invstd;
+    bn_fwd_coefs(mean, var, eps, g, beta[c], sc, sh, invstd);
     coef[0][threadIdx.x] = sc;
     coef[1][threadIdx.x] = sh;
     if (blockIdx.x == 0) {
@@ -416,8 +437,8 @@ __global__ __launch_bounds__(256) void bn_apply_fin_kernel(const float *__restri
       save_mean[c] = (float)mean;
       save_invstd[c] = invstd;
       if (run_mean) {
-        run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
-        run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+        run_mean[c] = bn_running(run_mean[c], (float)mean, momentum);
+        run_var[c] = bn_running(run_var[c], (float)var, momentum);
       }
     }
   }
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(256) void bn_apply_fin_kernel(const float *__restri
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float f = (float)v[j] * sc[j] + sh[j];
+      float f = bn_affine((float)v[j], sc[j], sh[j]);
       if (relu) f = f > 0.f ? f : 0.f;
       if (relu == 2) f = f < 6.f ? f : 6.f;
       o[j] = (half_t)f;
@@ -469,11 +490,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(const float *__restr
     const float db = (float)sg, dg = (float)(sgx * (double)invstd[c]);
     const float invM = 1.f / (float)M;
     const float scv = scale[c];
-    const float t = invstd[c] * dg * invM;   // xhat coefficient / scale
+    float kb, kd;
+    bn_dx_coefs(scv, invstd[c], mean[c], dg, db, invM, kb, kd);
     coef[0][threadIdx.x] = scv;
     coef[1][threadIdx.x] = shift[c];
-    coef[2][threadIdx.x] = -scv * t;
-    coef[3][threadIdx.x] = scv * (mean[c] * t - db * invM);
+    coef[2][threadIdx.x] = kb;
+    coef[3][threadIdx.x] = kd;
     if (blockIdx.x == 0) {
       if (fin) { fin[c] = db; fin[C + c] = dg; }
       if (dbeta) dbeta[c] += db;
@@ -497,8 +519,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(const float *__restr
     for (int j = 0; j < 8; ++j) {
       const float xf = (float)v[j];
       float gf = (float)g[j];
-      if (!bn_act_pass(xf * sc[j] + sh[j], relu)) gf = 0.f;
-      o[j] = (half_t)(sc[j] * gf + kb[j] * xf + kd[j] + (float)a[j]);
+      if (!bn_act_pass(bn_affine(xf, sc[j], sh[j]), relu)) gf = 0.f;
+      o[j] = (half_t)bn_dx_value(sc[j], gf, kb[j], xf, kd[j], (float)a[j]);
     }
     *reinterpret_cast<half8 *>(po + r * ps_dx) = o;
   };
@@ -521,11 +543,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(const float *__restr
          pa ? *reinterpret_cast<const half8 *>(pa + (size_t)r * ps_acc) : zero, (size_t)r);
 }
 
-// A/B and test switch (sn_debug_option "bn_fused_finalize"): 0 = the separate finalize launches everywhere
-static std::atomic<int> g_bn_fused_finalize{1};
-void bn_set_fused_finalize(int on) { g_bn_fused_finalize.store(on ? 1 : 0, std::memory_order_relaxed); }
+// OPT-IN (sn_debug_option("bn_fused_finalize", 1) / SNIPER_BN_FUSED_FINALIZE): measured in the step it LOSES -- 22.09 vs 20.97 ms per step
+// (profiles/r06_ab_bn_fused.txt, same card, interleaved): a slab workgroup re-reads 64 KB of partials for the 40 - 80 KB it streams
+// and starts streaming only behind that dependent chain, so each of the 180 fused launches is ~11 us slower than the streaming
+// kernel it replaces and saves a 5 us launch.  The partials would have to be ~8x fewer for this to pay.
 static bool bn_fused_ok(int nblk, int M, int C) {
-  return g_bn_fused_finalize.load(std::memory_order_relaxed) != 0 && nblk <= kBnFusedMaxBlocks && C % kBnSlab == 0 && M >= 1024;
+  return sn_debug_get(SN_OPT_BN_FUSED_FINALIZE) != 0 && nblk <= kBnFusedMaxBlocks && C % kBnSlab == 0 && M >= 1024;
 }
 // grid of the slab-owning kernels: about 1024 workgroups, >= 128 rows each (one unrolled pass of the 32 row lanes)
 static dim3 bn_slab_grid(int M, int C, int *rows_per_block) {

@@ -213,9 +213,11 @@ class BatchNormStep(Step):
             if self.bws is None:
                 self.bws = ex.empty((hip.query('sn_bn_workspace_bytes', M, c),), torch.uint8)
             if self.stats_from is not None:
+                # finalize + apply in one launch (the applying workgroups reduce the partials of their own channel slab)
                 part, nblk = self.stats_from
-                hip.call('sn_bn_finalize_blocks', part, nblk, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,
-                         self.var, self.scale, self.shift, self.save_mean, self.save_invstd, hip.stream())
+                hip.call('sn_bn_apply_blocks', part, nblk, x, self.y.t, M, c, c, c, self.eps, self.momentum, g, self.beta.master,
+                         self.mean, self.var, self.scale, self.shift, self.save_mean, self.save_invstd, self.act, hip.stream())
+                return
             else:
                 hip.call('sn_bn_stats', x, M, c, c, self.bws, hip.stream())
                 hip.call('sn_bn_finalize', self.bws, M, c, self.eps, self.momentum, g, self.beta.master, self.mean,

@@ -341,6 +341,52 @@ def test_batchnorm_train_fwd_bwd():
         assert_close(from_nhwc(dx), xt.grad.numpy(), 1e-2, 1e-2 * np.abs(xt.grad.numpy()).max(), 'bn dx')
 
 
+@pytest.mark.parametrize('M,C,nblk,relu', [(20480, 256, 128, 1), (20480, 1024, 128, 1), (2048, 64, 13, 0), (5000, 192, 160, 2),
+                                           (20480, 256, 512, 1), (3000, 72, 19, 1)])
+def test_bn_finalize_fused_into_apply_and_dx_equals_the_separate_launches(M, C, nblk, relu):
+    """sn_bn_apply_blocks / sn_bn_backward_blocks (round 6: the finalize launch folded into the consumer, which re-reduces the
+    partials of its own 64-channel slab in the separate kernel's summation order) against the separate launches
+    (the default; the fused form is opt-in, sn_debug_option bn_fused_finalize: in the step it measured slower): every output BIT-equal -- y, scale, shift, saved statistics, moving averages; dx, dgamma,
+    dbeta (accumulated onto a non-zero arena).  nblk = 512 and C = 72 are shapes that keep the separate launches either way."""
+    hip = _hip()
+    rs = np.random.RandomState(M + C + nblk)
+    td = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dev()).to(dt)
+    x = td(rs.standard_normal((M, C)) * 1.5 + 0.3, torch.float16)
+    dy = td(rs.standard_normal((M, C)), torch.float16)
+    acc = td(rs.standard_normal((M, C)), torch.float16)
+    xf = x.float()
+    # partials as a producer would leave them: per row block sums of x and x^2 (any split of the rows into nblk blocks)
+    edges = np.linspace(0, M, nblk + 1).astype(int)
+    part = torch.stack([torch.stack((xf[a:b].sum(0), (xf[a:b] ** 2).sum(0))) for a, b in zip(edges[:-1], edges[1:])]).contiguous()
+    bpart = td(rs.standard_normal((nblk, 2, C)) * 3)
+    gamma, beta = td(rs.uniform(0.5, 1.5, C)), td(rs.standard_normal(C) * 0.1)
+    ws = torch.empty(hip.query('sn_bn_workspace_bytes', M, C), dtype=torch.uint8, device=dev())
+    res = []
+    for fused in (0, 1):
+        hip.call('sn_debug_option', b'bn_fused_finalize', fused)
+        try:
+            f = lambda v=0.0: torch.full((C,), v, dtype=torch.float32, device=dev())
+            sc, sh, sm, si, rm, rv = f(7), f(7), f(7), f(7), f(0.25), f(1.5)
+            y = torch.full((M, C), 7.0, dtype=torch.float16, device=dev())
+            hip.call('sn_bn_apply_blocks', part, nblk, x, y, M, C, C, C, 2e-5, 0.9, gamma, beta, rm, rv, sc, sh, sm, si, relu, hip.stream())
+            dx = torch.full((M, C), 7.0, dtype=torch.float16, device=dev())
+            dg, db = f(0.5), f(-0.5)
+            hip.call('sn_bn_backward_blocks', bpart, nblk, dy, x, acc, dx, M, C, C, C, C, C, sc, sh, sm, si, relu, ws, dg, db, hip.stream())
+            dg2, db2 = f(0.0), f(0.0)          # parameter gradients only (dx = NULL: a BatchNorm on a tensor that needs no gradient)
+            hip.call('sn_bn_backward_blocks', bpart, nblk, dy, x, None, None, M, C, C, C, C, C, sc, sh, sm, si, relu, ws, dg2, db2, hip.stream())
+            torch.cuda.synchronize()
+            res.append([t.clone() for t in (y, sc, sh, sm, si, rm, rv, dx, dg, db, dg2, db2)])
+        finally:
+            hip.call('sn_debug_option', b'bn_fused_finalize', 0)
+    names = 'y scale shift save_mean save_invstd run_mean run_var dx dgamma dbeta dgamma_only dbeta_only'.split()
+    for n, a, b in zip(names, res[0], res[1]):
+        assert torch.equal(a, b), (n, float((a.float() - b.float()).abs().max()))
+    # and the statistics are right: mean / variance of the rows
+    mean, var = xf.double().mean(0), xf.double().var(0, unbiased=False)
+    assert_close(res[1][3].cpu().numpy(), mean.cpu().numpy(), 1e-4, 1e-4, 'saved mean')
+    assert_close(res[1][4].cpu().numpy(), (1.0 / torch.sqrt(var + 2e-5)).cpu().numpy(), 1e-4, 1e-4, 'saved invstd')
+
+
 def test_bn_global_maxpool_ew_layout_ops():
     hip = _hip()
     rs = np.random.RandomState(4)
