@@ -245,10 +245,13 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad, int use_cfg = -1) {
     int cfg = use_cfg > 0 ? use_cfg : (forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, nk, dgrad));
     // the persistent twins (24 / 26) of the 160 x 128 configurations: launches of >= 4 whole tiles per CU that divide over the 512
     // resident workgroups, short contractions (what a tile pays outside its K loop is what the persistent loop overlaps)
-    const bool may_persist = !by_class && p.ksplit <= 1 && conv_persist_tiles_per_wg(p.M, p.Nout, 160, 128) > 0;
-    if (use_cfg <= 0 && forced < 0 && (cfg == 14 || cfg == 16) && may_persist && nk <= 16 && sn_debug_get(SN_OPT_CONV_NO_PERSIST) == 0)
+    // its epilogue: 16-byte fp16 rows, no bias, the residual / BatchNorm-input tile through the register prefetch
+    const bool rows16 = !p.out_f32 && !p.out2 && !p.bias && p.out_ps % 8 == 0 && p.Nout % 8 == 0 && (!p.res || p.res_ps % 8 == 0) &&
+                        (!p.bn_x || (p.stats && !p.res && p.bn_x_ps % 8 == 0));
+    const bool may_persist = !by_class && p.ksplit <= 1 && rows16 && conv_persist_tiles_per_wg(p.M, p.Nout, 160, 128) > 0;
+    if (use_cfg <= 0 && forced < 0 && (cfg == 14 || cfg == 16) && may_persist && nk >= 2 && nk <= 16 && sn_debug_get(SN_OPT_CONV_NO_PERSIST) == 0)
       cfg += 10;
-    if ((cfg == 24 || cfg == 26) && !may_persist) cfg -= 10;      // forced on a launch that does not qualify: the plain twin
+    if ((cfg == 24 || cfg == 26) && (!may_persist || nk < 2)) cfg -= 10;      // forced on a launch that does not qualify: the plain twin
     if (cfg > 0) {
       const ConvDmaConfig c = conv_dma_config(cfg);
       q.dma = cfg;

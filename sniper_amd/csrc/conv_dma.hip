@@ -44,6 +44,30 @@ __device__ __forceinline__ float row16_sum(float v) {
   return dpp_add<0x140>(v);   // row_mirror: lane i <-> 15 - i (the other half row)
 }
 
+// 16-byte global load the compiler's wait-count pass does not see (PERSIST: the next tile's residual rows are requested behind one
+// tile's epilogue and consumed in the next one's; tracked loads in flight across the tile loop's back edge make hipcc drain the
+// whole queue -- vmcnt(0) -- wherever it is unsure, and loads return in order).  The consumer waits by hand: wait_vmcnt + tie().
+__device__ __forceinline__ half8 load16_untracked(const half_t *ptr) {
+  floatx4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+  return __builtin_bit_cast(half8, v);
+}
+// 16-byte LDS read the wait-count pass does not see either: a tracked ds_read of an LDS range an LDS-DMA wrote earlier gets a vmcnt
+// wait in front of it (the pass cannot know that DMA was waited for by hand), which in the epilogue means waiting for the stores
+__device__ __forceinline__ floatx4 lds_read16_untracked(const void *ptr) {
+  floatx4 v;
+  const unsigned a = (unsigned)(unsigned long)(lds_ptr_t)const_cast<void *>(ptr);
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ void tie(floatx4 &v) { asm volatile("" : "+v"(v)); }
+// orders later uses of x behind the asm statements in front of this one (an s_waitcnt): x is "redefined" here
+__device__ __forceinline__ void tie(half8 &x) {
+  floatx4 v = __builtin_bit_cast(floatx4, x);
+  asm volatile("" : "+v"(v));
+  x = __builtin_bit_cast(half8, v);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -85,7 +109,15 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
                 "a wave's repeated piece must exist");
   static_assert((S - 1) * L < 64, "vmcnt is a 6-bit counter");
   constexpr int RED = PERSIST ? WMW * 2 * BN * 2 : 0;   // half_t elements of the statistics scratch behind the ring ([wm][2][BN] floats)
-  __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE + RED];
+  // (PERSIST data gradient) the BatchNorm coefficients of the tile's BN output channels, [scale | shift | mean] x 256 floats (the upper
+  // half of each zero: one 1 KB LDS-DMA piece per vector), fetched by LDS-DMA while the tile's K loop runs: the persistent
+  // kernels contain NO load the compiler's wait-count pass tracks -- a tracked load that may be pending at the tile loop's back edge
+  // (every conditional one is, statically) makes hipcc drain the queue in front of unrelated register writes, and with it the next
+  // tile's residual requests
+  constexpr bool kBnLds = PERSIST && DGRAD;
+  constexpr int COEF = kBnLds ? 3 * 512 : 0;
+  static_assert(!kBnLds || BN <= 128, "one LDS-DMA piece carries 128 coefficients");
+  __shared__ __attribute__((aligned(1024))) half_t lds[S * STAGE + RED + COEF];
 
   // split-K forward: grid copy z of the tile grid walks its own K range into its own fp32 slab (ConvParams::ksplit)
   constexpr bool kSplitOk = !PERSIST && !DGRAD && BM * BN <= 160 * 128;      // (few-tile launches never take the 8-fragment-wide tiles)
@@ -145,7 +177,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   const int cw = producer ? 0 : wave;                      // index among the multiplying waves
   const int wm = cw / WNW, wn = cw % WNW;
   int m0 = mt_l * BM, n0 = nt * BN;       // the tile being MULTIPLIED / stored (PERSIST: advanced per tile; the gather state below runs ahead)
-  const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;   // row inside an 8-row group, global 16-byte chunk
+  int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;   // row inside an 8-row group, global 16-byte chunk
 
   // ---- per-lane gather state of the tile being FETCHED: A rows m0 + 8 (wave + NW i) + lrow
   int a_base[AGW], a_h[AGW], a_w[AGW];
@@ -268,9 +300,19 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   };
   zero_acc();
 
-  const int fr = lane & 15, fq = lane >> 4;
-  const int sw = fq ^ (fr & 7);
-  const int a_rd = (wm * WTM + fr) * BK, b_rd = BM * BK + (wn * WTN + fr) * BK;
+  int fr = lane & 15, fq = lane >> 4;
+  int sw = fq ^ (fr & 7);
+  int a_rd = (wm * WTM + fr) * BK, b_rd = BM * BK + (wn * WTN + fr) * BK;
+  // (PERSIST) the lane-derived constants above are re-derived per tile from an opaque copy of the lane id: as loop invariants they
+  // would all stay live across the epilogue, whose own pressure is the kernel's peak
+  auto rederive_lane_constants = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    lrow = l >> 3; gchunk = (l & 7) ^ lrow;
+    fr = l & 15; fq = l >> 4;
+    sw = fq ^ (fr & 7);
+    a_rd = (wm * WTM + fr) * BK; b_rd = BM * BK + (wn * WTN + fr) * BK;
+  };
   // The product is formed TRANSPOSED (weights as the MFMA A operand): D^T[n][m] puts 4 consecutive output channels
   // n = fq*4 + r of one pixel m = fr into each lane -> 8-byte epilogue stores.
   auto compute = [&](int buf) {
@@ -303,22 +345,27 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   half8 rpre[kPre ? MI : 1][kPre ? NP : 1];
   const bool pre_res = kPre && p.res != nullptr && vec8;
   // the BatchNorm input a fused backward reduction reads (sn_conv_dgrad_bn) takes the same slot when there is no residual
-  const bool pre_bnx = kPre && p.res == nullptr && p.bn_x != nullptr && p.stats != nullptr && vec8 && p.bn_x_ps % 8 == 0;
+  const bool pre_bnx = DGRAD && kPre && p.res == nullptr && p.bn_x != nullptr && p.stats != nullptr && vec8 && p.bn_x_ps % 8 == 0;   // (only sn_conv_dgrad_bn sets bn_x)
   const half_t *const pre_src = pre_res ? p.res : p.bn_x;
   const int pre_ps = pre_res ? p.res_ps : p.bn_x_ps;
   // group (i, jp) of the tile at (pm0, pn0)
   auto pre_load = [&](int pm0, int pn0, int i, int jp) {
     const int mr = pm0 + wm * WTM + i * 16 + (lane & 15);
-    const int m = row_pixel(mr < Mrows ? mr : 0);
     const int n = pn0 + wn * WTN + jp * 32 + (lane >> 4) * 8;
-    return (mr < Mrows && n < p.Nout) ? *reinterpret_cast<const half8 *>(pre_src + (size_t)m * pre_ps + n) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (PERSIST) {       // whole tiles only (launch_one): no bounds, and a load the compiler does not track
+      return load16_untracked(pre_src + (size_t)mr * pre_ps + n);
+    } else {
+      const int m = row_pixel(mr < Mrows ? mr : 0);
+      return (mr < Mrows && n < p.Nout) ? *reinterpret_cast<const half8 *>(pre_src + (size_t)m * pre_ps + n) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
   };
-  if constexpr (kPre) if ((pre_res || pre_bnx) && !producer) {
+  auto pre_load_tile = [&](int pm0, int pn0) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) rpre[i][jp] = pre_load(m0, n0, i, jp);
-  }
+      for (int jp = 0; jp < NP; ++jp) rpre[i][jp] = pre_load(pm0, pn0, i, jp);
+  };
+  if constexpr (kPre) if ((pre_res || pre_bnx) && !producer) pre_load_tile(m0, n0);
 
   if constexpr (PS) {
     if (producer) {
@@ -446,7 +493,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   // statistics of four stored values o[0..3] at channels n .. n+3 of pixel m (forward: sum, sum of squares; data gradient with
   // bn_x: sum g, sum g (x - mean) of the BatchNorm the gradient is about to pass)
   auto stats4 = [&](int m, int n, const half4 o, int jp, int h) {
-    if (p.bn_x) {
+    if (DGRAD && !PERSIST && p.bn_x) {
       const half4 xv = *reinterpret_cast<const half4 *>(p.bn_x + (size_t)m * p.bn_x_ps + n);
       const float4 sc = *reinterpret_cast<const float4 *>(p.bn_scale + n), sh = *reinterpret_cast<const float4 *>(p.bn_shift + n);
       const float4 mu = *reinterpret_cast<const float4 *>(p.bn_mean + n);
@@ -475,7 +522,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     constexpr int PATH = decltype(path_tag)::value;
     // fused BatchNorm-backward reduction, 16-byte path: the per-channel constants of this lane's channels are loaded once per
     // fragment pair, not once per pixel row (narrow tiles only: 24 VGPRs per pair)
-    constexpr bool kBnHoist = PATH == 0 && NP <= 2;
+    constexpr bool kBnHoist = DGRAD && !PERSIST && PATH == 0 && NP <= 2;
     float bsc[kBnHoist ? NP : 1][8], bsh[kBnHoist ? NP : 1][8], bmu[kBnHoist ? NP : 1][8];
     if constexpr (kBnHoist) {
       if (p.bn_x && p.stats) {
@@ -508,7 +555,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
         if constexpr (PATH == 0) {          // whole 16-byte groups: n + 8 <= Nout
-          if (p.bias) {
+          if (!PERSIST && p.bias) {      // (no persistent launch has a bias: conv_plan)
             const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
           }
@@ -526,7 +573,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
           }
-          if (p.out_f32) {
+          if (!PERSIST && p.out_f32) {
             float *yo = reinterpret_cast<float *>(ybase) + (size_t)m * p.out_ps + n;
             *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
             for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
             // (non-temporal stores measured: no difference in the step, profiles/r04_ab_class_nt_fold.txt)
             *reinterpret_cast<half8 *>(reinterpret_cast<half_t *>(ybase) + (size_t)m * p.out_ps + n) = o;
-            if constexpr (!DGRAD) if (p.out2) {   // the next unit's moving-statistics BatchNorm (+ ReLU) of the value just stored
+            if constexpr (!DGRAD && !PERSIST) if (p.out2) {   // the next unit's moving-statistics BatchNorm (+ ReLU) of the value just stored
               const float4 s0 = *reinterpret_cast<const float4 *>(p.o2_scale + n), s1 = *reinterpret_cast<const float4 *>(p.o2_scale + n + 4);
               const float4 h0 = *reinterpret_cast<const float4 *>(p.o2_shift + n), h1 = *reinterpret_cast<const float4 *>(p.o2_shift + n + 4);
               const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -551,6 +598,35 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
             }
             if (p.stats) {
               bool done = false;
+              if constexpr (kBnLds) {
+                if (p.bn_x) {      // (conv_plan: a persistent launch with bn_x has the BatchNorm input in `rpre`)
+                  // re-read per group (asm volatile: never merged over the groups, where the 24 values would be live across all of them)
+                  const float *cf = reinterpret_cast<const float *>(lds + S * STAGE + RED) + (wn * WTN + jp * 32 + fq * 8);
+                  floatx4 cv[6];
+#pragma unroll
+                  for (int w3 = 0; w3 < 3; ++w3)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) cv[2 * w3 + h] = lds_read16_untracked(cf + 256 * w3 + 4 * h);
+                  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                  for (int k6 = 0; k6 < 6; ++k6) tie(cv[k6]);
+                  float sc8[8], sh8[8], mu8[8];
+#pragma unroll
+                  for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sc8[4 * h + r] = cv[h][r]; sh8[4 * h + r] = cv[2 + h][r]; mu8[4 * h + r] = cv[4 + h][r]; }
+                  const half8 xv = rpre[i][jp];
+  #pragma unroll
+                  for (int r = 0; r < 8; ++r) {
+                    const float xf = (float)xv[r], yv = xf * sc8[r] + sh8[r];
+                    const bool pass = p.bn_act == 0 || (p.bn_act == 1 ? yv > 0.f : (yv >= 0.f && yv <= 6.f));
+                    const float gf = pass ? (float)o[r] : 0.f;
+                    st_s[jp][r] += gf;
+                    st_q[jp][r] += gf * (xf - mu8[r]);
+                  }
+                  done = true;
+                }
+              }
               if constexpr (kBnHoist) {
                 if (p.bn_x) {
                   half8 xv;
@@ -572,9 +648,6 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
                 stats4(m, n + 4, half4{o[4], o[5], o[6], o[7]}, jp, 1);
               }
             }
-          }
-          if constexpr (PERSIST && kPre) {   // this group's registers are free: the same group of the workgroup's NEXT tile
-            if (has_next && (pre_res || pre_bnx)) rpre[i][jp] = pre_load(nm0, nn0, i, jp);
           }
         } else if constexpr (PATH == 1) {   // 8-byte groups, each with its own bound (Nout = 84, ...)
   #pragma unroll
@@ -620,7 +693,13 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
       }
     }
   };
-  if (!producer) {
+  if constexpr (PERSIST) {
+    epilogue(std::integral_constant<int, 0>{});      // (the launcher takes the persistent twin only for 16-byte fp16 rows)
+    // the residual / BatchNorm-input tile of the workgroup's NEXT tile, requested behind the last store: it lands under the
+    // statistics and the first K-step of that tile (not group by group inside the epilogue: whatever wait the compiler places there
+    // -- a spill reload is enough -- would drain these cold requests one by one, loads return in order)
+    if constexpr (kPre) if (has_next && (pre_res || pre_bnx)) pre_load_tile(nm0, nn0);
+  } else if (!producer) {
     if (vec8) epilogue(std::integral_constant<int, 0>{});
     else if (vec4) epilogue(std::integral_constant<int, 1>{});
     else epilogue(std::integral_constant<int, 2>{});
@@ -662,7 +741,9 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
         }
     }
     sync();
-    for (int idx = tid; idx < 2 * BN; idx += T) {
+    int tid_s = tid;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_s));      // (derived per tile: hoisted out of the tile loop these addresses are spilled)
+    for (int idx = tid_s; idx < 2 * BN; idx += T) {
       const int which = idx / BN, col = idx - which * BN;
       const int n = n0 + col;
       if (n < p.Nout) {
@@ -682,11 +763,25 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     const int total = tpw * nk;
     issue(0);
     int cur = 0, g = 0;
-    for (int seq = 0; seq < tpw; ++seq) {
+    for (int seq = 0;; ++seq) {
       for (int t = 0; t < nk; ++t, ++g) {
         if (t > 0 || seq == 0) wait_vmcnt<0>();   // stage g has landed (this wave's part; a tile's first stage was waited for in front of the epilogue before it)
         __builtin_amdgcn_s_barrier();     // ... everybody's part has, and everybody is done with stage g - 1 (and its tile's statistics scratch)
         if (g == 0) stamp(1);
+        if constexpr (kBnLds) {
+          // this tile's BatchNorm coefficients -> LDS (wave 0, three 1 KB pieces: lanes 0 - 31 carry 128 floats, the others read
+          // out of range = zeros).  Behind barrier t = 0 nobody reads the previous tile's any more; this wave's vmcnt(0) of step 1 and
+          // that step's barrier (nk >= 2: conv_plan) put them in front of every wave's epilogue.
+          if (t == 0 && wave == 0 && p.bn_x) {
+            half_t *const cdst = lds + S * STAGE + RED;
+            const float *const src[3] = {p.bn_scale, p.bn_shift, p.bn_mean};
+#pragma unroll
+            for (int w3 = 0; w3 < 3; ++w3) {
+              const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src[w3] + n0), 0, BN * 4, 0x00020000);
+              dma16(rc, cdst + w3 * 512, (unsigned)lane * 16u);
+            }
+          }
+        }
         if (g + 1 < total) {
           if (t == nk - 1) fetch_seek(lin + (seq + 1) * (int)gridDim.x, 0);    // the next tile's first stage
           issue(cur ^ 1);
@@ -697,14 +792,23 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
       // the next tile's first stage was issued one compute phase ago: wait for it HERE, so that nothing the epilogue issues (stores,
       // the next residual tile) stands between that stage and the first barrier of the next tile's loop
       wait_vmcnt<0>();
+      if constexpr (kPre) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) tie(rpre[i][jp]);
+      }
       const bool has_next = seq + 1 < tpw;
       int nmt = mt, nnt = nt;
       if (has_next) tile_of(lin + (seq + 1) * (int)gridDim.x, nmt, nnt);
       finish_tile(has_next, nmt * BM, nnt * BN);
+      if (!has_next) break;
       mt = nmt; nt = nnt;
       m0 = mt * BM; n0 = nt * BN;
       zero_acc();
-      if (has_next && nk > 1) fetch_seek(lin + (seq + 1) * (int)gridDim.x, 1);
+      __builtin_amdgcn_sched_barrier(0);      // (the re-derivation below must not be scheduled up into the epilogue: its registers are the point)
+      rederive_lane_constants();
+      fetch_seek(lin + (seq + 1) * (int)gridDim.x, nk > 1 ? 1 : 0);   // (nk == 1: re-positioned again before the next issue)
     }
   } else {
     finish_tile(false, 0, 0);
@@ -733,7 +837,7 @@ static const ConvDmaConfig kCfg[kConvDmaConfigs + 1] = {
     // persistent tile loop (round 6; PERSIST in conv_dma_kernel): 512 workgroups walk tiles / 512 tiles each as one pipeline
     {160, 128, 256, 2, 2 * 288 * 128 + 2048},   // 24: 14's shape (forward)
     {0, 0, 0, 0, 0},
-    {160, 128, 512, 2, 2 * 288 * 128 + 2048},   // 26: 16's shape (data gradient)
+    {160, 128, 512, 2, 2 * 288 * 128 + 2048 + 3072},   // 26: 16's shape (data gradient; + the BatchNorm coefficients' 3 KB)
 };
 
 ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConfigs) ? kCfg[cfg] : kCfg[0]; }
@@ -749,10 +853,10 @@ static void launch_one(const ConvParams &p, hipStream_t s) {
     q.ksplit = 1;
     hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS, true>), dim3((unsigned)(base / q.tiles_per_wg)),
                        dim3(64 * WMW * WNW), 0, s, q, mtiles, ntiles);
-    return;
+  } else {
+    const dim3 grid((unsigned)base * (unsigned)((!DGRAD && p.ksplit > 1 && BM * BN <= 160 * 128) ? p.ksplit : 1));
+    hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, q, mtiles, ntiles);
   }
-  const dim3 grid((unsigned)base * (unsigned)((!DGRAD && p.ksplit > 1 && BM * BN <= 160 * 128) ? p.ksplit : 1));
-  hipLaunchKernelGGL((conv_dma_kernel<DGRAD, BM, BN, WMW, WNW, S, MINW, PS>), grid, dim3(64 * (WMW * WNW + (PS ? 4 : 0))), 0, s, q, mtiles, ntiles);
 }
 
 template <bool DGRAD>
@@ -766,7 +870,7 @@ static int launch_cfg(const ConvParams &p, int cfg, hipStream_t s) {
     case 16: launch_one<DGRAD, 160, 128, 2, 4, 2, 2>(p, s); break;
     case 18: launch_one<DGRAD, 160, 128, 2, 2, 4, 1, true>(p, s); break;
     case 24: launch_one<DGRAD, 160, 128, 2, 2, 2, 2, false, true>(p, s); break;
-    case 26: launch_one<DGRAD, 160, 128, 2, 4, 2, 2, false, true>(p, s); break;
+    case 26: launch_one<DGRAD, 160, 128, 2, 4, 2, 4, false, true>(p, s); break;
     default: SN_REQUIRE(false, "conv_dma_launch: unknown configuration %d", cfg);
   }
   SN_CHECK_LAUNCH();

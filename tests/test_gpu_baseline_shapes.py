@@ -183,6 +183,68 @@ def test_conv_fwd_stats_at_c2_launch_shapes_vs_oracle(name):
     assert np.all(np.abs(var - wvar) <= 1e-2 * wvar), float(np.max(np.abs(var - wvar) / wvar))
 
 
+# N, C, H, W, O, residual, relu: 1x1 layers of the 20-chip step whose tile count divides over the 512 resident workgroups
+PERSIST_SHAPES = {
+    'stage3 256->1024 @32 (+residual)': (B, 256, 32, 32, 1024, True, 0),
+    'stage2 128->512 @64 (+residual)': (B, 128, 64, 64, 512, True, 0),
+    'stage4 512->2048 @32': (B, 512, 32, 32, 2048, False, 1),
+}
+
+
+@pytest.mark.parametrize('name', list(PERSIST_SHAPES))
+def test_persistent_tile_loop_equals_one_tile_per_workgroup(name):
+    """Round 6: launches of >= 4 tiles per CU run as 512 persistent workgroups that walk their tiles as one pipeline (conv_dma.hip,
+    configurations 24 / 26).  Same arithmetic per output, so everything must be BIT-equal to the one-tile-per-workgroup launch
+    (sn_debug_option conv_no_persist): the forward with residual and the statistics partials of its epilogue, the plain data
+    gradient, and the data gradient with the BatchNorm-backward reduction (coefficients through LDS-DMA in the persistent kernel).
+    The comparison against the oracle at these shapes is the tests above (they run the persistent default)."""
+    from sniper_amd import hip
+    from gpu_util import to_nhwc_f16, w_to_otI
+    N, C, H, W, O, hr, relu = PERSIST_SHAPES[name]
+    rs = np.random.RandomState(len(name) + C)
+    x = to_nhwc_f16(rs.standard_normal((N, C, H, W)).astype(np.float32))
+    w = (rs.standard_normal((O, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+    wd = torch.from_numpy(w_to_otI(w)).to(dev()).half().contiguous()
+    res = to_nhwc_f16(rs.standard_normal((N, O, H, W)).astype(np.float32)) if hr else None
+    args = (N, H, W, C, C, O, O, O if hr else 0, 1, 1, 1, 0, 1)
+    nblk = hip.query('sn_conv_fwd_stats_blocks', *args)
+    assert nblk > 0
+    # backward operands: dy (N, H, W, O) -> dx (N, H, W, C) needs a persistent-sized launch too: use the transposed roles, i.e. the
+    # data gradient of the REDUCTION O -> C' = the forward's input width seen from the other side (dy has C channels, dx has O)
+    dy = to_nhwc_f16(rs.standard_normal((N, C, H, W)).astype(np.float32))
+    w2 = (rs.standard_normal((C, O, 1, 1)) / np.sqrt(O)).astype(np.float32)               # a conv O -> C; its dgrad: dy (.., C) -> dx (.., O)
+    wT = torch.empty((O, 1, C), dtype=torch.float16, device=dev())
+    hip.call('sn_weight_transpose', torch.from_numpy(w_to_otI(w2)).to(dev()), wT, C, 1, O, C, hip.stream())
+    dargs = (N, H, W, O, O, C, C, 0, 1, 1, 1, 0, 1)
+    dblk = hip.query('sn_conv_dgrad_bn_blocks', *dargs)
+    assert dblk > 0
+    bnx = to_nhwc_f16(rs.standard_normal((N, O, H, W)).astype(np.float32))
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev())
+    dsc, dsh, dmu = f(rs.uniform(0.5, 1.5, O)), f(rs.uniform(-0.3, 0.6, O)), f(rs.standard_normal(O) * 0.1)
+    acc = to_nhwc_f16(rs.standard_normal((N, O, H, W)).astype(np.float32))
+    out = []
+    for no_persist in (1, 0):
+        hip.call('sn_debug_option', b'conv_no_persist', no_persist)
+        try:
+            y = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+            part = torch.full((nblk, 2, O), 7.0, dtype=torch.float32, device=dev())
+            hip.call('sn_conv_fwd_stats', x, wd, None, res, y, *args, relu, part, hip.stream())
+            y2 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+            hip.call('sn_conv_fwd', x, wd, None, res, y2, N, H, W, C, C, O, O, O if hr else 0, 1, 1, 1, 0, 1, relu, 0, hip.stream())
+            dx = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+            bpart = torch.full((dblk, 2, O), 7.0, dtype=torch.float32, device=dev())
+            hip.call('sn_conv_dgrad_bn', dy, wT, None, dx, *dargs, bnx, O, dsc, dsh, dmu, 1, bpart, hip.stream())
+            dx2 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
+            hip.call('sn_conv_dgrad', dy, wT, acc, dx2, N, H, W, O, O, C, C, O, 1, 1, 1, 0, 1, 0, hip.stream())
+            torch.cuda.synchronize()
+            out.append((y, part, y2, dx, bpart, dx2))
+        finally:
+            hip.call('sn_debug_option', b'conv_no_persist', 0)
+    for k, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), ('fwd+stats y', 'fwd statistics partials', 'fwd y', 'dgrad+bn dx', 'BatchNorm-backward partials', 'dgrad (+accumulate) dx')[k]
+    assert torch.isfinite(out[1][0].float()).all() and not (out[1][0] == 7.0).all()
+
+
 @pytest.mark.parametrize('name,act', [(n, 1) for n in C2_CONV_SHAPES] + [('stage3 1x1 1024->256 @32', 0)])
 def test_conv_dgrad_bn_at_c2_launch_shapes_vs_oracle(name, act):
     """sn_conv_dgrad_bn (84 of the step's data-gradient launches) + sn_bn_backward_blocks at the C2 launch shapes against the
