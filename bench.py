@@ -261,6 +261,9 @@ HBM_KERNELS = ('dpsroi_fwd_roi_kernel', 'dpsroi_bwd_data_mfma_kernel', 'dpsroi_b
                'sgd_dev', 'maxpool_kernel')
 
 
+C4_HBM_KERNELS = ('psroi_ps_fwd', 'psroi_ps_bwd_data', 'psroi_ps_bwd_trans', 'avgpool_global')
+
+
 INFER_HBM_KERNELS = ('topk_select_sort_kernel', 'nms_lazy_kernel', 'dpsroi_fwd_roi_kernel', 'bn_apply_kernel', 'deform_im2col_kernel',
                      'maxpool_kernel', 'im_prepare_kernel', 'splitk_reduce_kernel', 'det_compact', 'soft_nms_kernel',
                      '__amd_rocclr_copyBuffer', 'FillFunctor')
@@ -743,6 +746,8 @@ def compact_line(full):
         line['cpu_baseline'] = c
     else:
         line['cpu_baseline'] = None
+    if isinstance(full.get('c4'), dict):      # BASELINE configs[3] at one GPU's share: three numbers
+        line['c4'] = _pick(full['c4'], ('value', 'unit', 'ms_per_step', 'head_ms', 'chips_per_gpu'))
     for k in ('dist', 'fit_path'):
         if isinstance(full.get(k), dict):
             line[k] = {a: b for a, b in full[k].items() if not isinstance(b, (dict, list, str)) or (isinstance(b, str) and len(b) <= 80)}
@@ -756,7 +761,7 @@ def compact_line(full):
             i['cpu_baseline'] = _pick(inf['cpu_baseline'], ('value', 'unit', 'cores', 'kind'))
         line['inference'] = i
     line['detail'] = 'BENCH_DETAIL line above / gpurun_out/bench_detail.json'
-    for drop in ('detail', 'fit_path', 'dist', 'device', 'inference'):
+    for drop in ('detail', 'fit_path', 'c4', 'dist', 'device', 'inference'):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -773,6 +778,7 @@ def main():
     ap.add_argument('--inference', action='store_true', help='(default on rank 0 at N = 1; kept for old command lines)')
     ap.add_argument('--no-inference', action='store_true', help='skip BASELINE config C5 (inf images/sec)')
     ap.add_argument('--no-fit-path', action='store_true', help='skip the reference main_train.py throughput leg (fit_path)')
+    ap.add_argument('--no-c4', action='store_true', help='skip BASELINE config C4 (R-FCN head, 16 chips) at one GPU\'s share')
     args = ap.parse_args()
 
     # the host driver only supports dmabuf IPC: without this RCCL's peer mapping fails with hipIpcGetMemHandle: invalid argument
@@ -934,6 +940,20 @@ def main():
                 fit_path['reference_iterator_ratio'] = round(ref_it['value'] / value, 3)
         except Exception as e:   # noqa: BLE001 -- a report
             fit_path = {'value': None, 'sample': 'failed: %r' % (e,)}
+    c4 = None
+    if rank == 0 and world == 1 and not args.no_c4:
+        # BASELINE configs[3] (R-FCN / PS-RoI pooling head) at one GPU's share -- 16 chips -- in its own process (tools/c4_bench.py):
+        # chips/s, ms per step, the head's own ms; HBM rows of the three position-sensitive kernels from the counter passes
+        try:
+            import subprocess
+            torch.cuda.empty_cache()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'c4_bench.py'), '20', '5', '16'], cwd=ROOT, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=420, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            c4 = json.loads(lines[-1]) if lines else {'value': None, 'sample': 'failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
+            c4['roofline_hbm'] = roofline_hbm('pmc_c4_kernels.json', C4_HBM_KERNELS)
+        except Exception as e:   # noqa: BLE001 -- a report
+            c4 = {'value': None, 'sample': 'failed: %r' % (e,)}
     if rank == 0:
         out = {
             'metric': 'train chips/sec (512x512, R101)', 'value': round(value, 2), 'unit': 'chips/s', 'n_gpus': world,
@@ -955,6 +975,8 @@ def main():
             out['dist'] = dist_report
         if fit_path is not None:
             out['fit_path'] = fit_path
+        if c4 is not None:
+            out['c4'] = c4
         # the committed rocprofv3 --kernel-trace --stats cross-check of this same command ON THIS BUILD (tools/roofline_check.py,
         # same session as a bench line of that card): lets a reader tell card-to-card spread from a regression
         try:

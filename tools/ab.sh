@@ -4,7 +4,7 @@
 # interleaved so that clock drift hits every variant alike.
 #   tools/ab.sh "" "SNIPER_DGRAD_BY_CLASS=0"
 ROUNDS=${ROUNDS:-2}
-run() { env $1 python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline --no-inference --no-fit-path 2>/tmp/ab.err | grep '^BENCH_DETAIL ' | tail -1 | cut -c14- | python -c "
+run() { env $1 python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline --no-inference --no-fit-path --no-c4 2>/tmp/ab.err | grep '^BENCH_DETAIL ' | tail -1 | cut -c14- | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; e=r['by_entry']
 g=lambda k: e.get(k, {'ms_per_step': 0.0})['ms_per_step']

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit.  Everything lands in gpurun_out/ (copy what should be judged into profiles/).
-# usage: tools/gpu_session.sh [tests|bench|prof|pmc|pmcinf|micro]...
+# usage: tools/gpu_session.sh [tests|bench|prof|pmc|pmcc4|pmcinf|micro]...
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 ROOT=$(pwd)
 mkdir -p gpurun_out
@@ -29,7 +29,7 @@ bench)
 prof)
   # kernel stats of the SAME command (minus the CPU / inference legs): 3 + 10 + 1 + 3 = 17 steps of conv launches
   (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_bench" -o bench -- \
-      python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-inference --no-fit-path > "$ROOT/gpurun_out/rocprof_bench.log" 2>&1; echo "rocprof exit $?")
+      python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-inference --no-fit-path --no-c4 > "$ROOT/gpurun_out/rocprof_bench.log" 2>&1; echo "rocprof exit $?")
   F=$(find gpurun_out/prof_bench -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && head -30 "$F" && python tools/roofline_check.py "$F" gpurun_out/rocprof_bench.log 17 gpurun_out/roofline_check.json
   T=$(find gpurun_out/prof_bench -name "*kernel_trace.csv" | head -1)
@@ -39,7 +39,7 @@ pmc)
   # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC has 4 slots: 3 + 2); counters only, no other trace domain
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/gpurun_out/pmc_$C" -o pmc -- \
-        python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-fit-path > "$ROOT/gpurun_out/rocprof_pmc_$C.log" 2>&1; echo "pmc $C exit $?")
+        python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-fit-path --no-c4 > "$ROOT/gpurun_out/rocprof_pmc_$C.log" 2>&1; echo "pmc $C exit $?")
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json > /dev/null
   # (rates also over the un-countered durations of the `prof` step's kernel statistics, when that step ran in this visit)
@@ -47,6 +47,18 @@ pmc)
       "$(find gpurun_out/prof_bench -name '*kernel_stats.csv' 2>/dev/null | head -1)" | head -60
   # (copy gpurun_out/pmc_traffic.json and gpurun_out/pmc_kernels.json to profiles/: bench.py reads them there, keyed on the source hash)
   find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete ;;
+pmcc4)
+  # HBM traffic of the position-sensitive R-FCN head's kernels (BASELINE C4, tools/c4_bench.py): durations from an un-countered --stats
+  # run, FETCH / WRITE from two counter passes of the same command -> gpurun_out/pmc_c4_kernels.json (copy to profiles/: bench.py's c4 leg)
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_c4" -o c4 -- \
+      python "$ROOT/tools/c4_bench.py" 6 2 16 > "$ROOT/gpurun_out/prof_c4.log" 2>&1; echo "prof c4 exit $?")
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/gpurun_out/pmcc4_$C" -o pmc -- \
+        python "$ROOT/tools/c4_bench.py" 2 1 16 > "$ROOT/gpurun_out/rocprof_pmcc4_$C.log" 2>&1; echo "pmcc4 $C exit $?")
+  done
+  python tools/pmc_report.py gpurun_out/pmcc4_FETCH_SIZE gpurun_out/pmcc4_WRITE_SIZE gpurun_out/pmc_c4_kernels.json "" \
+      "$(find gpurun_out/prof_c4 -name '*kernel_stats.csv' 2>/dev/null | head -1)" | grep -i "psroi_ps\|avgpool\|kernel" | head -12
+  find gpurun_out/pmcc4_FETCH_SIZE gpurun_out/pmcc4_WRITE_SIZE gpurun_out/prof_c4 -name "*.csv" -size +8M -delete ;;
 pmcinf)
   # HBM traffic of the inference pass's kernels: the same two counter passes over a 16-image AutoFocus pass,
   # durations from an un-countered --stats run of the same command

@@ -8,7 +8,7 @@ for v in "$@"; do
   D="$ROOT/gpurun_out/kab_$(echo "$v" | tr -c 'A-Za-z0-9' '_')"
   rm -rf "$D"
   (cd /tmp && export TMPDIR=/tmp && env $v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o k -- \
-      python "$ROOT/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-inference --no-fit-path > "$D.log" 2>&1)
+      python "$ROOT/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-inference --no-fit-path --no-c4 > "$D.log" 2>&1)
   F=$(find "$D" -name "*kernel_stats.csv" | head -1)
   echo "== ${v:-(defaults)}  $(grep -o '"ms_per_step": [0-9.]*' "$D.log" | head -1)"
   [ -n "$F" ] && python - "$F" "$PAT" <<'PY'

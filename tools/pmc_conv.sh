@@ -11,7 +11,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   i=$((i+1))
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$ROOT/gpurun_out/pmc_conv$i" -o c -- \
-      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-fit-path > "$ROOT/gpurun_out/pmc_conv$i.log" 2>&1; echo "set $i exit $?")
+      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-fit-path --no-c4 > "$ROOT/gpurun_out/pmc_conv$i.log" 2>&1; echo "set $i exit $?")
 done
 python - <<'PY' > gpurun_out/pmc_conv_insitu.txt
 import csv, glob, collections, re
