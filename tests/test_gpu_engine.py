@@ -657,13 +657,17 @@ def test_r101_c2_network_parity_vs_cpu_reference_ops(B):
 
 
 
-@pytest.mark.parametrize('B', [2, 8])
+@pytest.mark.parametrize('B', [2, 16])
 def test_r101_c4_rfcn_head_parity_vs_cpu_reference_ops(B):
     """BASELINE config C4: the R101 trunk with the position-sensitive R-FCN head (group_size 7 deformable PS-RoI pooling
-    of 7*7*81 / 7*7*4 maps with pooled offsets, bin vote by global average pooling), 2 chips and 8 chips (2400 RoIs through the
-    head; the trunk at the C2 batch is test_r101_c2_network_parity_vs_cpu_reference_ops[20] -- the 16-chip run of rounds 2-4
-    spent 119 s of CPU-oracle time re-checking that trunk), teacher-forced against oracle/graph_cpu.py like C1 / C2."""
+    of 7*7*81 / 7*7*4 maps with pooled offsets, bin vote by global average pooling), teacher-forced against oracle/graph_cpu.py like
+    C1 / C2.  2 chips by default; the 16-chip run (one GPU's share of the C4 batch: 119 s, almost all of it CPU-oracle time on a trunk
+    that test_r101_c2_network_parity_vs_cpu_reference_ops[20] checks at the larger C2 batch) with SNIPER_SLOW_TESTS=1.  The head's
+    kernels at the C4 LAUNCH shape -- 16 x 300 RoIs, 32 x 32 maps of 7*7*81 / 7*7*4 channels -- are checked directly, without a
+    trunk, by tests/test_gpu_baseline_shapes.py::test_position_sensitive_pool_at_c4_launch_shape."""
     import os
+    if B > 2 and os.environ.get('SNIPER_SLOW_TESTS', '0') != '1':
+        pytest.skip('16-chip C4 end-to-end run: SNIPER_SLOW_TESTS=1 (the launch-shape kernel test and the 2-chip run cover it by default)')
     from sniper_amd import config as cfgmod
     from sniper_amd.engine.executor import Executor
     from sniper_amd.symbols.faster import resnet_mx_101_e2e_rfcn as rf
