@@ -642,6 +642,7 @@ class Executor(object):
     # parameters in / out (reference layout on the host side)
     # ------------------------------------------------------------------------------------------
     def set_params(self, arg_params, aux_params=None, allow_missing=False):
+        self.fold_store['__valid__'] = False        # the derived buffers (shared per Module) follow the masters again in refresh_compute_copies
         for name, p in self.params.items():
             if name in arg_params:
                 a = arg_params[name]
@@ -677,6 +678,32 @@ class Executor(object):
         self._bn_cache_valid = False
         for s in self.steps:
             s.params_changed(only_trainable)
+        if not self.for_training:
+            self.fold_store['__valid__'] = True
+
+    def derived_buffer(self, key, shape, dtype):
+        """Test time: a buffer DERIVED from the parameters alone (a BatchNorm's scale / shift from its moving statistics) -- one per
+        Module like the parameters themselves (share_params): the executors of its batch shapes hold the same tensor."""
+        if self.for_training:
+            return self.empty(shape, dtype)
+        t = self.fold_store.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = self.fold_store[key] = self.empty(shape, dtype)
+        return t
+
+    def adopt_derived(self):
+        """A further batch shape of a test-time Module whose parameters are all shared with an executor that already derived
+        everything from them (fp16 copies, BatchNorm scale / shift, BatchNorm-folded weights: Module._exe_for): nothing to compute --
+        round 5 re-ran ~340 copies, 101 scale / shift kernels and 64 folds per new shape, 6 ms of host time each.  False = something
+        is not there yet (the caller refreshes as before)."""
+        if self.for_training or not self.fold_store.get('__valid__'):
+            return False
+        if not all(n in self.shared_names for n in list(self.params) + list(self.aux)):
+            return False
+        for s in self.steps:
+            if not s.adopt_derived():
+                return False
+        return True
 
     def transpose_jobs(self, only_trainable):
         """(master, dst, O, T, I) of every transposed data-gradient copy: the parameters' own plus what the steps add."""
@@ -793,10 +820,22 @@ class Executor(object):
                 gc_was = gc.isenabled()
                 gc.disable()             # (no collection -- no foreign destructor freeing memory -- on a capturing stream: _capture)
                 try:
-                    torch.cuda.synchronize()
+                    # capture_begin / capture_end on a side stream of this thread instead of the torch.cuda.graph context: that
+                    # context synchronises the DEVICE (every other lane's queue), collects garbage and empties the allocator's cache
+                    # on entry -- most of the 6 - 39 ms a capture cost per new batch shape (tools/cold_shape_probe.py).  The eager
+                    # first call already made every lazy allocation, so nothing here needs freed memory.
+                    cur = torch.cuda.current_stream()
+                    side = self.__dict__.setdefault('_capture_stream', None) or torch.cuda.Stream(device=self.device)
+                    self._capture_stream = side
+                    side.wait_stream(cur)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                        self._forward_body()
+                    with torch.cuda.stream(side):
+                        g.capture_begin(capture_error_mode='thread_local')
+                        try:
+                            self._forward_body()
+                        finally:
+                            g.capture_end()
+                    cur.wait_stream(side)
                     g.replay()
                     self._infer_graph = g
                     if gc_was:

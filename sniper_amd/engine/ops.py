@@ -69,6 +69,10 @@ class Step(object):
     def params_changed(self, only_trainable=False):
         pass
 
+    def adopt_derived(self):
+        """Executor.adopt_derived: True when this step needs nothing recomputed on a shape that shares its parameters"""
+        return True
+
     def transpose_jobs(self, only_trainable=False):
         """extra (master, dst, O, T, I) transposed weight copies this step needs (Executor.transpose_jobs)"""
         return []
@@ -100,7 +104,9 @@ class BatchNormStep(Step):
         self.var = ex.register_aux(self.pname('moving_var'))
         if self.pname('moving_var') not in ex.shared_names:      # (a shared statistic already holds the Module's values)
             ex.aux[self.pname('moving_var')].fill_(1.0)
-        self.scale, self.shift = ex.empty((C,), F32), ex.empty((C,), F32)
+        # (test time: one scale / shift per Module, shared by the executors of its batch shapes -- Executor.derived_buffer)
+        self.scale = ex.derived_buffer(('bn_scale', self.node.name), (C,), F32)
+        self.shift = ex.derived_buffer(('bn_shift', self.node.name), (C,), F32)
         self.save_mean, self.save_invstd = ex.empty((C,), F32), ex.empty((C,), F32)
         self.bws = None
         # image input (C <= 4): folded into the stem convolution's input packing
@@ -186,6 +192,18 @@ class BatchNormStep(Step):
                 self._global_ready = True
                 if self.folded_into is not None:
                     self.folded_into.refold(self.scale, self.shift)
+
+    def adopt_derived(self):
+        # scale / shift are the Module's (derived_buffer) and hold the folded moving statistics; a folded convolution takes the
+        # Module's folded weights
+        if self.folded_into is not None:
+            conv = self.folded_into
+            ent = self.ex.fold_store.get(conv.w.name)
+            if ent is None or conv.w.name not in self.ex.shared_names or ent[0].shape != conv.w.w16.shape:
+                return False
+            conv.wf, conv.bf = ent
+        self._global_ready = True
+        return True
 
     def _use_batch_stats(self):
         return self.ex.is_train and not self.global_stats

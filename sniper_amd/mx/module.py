@@ -135,7 +135,9 @@ class Module(object):
             ex = Executor(self.symbol, dict(shapes), for_training=self.for_training, fixed_param_names=self.fixed_param_names,
                           device=self._device, split_backward=split, act_pool=pool, share_params=share)
             if self._arg_params is not None:
-                if share is not None and all(n in ex.shared_names for n in list(ex.params) + list(ex.aux)):
+                if share is not None and ex.adopt_derived():
+                    pass                                         # parameters AND everything derived from them are the Module's: nothing to do
+                elif share is not None and all(n in ex.shared_names for n in list(ex.params) + list(ex.aux)):
                     ex.refresh_compute_copies()                  # the values are there: only this shape's derived buffers
                 else:
                     ex.set_params(self._arg_params, self._aux_params)

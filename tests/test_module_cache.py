@@ -151,6 +151,23 @@ def test_test_time_executors_share_one_parameter_set():
     assert b.aux['stage1_unit1_bn2_moving_var'].data_ptr() == a.aux['stage1_unit1_bn2_moving_var'].data_ptr()
     c = bind(128, 192)
     assert c.params['conv0_weight'].master.data_ptr() != a.params['conv0_weight'].master.data_ptr()
+    # round 6: what is DERIVED from the parameters alone is the Module's too -- a BatchNorm's scale / shift (derived_buffer) -- and a
+    # further shape adopts it instead of recomputing (Executor.adopt_derived), but only once an executor of the Module has derived
+    # everything from the current parameters (the '__valid__' mark refresh_compute_copies leaves; set_params clears it first)
+    bn_a = next(s for s in a.steps if type(s).__name__ == 'BatchNormStep' and s.node.name == 'stage3_unit1_bn1')
+    bn_b = next(s for s in b.steps if type(s).__name__ == 'BatchNormStep' and s.node.name == 'stage3_unit1_bn1')
+    assert bn_b.scale.data_ptr() == bn_a.scale.data_ptr() and bn_b.shift.data_ptr() == bn_a.shift.data_ptr()
+    assert not b.adopt_derived()                      # nothing derived yet: no parameters were ever set
+    a.fold_store['__valid__'] = True                  # (what a.set_params(...) leaves on a device; no kernels on the CPU)
+    folded = next(s for s in b.steps if type(s).__name__ == 'BatchNormStep' and s.folded_into is not None)
+    assert not b.adopt_derived()                      # ... and the folded weights must be there as well
+    for s in a.steps:
+        if type(s).__name__ == 'BatchNormStep' and s.folded_into is not None:
+            w = s.folded_into.w
+            a.fold_store[w.name] = (torch.zeros_like(w.w16), torch.zeros(w.w16.shape[0]))
+    assert b.adopt_derived()
+    assert folded.folded_into.wf is a.fold_store[folded.folded_into.w.name][0] and folded._global_ready
+    assert not c.adopt_derived()                      # an executor with its own parameters never adopts
 
 
 def test_closed_prefetching_iter_dies_by_reference_counting_even_with_a_frozen_heap():
