@@ -417,12 +417,17 @@ int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, co
 /* Position-sensitive variant (group_size G > 1: the R-FCN head of BASELINE config C4; msracver Deformable R-FCN's
  * DeformablePSROIPooling(group_size=7)).  data (B,H,W,C = output_dim*G*G) fp16 in the operator's channel order
  * c = (d*G + gh)*G + gw, out (R,P,P,output_dim) fp16; bin (ph,pw) of output channel d reads channel
- * (d*G + floor(ph*G/P))*G + floor(pw*G/P).  trans (R,2,P,P) class-agnostic or NULL.  Backward as above (overwrites). */
+ * (d*G + floor(ph*G/P))*G + floor(pw*G/P).  trans (R,2,P,P) class-agnostic or NULL.  Backward as above (overwrites).
+ * group_major = 1: the map (and d_data) is laid out (gh*G + gw)*output_dim + d instead -- a bin's output_dim channels are one
+ * contiguous run, so a wave's gathers coalesce (the operator order pulls the whole 7.9 KB pixel of a 7*7*81 map through L2 for every
+ * bin: 7.5 ms per forward at 16 x 300 RoIs; group-major 50x less).  The caller owns the permutation: the executor applies it to the
+ * OUTPUT CHANNELS of the convolution that produces the map (engine/ops.py DPSROIPoolStep), which costs nothing at run time. */
 int sn_psroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int output_dim,
-                      int group_size, int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream);
+                      int group_size, int pooled, int sample_per_part, float spatial_scale, float trans_std, int group_major,
+                      sn_stream_t stream);
 int sn_psroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data, int d_data_f32,
                       float *d_trans, int R, int B, int H, int W, int output_dim, int group_size, int pooled, int sample_per_part,
-                      float spatial_scale, float trans_std, void *ws, sn_stream_t stream);
+                      float spatial_scale, float trans_std, int group_major, void *ws, sn_stream_t stream);
 
 /* DeformableConvolution sampling (:124-128): column buffer (M, KH*KW, C) fp16 for the 1x1 GEMM, and its backward:
  * d_data (N,H,W,C) fp16/fp32 and d_offset (same layout/dtype as offset) are OVERWRITTEN; either may be NULL.  ws: 16 bytes of

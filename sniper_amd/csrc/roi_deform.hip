@@ -861,36 +861,68 @@ __device__ __forceinline__ int ps_group(int p, int G, int P) {
   return g < 0 ? 0 : (g > G - 1 ? G - 1 : g);
 }
 
+// Channel of output channel d in bin group (gh, gw).  gm = 0: the operator's own order (d*G + gh)*G + gw -- the D channels of a bin are
+// G*G apart, every 2-byte gather of a wave lands in its own cache line and a bin pulls the whole pixel (7.9 KB for D = 81, G = 7) through
+// L2: 16.7 GB per call at the C4 launch shape, 7.5 ms.  gm = 1 ("group-major", round 6): (gh*G + gw)*D + d -- the bin's D channels are
+// one contiguous run, a wave's loads coalesce.  The executor permutes the output channels of the convolution that produces the map
+// (its weight rows, internally; Param.out_perm), so the layout costs nothing at run time.
+__device__ __forceinline__ int ps_channel(int d, int gh, int gw, int G, int D, int gm) {
+  return gm ? (gh * G + gw) * D + d : (d * G + gh) * G + gw;
+}
+
+// sum over the bin's window of the separable weights (the S x S sample grid factorises like the group_size = 1 forward: every cell
+// of the window is read once per channel instead of once per sample corner)
+__device__ __forceinline__ float ps_bin_value(const AxisSamples &ax, const AxisSamples &ay, const half_t *__restrict__ img, int W, int C) {
+  float sum = 0.f;
+  for (int y = ay.lo; y <= ay.hi; ++y) {
+    const float wy = tent_sum(ay, y);
+    if (wy == 0.f) continue;
+    for (int x = ax.lo; x <= ax.hi; ++x) {
+      const float wgt = wy * tent_sum(ax, x);
+      if (wgt == 0.f) continue;
+      sum += wgt * (float)img[((size_t)y * W + x) * C];
+    }
+  }
+  return sum;
+}
+
+// D >= 32: one wave per (RoI, bin), the lanes stride over the D output channels -- the bin geometry and the window weights are
+// wave-uniform (computed once per wave-instruction, not once per element); D < 32: one thread per output element.
+template <bool WAVE_PER_BIN>
 __global__ __launch_bounds__(256) void psroi_ps_fwd_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
                                                            const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
-                                                           int W, int C, int P, int S, int G, int D, float scale, float trans_std) {
-  const long total = (long)R * P * P * D;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int d = (int)(i % D);
-    long t = i / D;
-    const int pw = (int)(t % P); t /= P;
-    const int ph = (int)(t % P);
-    const int r = (int)(t / P);
+                                                           int W, int C, int P, int S, int G, int D, float scale, float trans_std, int gm) {
+  if constexpr (WAVE_PER_BIN) {
+    const long total = (long)R * P * P;
+    const long wv = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wv >= total) return;                                           // whole waves leave together
+    const int lane = threadIdx.x & 63;
+    const int pw = (int)(wv % P), ph = (int)((wv / P) % P), r = (int)(wv / ((long)P * P));
     const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-    const int c = (d * G + ps_group(ph, G, P)) * G + ps_group(pw, G, P);
-    const half_t *img = data + (size_t)g.b * H * W * C + c;
-    float sum = 0.f;
-    int count = 0;
-    for (int ih = 0; ih < S; ++ih) {
-      for (int iw = 0; iw < S; ++iw) {
-        float w = sample_pos(g.wstart, iw, g.sub_w), h = sample_pos(g.hstart, ih, g.sub_h);
-        if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) continue;
-        w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
-        h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
-        const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
-        const float dx = w - (float)x0, dy = h - (float)y0;
-        const float v00 = (float)img[((size_t)y0 * W + x0) * C], v01 = (float)img[((size_t)y0 * W + x1) * C];
-        const float v10 = (float)img[((size_t)y1 * W + x0) * C], v11 = (float)img[((size_t)y1 * W + x1) * C];
-        sum += (1.f - dx) * (1.f - dy) * v00 + dx * (1.f - dy) * v01 + (1.f - dx) * dy * v10 + dx * dy * v11;
-        ++count;
-      }
+    const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+    const int count = ax.n * ay.n;
+    const float inv = count ? 1.f / (float)count : 0.f;
+    const int gh = ps_group(ph, G, P), gw = ps_group(pw, G, P);
+    const half_t *img = data + (size_t)g.b * H * W * C;
+    for (int d = lane; d < D; d += 64) {
+      const float sum = count ? ps_bin_value(ax, ay, img + ps_channel(d, gh, gw, G, D, gm), W, C) : 0.f;
+      out[(size_t)wv * D + d] = (half_t)(sum * inv);
     }
-    out[i] = (half_t)(count ? sum / (float)count : 0.f);
+  } else {
+    const long total = (long)R * P * P * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int d = (int)(i % D);
+      long t = i / D;
+      const int pw = (int)(t % P); t /= P;
+      const int ph = (int)(t % P);
+      const int r = (int)(t / P);
+      const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+      const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+      const int count = ax.n * ay.n;
+      const int c = ps_channel(d, ps_group(ph, G, P), ps_group(pw, G, P), G, D, gm);
+      const float sum = count ? ps_bin_value(ax, ay, data + (size_t)g.b * H * W * C + c, W, C) : 0.f;
+      out[i] = (half_t)(count ? sum / (float)count : 0.f);
+    }
   }
 }
 
@@ -999,11 +1031,133 @@ __global__ __launch_bounds__(256) void psroi_ps_bwd_data_kernel(const half_t *__
   if (active_c) tile_store(acc, d_data, out_f32, b, y0, x0, H, W, C, (d * G + gh) * G + gw);
 }
 
+// Group-major layout (gm = 1): a workgroup owns (4x4-cell tile, image, 256 CONSECUTIVE map channels c = grp*D + d).  Those channels
+// span ceil(256 / D) + 1 bin groups at most (D = 81: four; D = 4 or 2: all 49), so the workgroup walks the (RoI, bin) items of every
+// group it covers once, each entry carries its group, and a thread accumulates the entries of its own group.  Against the operator-
+// order kernel above: 16 instead of 49 channel slices for D = 81 with every lane active (81 of 256 there), ONE slice instead of 49
+// for the D = 4 / D = 2 maps (4 / 2 active lanes of 256 there); stores of a wave are one contiguous run.
+__global__ __launch_bounds__(256) void psroi_ps_bwd_data_gm_kernel(const half_t *__restrict__ dout, const float *__restrict__ rois,
+                                                                   const float *__restrict__ trans, const int4 *__restrict__ win,
+                                                                   void *__restrict__ d_data, int out_f32, int R, int H, int W, int C,
+                                                                   int P, int S, int G, int D, float scale, float trans_std) {
+  __shared__ __attribute__((aligned(16))) float ent[256 * kEntStride];
+  __shared__ int roi_list[256];
+  __shared__ int bins[256];
+  __shared__ int wave_cnt[4], ent_cnt[4], nb_s;
+  const int PP = P * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int tiles_x = (W + 3) >> 2;
+  const int x0 = (int)(blockIdx.x % tiles_x) * 4, y0 = (int)(blockIdx.x / tiles_x) * 4;
+  const int b = blockIdx.y;
+  const int c = blockIdx.z * 256 + tid;          // this thread's map channel
+  const bool active_c = c < C;
+  const int mygrp = active_c ? c / D : -1, d = active_c ? c - mygrp * D : 0;
+  const int g_lo = (blockIdx.z * 256) / D, g_hi = min(G * G - 1, (blockIdx.z * 256 + 255) / D);
+  if (tid == 0) {
+    int n = 0;
+    for (int bin = 0; bin < PP; ++bin) {
+      const int grp = ps_group(bin / P, G, P) * G + ps_group(bin % P, G, P);
+      if (grp >= g_lo && grp <= g_hi) bins[n++] = bin;
+    }
+    nb_s = n;
+  }
+  __syncthreads();
+  const int nb = nb_s;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  if (nb > 0) {
+    for (int base = 0; base < R; base += 256) {
+      const int rr = base + tid;
+      bool hit = false;
+      if (rr < R) {
+        const int4 w = win[rr];
+        hit = w.w && w.x == b && (w.y & 0xffff) <= x0 + 3 && (w.y >> 16) >= x0 && (w.z & 0xffff) <= y0 + 3 && (w.z >> 16) >= y0;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = 0, total = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int n = wave_cnt[k];
+        off += k < wave ? n : 0;
+        total += n;
+      }
+      if (hit) roi_list[off + __popcll(m & lt)] = rr;
+      __syncthreads();
+      const int nitems = total * nb;
+      for (int it0 = 0; it0 < nitems; it0 += 256) {
+        const int item = it0 + tid;
+        bool act = false;
+        float Wx[4] = {0.f, 0.f, 0.f, 0.f}, Wy[4] = {0.f, 0.f, 0.f, 0.f};
+        float inv = 0.f;
+        int idx = 0, grp = 0;
+        if (item < nitems) {
+          const int r = roi_list[item / nb], bin = bins[item % nb];
+          const int ph = bin / P, pw = bin - ph * P;
+          grp = ps_group(ph, G, P) * G + ps_group(pw, G, P);
+          const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+          int nvx = 0, nvy = 0;
+          for (int i = 0; i < S; ++i) {
+            float w = sample_pos(g.wstart, i, g.sub_w), h = sample_pos(g.hstart, i, g.sub_h);
+            if (!(w < -0.5f || w > (float)W - 0.5f)) {
+              ++nvx;
+              tent4(fminf(fmaxf(w, 0.f), (float)W - 1.f), x0, Wx);
+            }
+            if (!(h < -0.5f || h > (float)H - 0.5f)) {
+              ++nvy;
+              tent4(fminf(fmaxf(h, 0.f), (float)H - 1.f), y0, Wy);
+            }
+          }
+          const float sx = Wx[0] + Wx[1] + Wx[2] + Wx[3], sy = Wy[0] + Wy[1] + Wy[2] + Wy[3];
+          act = nvx * nvy > 0 && sx > 0.f && sy > 0.f;
+          inv = act ? 1.f / (float)(nvx * nvy) : 0.f;
+          idx = r * PP + bin;
+        }
+        const unsigned long long am = __ballot(act);
+        if (lane == 0) ent_cnt[wave] = __popcll(am);
+        __syncthreads();
+        int eoff = 0, n_e = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int n = ent_cnt[k];
+          eoff += k < wave ? n : 0;
+          n_e += n;
+        }
+        if (act) {
+          float *e = ent + (size_t)(eoff + __popcll(am & lt)) * kEntStride;
+          e[0] = __int_as_float(idx);
+          e[1] = __int_as_float(grp);
+          *reinterpret_cast<float4 *>(e + 4) = make_float4(Wx[0] * inv, Wx[1] * inv, Wx[2] * inv, Wx[3] * inv);
+          *reinterpret_cast<float4 *>(e + 8) = make_float4(Wy[0], Wy[1], Wy[2], Wy[3]);
+        }
+        __syncthreads();
+        for (int e = 0; e < n_e; ++e) {           // entries in list order: fixed summation order per channel
+          const float *q = ent + e * kEntStride;
+          if (__float_as_int(q[1]) != mygrp) continue;
+          const float dv = (float)dout[(size_t)__float_as_int(q[0]) * D + d];
+          const float4 wx = *reinterpret_cast<const float4 *>(q + 4), wy = *reinterpret_cast<const float4 *>(q + 8);
+          const float X[4] = {wx.x * dv, wx.y * dv, wx.z * dv, wx.w * dv};
+          const float Y[4] = {wy.x, wy.y, wy.z, wy.w};
+#pragma unroll
+          for (int cy = 0; cy < 4; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 4; ++cx) acc[cy * 4 + cx] += Y[cy] * X[cx];
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (active_c) tile_store(acc, d_data, out_f32, b, y0, x0, H, W, C, c);
+}
+
 // d_trans (R,2,P,P): one wave per (r, ph, pw); the lanes stride over the D output channels, shuffle reduction.
 __global__ __launch_bounds__(256) void psroi_ps_bwd_trans_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                  const float *__restrict__ rois, const float *__restrict__ trans,
                                                                  float *__restrict__ d_trans, int R, int H, int W, int C, int P,
-                                                                 int S, int G, int D, float scale, float trans_std) {
+                                                                 int S, int G, int D, float scale, float trans_std, int gm) {
   const long total = (long)R * P * P;
   const long wv = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wv >= total) return;                                           // whole waves leave together
@@ -1024,7 +1178,7 @@ __global__ __launch_bounds__(256) void psroi_ps_bwd_trans_kernel(const half_t *_
       const int xa = (int)floorf(w), xb = (int)ceilf(w), ya = (int)floorf(h), yb = (int)ceilf(h);
       const float dx = w - (float)xa, dy = h - (float)ya;
       for (int d = lane; d < D; d += 64) {
-        const int c = (d * G + gh) * G + gw;
+        const int c = ps_channel(d, gh, gw, G, D, gm);
         const float dv = (float)dout[(size_t)wv * D + d];
         const float U00 = (float)img[((size_t)ya * W + xa) * C + c], U01 = (float)img[((size_t)ya * W + xb) * C + c];
         const float U10 = (float)img[((size_t)yb * W + xa) * C + c], U11 = (float)img[((size_t)yb * W + xb) * C + c];
@@ -1048,20 +1202,27 @@ __global__ __launch_bounds__(256) void psroi_ps_bwd_trans_kernel(const half_t *_
 
 SN_EXPORT int sn_psroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W,
                                 int output_dim, int group_size, int pooled, int sample_per_part, float spatial_scale,
-                                float trans_std, sn_stream_t stream) {
-  SN_REQUIRE(data && rois && out && R > 0 && output_dim > 0 && group_size > 0 && pooled > 0 && sample_per_part > 0,
-             "sn_psroi_pool_fwd: bad arguments");
+                                float trans_std, int group_major, sn_stream_t stream) {
+  SN_REQUIRE(data && rois && out && R > 0 && output_dim > 0 && group_size > 0 && pooled > 0 && sample_per_part > 0 &&
+                 sample_per_part <= kMaxS, "sn_psroi_pool_fwd: bad arguments (sample_per_part <= %d)", kMaxS);
   const int C = output_dim * group_size * group_size;
-  hipLaunchKernelGGL(psroi_ps_fwd_kernel, dim3((unsigned)blocks_for((long)R * pooled * pooled * output_dim)), dim3(256), 0,
-                     sn_stream(stream), (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part,
-                     group_size, output_dim, spatial_scale, trans_std);
+  if (output_dim >= 32) {
+    const long waves = (long)R * pooled * pooled;
+    hipLaunchKernelGGL(psroi_ps_fwd_kernel<true>, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, sn_stream(stream),
+                       (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part, group_size, output_dim,
+                       spatial_scale, trans_std, group_major ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(psroi_ps_fwd_kernel<false>, dim3((unsigned)blocks_for((long)R * pooled * pooled * output_dim)), dim3(256), 0,
+                       sn_stream(stream), (const half_t *)data, rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part,
+                       group_size, output_dim, spatial_scale, trans_std, group_major ? 1 : 0);
+  }
   SN_CHECK_LAUNCH();
   return SN_OK;
 }
 
 SN_EXPORT int sn_psroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data,
                                 int d_data_f32, float *d_trans, int R, int B, int H, int W, int output_dim, int group_size,
-                                int pooled, int sample_per_part, float spatial_scale, float trans_std, void *ws,
+                                int pooled, int sample_per_part, float spatial_scale, float trans_std, int group_major, void *ws,
                                 sn_stream_t stream) {
   SN_REQUIRE(dout && data && rois && d_data && ws && R > 0 && B > 0 && output_dim > 0 && group_size > 0 && pooled > 0 &&
                  sample_per_part > 0, "sn_psroi_pool_bwd: bad arguments");
@@ -1076,15 +1237,20 @@ SN_EXPORT int sn_psroi_pool_bwd(const void *dout, const void *data, const float 
                      sample_per_part, spatial_scale, trans_std);
   SN_CHECK_LAUNCH();
   const int tiles = sn_div_up(W, 4) * sn_div_up(H, 4);
-  hipLaunchKernelGGL(psroi_ps_bwd_data_kernel, dim3(tiles, B, (unsigned)gz), dim3(256), 0, s, (const half_t *)dout, rois, trans,
-                     (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, group_size, output_dim,
-                     spatial_scale, trans_std);
+  if (group_major)
+    hipLaunchKernelGGL(psroi_ps_bwd_data_gm_kernel, dim3(tiles, B, (unsigned)sn_div_up(C, 256)), dim3(256), 0, s, (const half_t *)dout,
+                       rois, trans, (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, group_size, output_dim,
+                       spatial_scale, trans_std);
+  else
+    hipLaunchKernelGGL(psroi_ps_bwd_data_kernel, dim3(tiles, B, (unsigned)gz), dim3(256), 0, s, (const half_t *)dout, rois, trans,
+                       (const int4 *)win, d_data, d_data_f32, R, H, W, C, pooled, sample_per_part, group_size, output_dim,
+                       spatial_scale, trans_std);
   SN_CHECK_LAUNCH();
   if (trans) {
     const long waves = (long)R * pooled * pooled;
     hipLaunchKernelGGL(psroi_ps_bwd_trans_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, s,
                        (const half_t *)dout, (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part,
-                       group_size, output_dim, spatial_scale, trans_std);
+                       group_size, output_dim, spatial_scale, trans_std, group_major ? 1 : 0);
     SN_CHECK_LAUNCH();
   }
   return SN_OK;

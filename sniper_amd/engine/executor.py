@@ -33,11 +33,12 @@ def _pad8(n):
 class Val(object):
     """One tensor of the graph.  fmt 'act': fp16 channels-last, t has shape (N,H,W,C) (2-D logical
     tensors use H=W=1); fmt 'f32': fp32, reference order, t has the logical shape."""
-    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer', 'grad_group')
+    __slots__ = ('name', 'shape', 'fmt', 't', 'needs_grad', 'grad', 'alt', 'stem', 'consumers', 'producer', 'grad_group', 'chan_perm')
 
     def __init__(self, name, shape, fmt):
         self.name, self.shape, self.fmt = name, tuple(shape), fmt
         self.t = None
+        self.chan_perm = None    # device channel j holds reference channel chan_perm[j] (a group-major position-sensitive map), or None
         self.needs_grad = False
         self.grad = None
         self.alt = None      # cached other-format copy (forward)
@@ -53,7 +54,7 @@ class Val(object):
 
 class Param(object):
     __slots__ = ('name', 'ref_shape', 'kind', 'int_shape', 'trainable', 'lr_mult', 'wd_mult', 'master', 'grad', 'mom',
-                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in', 'half_region', 'step_index', 'phase')
+                 'w16', 'wT16', 'need_wT', 'offset', 'numel', 'fc_in', 'half_region', 'step_index', 'phase', 'out_perm')
 
     def __init__(self, name, ref_shape):
         self.name, self.ref_shape = name, tuple(ref_shape)
@@ -66,10 +67,15 @@ class Param(object):
         self.step_index = 0        # forward index of the (first) step that owns it
         self.phase = 0             # 0: its gradient is complete after the first backward segment, 1: after the second
         self.numel = int(np.prod(ref_shape))
+        # permutation of the OUTPUT channels (axis 0), internal row i = reference row out_perm[i]: a convolution whose output map a
+        # position-sensitive RoI pooling reads writes it group-major (ops.py DPSROIPoolStep); None = reference order
+        self.out_perm = None
 
     # reference layout <-> kernel layout
     def to_internal(self, a):
         a = np.asarray(a, np.float32).reshape(self.ref_shape)
+        if self.out_perm is not None:
+            a = a[self.out_perm]
         if self.kind == 'conv':
             return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
         if self.kind == 'deconv':    # (Cin, Cout, 2, 2) -> rows (a, b, o) of a 1x1 convolution: [4*Cout][1][Cin]
@@ -85,6 +91,15 @@ class Param(object):
         return a
 
     def to_reference(self, a):
+        if self.out_perm is not None:
+            perm, self.out_perm = self.out_perm, None
+            try:
+                rows = self.to_reference(a)          # reference layout, rows still in internal order
+            finally:
+                self.out_perm = perm
+            out = np.empty_like(rows)
+            out[perm] = rows
+            return out
         a = np.asarray(a, np.float32)
         if self.kind == 'conv':
             o, i, kh, kw = self.ref_shape
@@ -312,6 +327,10 @@ class Executor(object):
                 hip.call('sn_copy2d', v.t, out, n, c, c, c, 0, 1, hip.stream())
             else:
                 hip.call('sn_transpose_batched', v.t, out, n, h * w, c, h * w * c, c * h * w, c, h * w, 0, 1, hip.stream())
+            if v.chan_perm is not None:      # (a head / a test reading a group-major map: back to the reference's channel order)
+                inv = np.empty(len(v.chan_perm), np.int64)
+                inv[np.asarray(v.chan_perm)] = np.arange(len(v.chan_perm))
+                out = out.index_select(1, torch.from_numpy(inv).to(out.device))
             v.alt = out
         return v.alt
 
@@ -696,7 +715,7 @@ class Executor(object):
         everything from them (fp16 copies, BatchNorm scale / shift, BatchNorm-folded weights: Module._exe_for): nothing to compute --
         round 5 re-ran ~340 copies, 101 scale / shift kernels and 64 folds per new shape, 6 ms of host time each.  False = something
         is not there yet (the caller refreshes as before)."""
-        if self.for_training or not self.fold_store.get('__valid__'):
+        if self.for_training or not self.fold_store.get('__valid__') or os.environ.get('SNIPER_ADOPT_DERIVED', '1') == '0':
             return False
         if not all(n in self.shared_names for n in list(self.params) + list(self.aux)):
             return False
@@ -824,18 +843,23 @@ class Executor(object):
                     # context synchronises the DEVICE (every other lane's queue), collects garbage and empties the allocator's cache
                     # on entry -- most of the 6 - 39 ms a capture cost per new batch shape (tools/cold_shape_probe.py).  The eager
                     # first call already made every lazy allocation, so nothing here needs freed memory.
-                    cur = torch.cuda.current_stream()
-                    side = self.__dict__.setdefault('_capture_stream', None) or torch.cuda.Stream(device=self.device)
-                    self._capture_stream = side
-                    side.wait_stream(cur)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.stream(side):
-                        g.capture_begin(capture_error_mode='thread_local')
-                        try:
+                    if os.environ.get('SNIPER_INFER_LIGHT_CAPTURE', '1') == '0':      # (A/B: the torch context, as until round 5)
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(g, capture_error_mode='thread_local'):
                             self._forward_body()
-                        finally:
-                            g.capture_end()
-                    cur.wait_stream(side)
+                    else:
+                        cur = torch.cuda.current_stream()
+                        side = self.__dict__.setdefault('_capture_stream', None) or torch.cuda.Stream(device=self.device)
+                        self._capture_stream = side
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            g.capture_begin(capture_error_mode='thread_local')
+                            try:
+                                self._forward_body()
+                            finally:
+                                g.capture_end()
+                        cur.wait_stream(side)
                     g.replay()
                     self._infer_graph = g
                     if gc_was:

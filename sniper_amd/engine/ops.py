@@ -1295,6 +1295,26 @@ class DPSROIPoolStep(Step):
         self.y = self.new_out('act')
         self.y.needs_grad = self.x.needs_grad or (self.trans is not None and self.trans.needs_grad)
         self.ws = None
+        # Position-sensitive maps GROUP-MAJOR (round 6): in the operator's channel order (d, gh, gw) the output_dim channels of one bin
+        # lie group_size^2 apart, and every bin drags the whole pixel through L2 (sn_psroi_pool_fwd: 7.5 ms per call on the 7*7*81 map
+        # at 16 x 300 RoIs).  When the map comes straight out of a convolution that nobody else reads, that convolution writes its
+        # output channels in (gh, gw, d) order instead -- a permutation of its weight ROWS and bias in the kernels' layout
+        # (Param.out_perm; reference order at the checkpoint boundary as ever) -- and the pooling kernels index (gh*G + gw)*D + d.
+        self.gm = 0
+        prod = self.x.producer
+        if (self.G > 1 and os.environ.get('SNIPER_PS_GROUP_MAJOR', '1') != '0' and type(prod).__name__ == 'ConvolutionStep'
+                and self.x.fmt == 'act' and not prod.depthwise and not prod.out_f32 and getattr(prod, 'fold_bn', None) is None
+                and len(ex.consumers.get((id(prod.node), 0), [])) == 1 and (id(prod.node), 0) not in ex.head_keys):
+            G, D = self.G, self.D
+            perm = np.empty(D * G * G, np.int64)
+            for g in range(G * G):
+                for d in range(D):
+                    perm[g * D + d] = d * G * G + g
+            for q in (prod.w, prod.b):
+                if q is not None:
+                    q.out_perm = perm
+            self.x.chan_perm = perm
+            self.gm = 1
 
     def forward(self):
         ex = self.ex
@@ -1306,7 +1326,7 @@ class DPSROIPoolStep(Step):
                      self.scale, self.tstd, hip.stream())
         else:
             hip.call('sn_psroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), trans, self.y.t, R, h, w, self.D, self.G,
-                     self.P, self.S, self.scale, self.tstd, hip.stream())
+                     self.P, self.S, self.scale, self.tstd, self.gm, hip.stream())
 
     def backward(self):
         ex = self.ex
@@ -1324,7 +1344,7 @@ class DPSROIPoolStep(Step):
                      w, c, self.P, self.S, self.scale, self.tstd, self.ws, hip.stream())
         else:
             hip.call('sn_psroi_pool_bwd', self.y.grad, ex.as_act(self.x), ex.as_f32(self.rois), trans, d16, 0, d_trans, R, n, h,
-                     w, self.D, self.G, self.P, self.S, self.scale, self.tstd, self.ws, hip.stream())
+                     w, self.D, self.G, self.P, self.S, self.scale, self.tstd, self.gm, self.ws, hip.stream())
         if self.x.needs_grad:
             ex.add_grad(self.x, d16, 'act')
         if self.trans is not None and self.trans.needs_grad:

@@ -114,7 +114,10 @@ def test_position_sensitive_pool_at_c4_launch_shape(D):
     dd = torch.from_numpy(np.ascontiguousarray(data.transpose(0, 2, 3, 1))).to(dev()).half()
     td = lambda z: torch.from_numpy(z).to(dev())
     out = torch.full((R, P, P, D), 7.0, dtype=torch.float16, device=dev())
-    hip.call('sn_psroi_pool_fwd', dd, td(rois), td(trans), out, R, H, W, D, G, P, S, 1.0 / SC, tstd, hip.stream())
+    # (group-major maps, as the executor lays them out: channel (gh*G + gw)*D + d of the device tensor = operator channel (d*G + gh)*G + gw)
+    perm = torch.from_numpy(np.array([d * G * G + g for g in range(G * G) for d in range(D)])).to(dev())
+    dd = dd[..., perm].contiguous()
+    hip.call('sn_psroi_pool_fwd', dd, td(rois), td(trans), out, R, H, W, D, G, P, S, 1.0 / SC, tstd, 1, hip.stream())
     want = onn.dpsroi_pool_fast(f16r(data), rois[sel], trans[sel], P, S, 1.0 / SC, tstd, group_size=G)
     got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
     assert_close(got[sel], want, 1e-2, 1e-2, 'psroi fwd C4 D=%d' % D)
@@ -126,15 +129,18 @@ def test_position_sensitive_pool_at_c4_launch_shape(D):
     ws = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=dev())
     d_data = torch.full((Bc, H, W, C), 7.0, dtype=torch.float16, device=dev())
     d_trans = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
-    hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), td(trans), d_data, 0, d_trans, R, Bc, H, W, D, G, P, S, 1.0 / SC, tstd, ws,
+    hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), td(trans), d_data, 0, d_trans, R, Bc, H, W, D, G, P, S, 1.0 / SC, tstd, 1, ws,
              hip.stream())
-    assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, 1e-2, 1e-2 * np.abs(wd).max(), 'psroi d_data C4 D=%d' % D)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(C, device=dev())
+    got_d = d_data[..., inv].float().cpu().numpy().transpose(0, 3, 1, 2)       # back to the operator's channel order
+    assert_close(got_d, wd, 1e-2, 1e-2 * np.abs(wd).max(), 'psroi d_data C4 D=%d' % D)
     gtr = d_trans.cpu().numpy()
     assert_close(gtr[sel], wtr, 1e-2, 1e-2 * np.abs(wtr).max(), 'psroi d_trans C4 D=%d' % D)
     rest = np.setdiff1d(np.arange(R), sel)
     assert not gtr[rest].any()                                                         # zero output gradient -> zero offset gradient
     d2 = torch.empty_like(d_data)
-    hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), td(trans), d2, 0, d_trans, R, Bc, H, W, D, G, P, S, 1.0 / SC, tstd, ws, hip.stream())
+    hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), td(trans), d2, 0, d_trans, R, Bc, H, W, D, G, P, S, 1.0 / SC, tstd, 1, ws, hip.stream())
     assert torch.equal(d2, d_data)                                                     # fixed summation order
 
 

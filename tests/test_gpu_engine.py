@@ -553,6 +553,10 @@ def _forced_parity(sym, ex, P, AUX, inp, tol_fwd, tol_grad):
         t = y.t.float()
         if y.fmt == 'act' and len(y.shape) == 4:
             t = t.permute(0, 3, 1, 2)
+            if getattr(y, 'chan_perm', None) is not None:       # a group-major position-sensitive map: back to the operator's order
+                inv = np.empty(len(y.chan_perm), np.int64)
+                inv[np.asarray(y.chan_perm)] = np.arange(len(y.chan_perm))
+                t = t[:, torch.from_numpy(inv).to(t.device)]
         if int(np.prod(y.shape)) != t.numel():
             continue
         dev_vals[st.node.name] = t.reshape(y.shape).cpu().numpy()

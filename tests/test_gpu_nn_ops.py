@@ -1012,7 +1012,7 @@ def test_position_sensitive_pool_fwd_bwd_vs_oracle(B, D, G, P, H, W, R, SC):
     ws = torch.empty(hip.query('sn_dpsroi_bwd_workspace_bytes', R), dtype=torch.uint8, device=dev())
     for tr, tstd in ((None, 0.0), (trans, 0.1)):
         out = torch.empty((R, P, P, D), dtype=torch.float16, device=dev())
-        hip.call('sn_psroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, D, G, P, S, 1.0 / SC, tstd,
+        hip.call('sn_psroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, D, G, P, S, 1.0 / SC, tstd, 0,
                  hip.stream())
         want = onn.dpsroi_pool(f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC, tstd, group_size=G)
         assert_close(out.float().cpu().numpy().transpose(0, 3, 1, 2), want, 1e-2, 1e-2, 'psroi fwd')
@@ -1024,15 +1024,31 @@ def test_position_sensitive_pool_fwd_bwd_vs_oracle(B, D, G, P, H, W, R, SC):
             d_data = torch.full((B, H, W, C), 7.0, dtype=torch.float32 if f32 else torch.float16, device=dev())
             d_trans = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
             hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d_data, f32,
-                     d_trans if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, ws, hip.stream())
+                     d_trans if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, 0, ws, hip.stream())
             tol = 1e-3 if f32 else 1e-2
             assert_close(d_data.float().cpu().numpy().transpose(0, 3, 1, 2), wd, tol, tol * np.abs(wd).max(), 'psroi d_data')
             if tr is not None:
                 assert_close(d_trans.cpu().numpy(), wtr, 1e-3, 1e-3 * np.abs(wtr).max(), 'psroi d_trans')
         d2 = torch.empty_like(d_data)
         hip.call('sn_psroi_pool_bwd', dod, dd, td(rois), None if tr is None else td(tr), d2, 0,
-                 d_trans if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, ws, hip.stream())
+                 d_trans if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, 0, ws, hip.stream())
         assert torch.equal(d2, d_data)
+        # group-major layout (round 6): the same map with its channels in (gh, gw, d) order -> the same pooled values (the forward's
+        # arithmetic per output does not depend on the layout: bit-equal), the data gradient in that order (its summation order over
+        # the (RoI, bin) entries is the list order in both kernels: bit-equal too), the same offset gradient
+        perm = np.array([d * G * G + g for g in range(G * G) for d in range(D)])
+        dgm = dd[..., torch.from_numpy(perm).to(dev())].contiguous()
+        out_gm = torch.full_like(out, 7.0)
+        hip.call('sn_psroi_pool_fwd', dgm, td(rois), None if tr is None else td(tr), out_gm, R, H, W, D, G, P, S, 1.0 / SC, tstd, 1,
+                 hip.stream())
+        assert torch.equal(out_gm, out)
+        d_gm = torch.full((B, H, W, C), 7.0, dtype=torch.float16, device=dev())
+        dt_gm = torch.full((R, 2, P, P), 7.0, dtype=torch.float32, device=dev())
+        hip.call('sn_psroi_pool_bwd', dod, dgm, td(rois), None if tr is None else td(tr), d_gm, 0,
+                 dt_gm if tr is not None else None, R, B, H, W, D, G, P, S, 1.0 / SC, tstd, 1, ws, hip.stream())
+        assert torch.equal(d_gm, d_data[..., torch.from_numpy(perm).to(dev())])
+        if tr is not None:
+            assert torch.equal(dt_gm, d_trans)
 
 
 def test_global_average_pool():
