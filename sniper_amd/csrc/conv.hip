@@ -233,7 +233,10 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad, int use_cfg = -1) {
   ConvPlan q = {0, 0, 0, 0, 0u, 0u, 0, 0};
   const unsigned long x_bytes = ((unsigned long)p.N * p.H * p.W - 1) * p.in_ps * 2 + (unsigned long)p.Cin * 2;
   const unsigned long w_bytes = (unsigned long)p.Nout * p.KH * p.KW * p.Cin * 2;
-  if (p.Nout > 64 && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul) {
+  // (Nout == 64 -- the stage-1 reductions and 3 x 3 layers, 327 680 pixels each -- takes the pipelined 64 x 128 tile with half of its
+  //  columns zero-filled when SN_OPT_CONV_DMA_NOUT64 is set: HBM-bound layers, the wasted MFMA half is free; A/B profiles/r06_ab_nout64.txt)
+  const int min_nout = sn_debug_get(SN_OPT_CONV_DMA_NOUT64) ? 64 : 65;
+  if (p.Nout >= min_nout && p.Cin % 64 == 0 && p.in_ps % 8 == 0 && x_bytes <= 0xFFFFFF00ul && w_bytes <= 0xFFFFFF00ul) {
     q.x_bytes = (unsigned)x_bytes;
     q.w_bytes = (unsigned)w_bytes;
     const int forced = g_conv_cfg.load(std::memory_order_relaxed);
