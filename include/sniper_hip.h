@@ -409,6 +409,11 @@ int sn_pick_bwd(const void *dy, const float *index, void *dx, int N, int HW, int
  * OVERWRITTEN (every element written exactly once, no atomics); ws = sn_dpsroi_bwd_workspace_bytes(R). */
 int sn_dpsroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int C, int pooled,
                        int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream);
+/* ... with the number of images B of `data` (every RoI's image index in [0, B)).  OPT-IN sn_debug_option("dpsroi_slab", 1) /
+ * SNIPER_DPSROI_SLAB: the (image, 64-channel slab)-stationary kernel (maps of <= 1024 cells, C % 64 == 0, <= 49 bins) -- same outputs
+ * bit for bit, measured 1.6x SLOWER at R = 6000 (the bin geometry is recomputed per slab: profiles/r06_kab_dpsroi.txt). */
+int sn_dpsroi_pool_fwd_images(const void *data, const float *rois, const float *trans, void *out, int R, int B, int H, int W, int C,
+                              int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream);
 size_t sn_dpsroi_bwd_workspace_bytes(int R);
 int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float *rois, const float *trans, void *d_data, int d_data_f32,
                        float *d_trans, int R, int B, int H, int W, int C, int pooled, int sample_per_part, float spatial_scale,

@@ -42,8 +42,8 @@ void sn_set_error(const char *fmt, ...);
 // thread-safe (a mutex-guarded registry, no unsynchronised flag).
 hipError_t sn_once_per_device_max_lds(const void *kernel, int bytes);
 // Process-wide test / A-B switches (sn_debug_option in the header): relaxed atomics, initialised from the environment once at
-// load time (SNIPER_FULL_SORT, SNIPER_NMS_FULL, SNIPER_BN_FUSED_FINALIZE, SNIPER_CONV_NO_PERSIST, SNIPER_CONV_DMA_NOUT64), never a getenv inside a launch path.
-enum SnDebugOption { SN_OPT_PROPOSAL_FULL_SORT = 0, SN_OPT_NMS_FULL_MASK = 1, SN_OPT_BN_FUSED_FINALIZE = 2, SN_OPT_CONV_NO_PERSIST = 3, SN_OPT_CONV_DMA_NOUT64 = 4, SN_OPT_COUNT };
+// load time (SNIPER_FULL_SORT, SNIPER_NMS_FULL, SNIPER_BN_FUSED_FINALIZE, SNIPER_CONV_NO_PERSIST, SNIPER_CONV_DMA_NOUT64, SNIPER_DPSROI_SLAB), never a getenv inside a launch path.
+enum SnDebugOption { SN_OPT_PROPOSAL_FULL_SORT = 0, SN_OPT_NMS_FULL_MASK = 1, SN_OPT_BN_FUSED_FINALIZE = 2, SN_OPT_CONV_NO_PERSIST = 3, SN_OPT_CONV_DMA_NOUT64 = 4, SN_OPT_DPSROI_SLAB = 5, SN_OPT_COUNT };
 int sn_debug_get(SnDebugOption which);
 
 static inline hipStream_t sn_stream(sn_stream_t s) { return (hipStream_t)s; }

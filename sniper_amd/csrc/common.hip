@@ -38,8 +38,8 @@ hipError_t sn_once_per_device_max_lds(const void *kernel, int bytes) {
 }
 
 static std::atomic<int> g_debug[SN_OPT_COUNT];
-static const char *const kDebugNames[SN_OPT_COUNT] = {"proposal_full_sort", "nms_full_mask", "bn_fused_finalize", "conv_no_persist", "conv_dma_nout64"};
-static const char *const kDebugEnv[SN_OPT_COUNT] = {"SNIPER_FULL_SORT", "SNIPER_NMS_FULL", "SNIPER_BN_FUSED_FINALIZE", "SNIPER_CONV_NO_PERSIST", "SNIPER_CONV_DMA_NOUT64"};
+static const char *const kDebugNames[SN_OPT_COUNT] = {"proposal_full_sort", "nms_full_mask", "bn_fused_finalize", "conv_no_persist", "conv_dma_nout64", "dpsroi_slab"};
+static const char *const kDebugEnv[SN_OPT_COUNT] = {"SNIPER_FULL_SORT", "SNIPER_NMS_FULL", "SNIPER_BN_FUSED_FINALIZE", "SNIPER_CONV_NO_PERSIST", "SNIPER_CONV_DMA_NOUT64", "SNIPER_DPSROI_SLAB"};
 namespace {
 struct DebugInit {
   DebugInit() {

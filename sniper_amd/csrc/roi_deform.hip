@@ -61,18 +61,24 @@ __device__ __forceinline__ float sample_pos(float start, int i, float sub) { ret
 // instead of once per sample corner (S*S*4 = 64 gathers per bin shrink to the 4..36 distinct cells: the forward was
 // bound by L2 gather traffic, 9.6 GB per call at R = 6000).
 constexpr int kMaxS = 8;
-struct AxisSamples {
-  float p[kMaxS];   // clamped coordinate of sample i (meaningful where bit i of `mask` is set)
+// SM = compile-time bound of the sample loops (4 where sample_per_part <= 4 -- every symbol of the reference -- else kMaxS): the
+// bin geometry is VALU work per (RoI, bin) thread, ~1000 instructions with eight-sample loops, and these kernels are VALU-bound
+// (round 6: instruction counts in DESIGN 12).  Same operations in the same order for the samples that exist: identical values.
+template <int SM>
+struct AxisSamplesT {
+  float p[SM];   // clamped coordinate of sample i (meaningful where bit i of `mask` is set)
   unsigned mask;
   int n, lo, hi;
 };
-__device__ __forceinline__ AxisSamples axis_samples(float start, float sub, int S, int dim) {
-  AxisSamples a;
+typedef AxisSamplesT<kMaxS> AxisSamples;
+template <int SM = kMaxS>
+__device__ __forceinline__ AxisSamplesT<SM> axis_samples(float start, float sub, int S, int dim) {
+  AxisSamplesT<SM> a;
   a.n = 0;
   a.mask = 0u;
   float mn = 1e30f, mx = -1e30f;
 #pragma unroll
-  for (int i = 0; i < kMaxS; ++i) {
+  for (int i = 0; i < SM; ++i) {
     float w = sample_pos(start, i, sub);
     const bool ok = i < S && !(w < -0.5f || w > (float)dim - 0.5f);
     w = fminf(fmaxf(w, 0.f), (float)dim - 1.f);
@@ -88,23 +94,48 @@ __device__ __forceinline__ AxisSamples axis_samples(float start, float sub, int 
   a.hi = a.n ? (int)ceilf(mx) : -1;
   return a;
 }
-__device__ __forceinline__ float tent_sum(const AxisSamples &a, int x) {
+template <int SM>
+__device__ __forceinline__ float tent_sum(const AxisSamplesT<SM> &a, int x) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMaxS; ++i)
+  for (int i = 0; i < SM; ++i)
     if ((a.mask >> i) & 1u) s += fmaxf(0.f, 1.f - fabsf((float)x - a.p[i]));
   return s;
 }
 // d/dw of the tent sum: +1 on the sample's upper cell, -1 on its lower cell (nothing when the sample sits on a cell)
-__device__ __forceinline__ float tent_dsum(const AxisSamples &a, int x) {
+template <int SM>
+__device__ __forceinline__ float tent_dsum(const AxisSamplesT<SM> &a, int x) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMaxS; ++i)
+  for (int i = 0; i < SM; ++i)
     if ((a.mask >> i) & 1u) {
       const int lo = (int)floorf(a.p[i]), hi = (int)ceilf(a.p[i]);
       s += (hi != lo) ? ((x == hi ? 1.f : 0.f) - (x == lo ? 1.f : 0.f)) : 0.f;
     }
   return s;
+}
+
+// sum[q] += w * (float)v[q], q = 0..7, as eight v_fma_mix_f32: the fp16 operand is converted inside the FMA (hipcc emits
+// 8 v_cvt_f32_f16 + 4 v_pk_fma_f32 for the plain expression: 12 instructions per window cell against 8; same bits, subnormals
+// included -- tools/probes/fma_mix_probe.hip)
+typedef float roi_floatx4 __attribute__((ext_vector_type(4)));
+// sum_q u[q] * g[q] over a lane's eight channels as four v_dot2_f32_f16 (fp16 pairs, fp32 accumulate; products exact) instead of
+// 8 conversions + 8 FMAs
+typedef _Float16 roi_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot8(half8 u, half8 g) {
+  float d = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    d = __builtin_amdgcn_fdot2(roi_half2{u[2 * k], u[2 * k + 1]}, roi_half2{g[2 * k], g[2 * k + 1]}, d, false);
+  return d;
+}
+__device__ __forceinline__ void fma_mix8(float (&sum)[8], float w, half8 v) {
+  const roi_floatx4 p = __builtin_bit_cast(roi_floatx4, v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(sum[2 * k]) : "v"(w), "v"(p[k]));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(sum[2 * k + 1]) : "v"(w), "v"(p[k]));
+  }
 }
 
 __global__ __launch_bounds__(256) void dpsroi_fwd_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
@@ -163,6 +194,7 @@ struct BinWin {
   int x_lo, nx, y_lo, ny, slow;
   float inv;
 };
+template <int SM>
 __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
                                                              const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
                                                              int W, int C, int P, int S, float scale, float trans_std) {
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
   if (threadIdx.x < nb) {
     const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
     const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-    const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+    const AxisSamplesT<SM> ax = axis_samples<SM>(g.wstart, g.sub_w, S, W), ay = axis_samples<SM>(g.hstart, g.sub_h, S, H);
     BinWin &b = win[threadIdx.x];
     const int count = ax.n * ay.n;
     b.inv = count ? 1.f / (float)count : 0.f;
@@ -181,9 +213,19 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
     b.slow = (b.nx > kWinMax || b.ny > kWinMax) ? 1 : 0;
     if (!b.slow) {
 #pragma unroll
-      for (int k = 0; k < kWinMax; ++k) {
+      for (int k = 0; k < 4; ++k) {
         b.wx[k] = k < b.nx ? tent_sum(ax, ax.lo + k) : 0.f;
         b.wy[k] = k < b.ny ? tent_sum(ay, ay.lo + k) : 0.f;
+      }
+      if (b.nx > 4 || b.ny > 4) {      // (a branch, not a select: the usual bin of a training RoI covers <= 4 cells per axis)
+#pragma unroll
+        for (int k = 4; k < kWinMax; ++k) {
+          b.wx[k] = k < b.nx ? tent_sum(ax, ax.lo + k) : 0.f;
+          b.wy[k] = k < b.ny ? tent_sum(ay, ay.lo + k) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 4; k < kWinMax; ++k) b.wx[k] = b.wy[k] = 0.f;
       }
     }
     if (threadIdx.x == 0) s_b = g.b;
@@ -219,8 +261,7 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
 #pragma unroll
           for (int kx = 0; kx < NW; ++kx) {
             const float wgt = b.wy[ky] * b.wx[kx];      // zero beyond (ny, nx): BinWin pads its weights with zeros
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum[j] += wgt * (float)v[ky][kx][j];
+            fma_mix8(sum, wgt, v[ky][kx]);
           }
       };
       if (nx <= 2 && ny <= 2) window(std::integral_constant<int, 2>{});
@@ -242,7 +283,7 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
     } else if (b.nx > 0) {   // oversized window: weights on the fly, as dpsroi_fwd_kernel
       const int ph = bin / P, pw = bin - ph * P;
       const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-      const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+      const AxisSamplesT<SM> ax = axis_samples<SM>(g.wstart, g.sub_w, S, W), ay = axis_samples<SM>(g.hstart, g.sub_h, S, H);
       for (int y = ay.lo; y <= ay.hi; ++y) {
         const float wy = tent_sum(ay, y);
         if (wy == 0.f) continue;
@@ -259,6 +300,132 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)(sum[j] * b.inv);
     *reinterpret_cast<half8 *>(orow + (size_t)it * 8) = o;
+  }
+}
+
+// ---- (image, 64-channel slab)-stationary forward (round 6) ------------------------------------------------
+// The per-RoI kernel above gathers every window cell through TCP / L2: 49 bins x ~9 cells x 512 B = 226 KB per RoI, 1.35 GB per call
+// at R = 6000 for a 10.5 MB map and 150 MB of output -- the call is bound by cache gather bandwidth (8.7 TB/s over its 155 us), not
+// by HBM.  Here a workgroup owns one image's 64-channel slab for the whole launch: H x W x 64 fp16 (128 KB at 32 x 32) arrives in
+// LDS once by LDS-DMA, and the workgroup walks the image's RoIs (every T-th of them: T workgroups share a slab so that the
+// B x C/64 x T grid fills the chip), twelve at a time: one thread per (RoI, bin) puts the separable window weights into LDS, then
+// the threads walk the (RoI, bin, 16-byte chunk) items with ds_read_b128 gathers.  Same bin geometry, same cell order, same
+// products as dpsroi_fwd_roi_kernel: identical outputs.  Maps beyond 1024 cells (test-time images), C % 64 != 0 or more than 49
+// bins take the per-RoI kernel.  RoIs whose image index lies outside [0, B) are not written (the per-RoI kernel would read out of
+// bounds for them).
+typedef __attribute__((address_space(3))) void *roi_lds_ptr_t;
+constexpr int kSlabC = 64, kSlabPix = 1024, kSlabRois = 12, kSlabThreads = 1024, kSlabBins = 49;
+struct BinWin4 {
+  float wx[4], wy[4];
+  int geo;          // x_lo | y_lo << 11 | nx << 22 | ny << 26 | slow << 30 (slow: a window beyond 4 cells per axis -> weights on the fly)
+  float inv;
+};
+template <int SM>
+__global__ __launch_bounds__(kSlabThreads) void dpsroi_fwd_slab_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
+                                                                       const float *__restrict__ trans, half_t *__restrict__ out, int R,
+                                                                       int H, int W, int C, int P, int S, float scale, float trans_std,
+                                                                       int T) {
+  __shared__ __attribute__((aligned(1024))) half_t slab[kSlabPix * kSlabC];
+  __shared__ BinWin4 win[kSlabRois * kSlabBins];
+  __shared__ int list[kSlabThreads];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nslab = C / kSlabC, nb = P * P, npix = H * W;
+  const int t = blockIdx.x % T, bs = blockIdx.x / T, sl = bs % nslab, b = bs / nslab;
+  // ---- the slab: pixel p's 128 bytes at slab + 64 p; one LDS-DMA instruction moves 8 pixels (lane l: pixel l >> 3, chunk l & 7)
+  {
+    const half_t *img = data + (size_t)b * npix * C + sl * kSlabC;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(img), 0, (int)(((size_t)(npix - 1) * C + kSlabC) * 2), 0x00020000);
+    for (int piece = wave; piece * 8 < npix; piece += kSlabThreads / 64) {
+      const int pix = piece * 8 + (lane >> 3);
+      const unsigned voff = pix < npix ? (unsigned)pix * (unsigned)C * 2u + (unsigned)(lane & 7) * 16u : 0xFFFFFF00u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (roi_lds_ptr_t)(slab + piece * 512), 16, voff, 0, 0, 0);
+    }
+  }
+  const int cand = (R - t + T - 1) / T;        // this workgroup's candidates: r = t + T k
+  for (int base = 0; base < cand; base += kSlabThreads) {
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    {
+      const int k = base + tid, r = t + T * k;
+      if (k < cand && (int)rois[(size_t)r * 5] == b) list[atomicAdd(&s_n, 1)] = r;      // (any order: the rows are independent)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slab has landed (first pass)
+    __syncthreads();
+    const int n = s_n;
+    for (int j0 = 0; j0 < n; j0 += kSlabRois) {
+      const int nr = min(kSlabRois, n - j0);
+      if (tid < nr * nb) {
+        const int j = tid / nb, bin = tid - j * nb, r = list[j0 + j];
+        const int ph = bin / P, pw = bin - ph * P;
+        const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+        const AxisSamplesT<SM> ax = axis_samples<SM>(g.wstart, g.sub_w, S, W), ay = axis_samples<SM>(g.hstart, g.sub_h, S, H);
+        BinWin4 &bw = win[tid];
+        const int count = ax.n * ay.n;
+        const int nx = count ? ax.hi - ax.lo + 1 : 0, ny = count ? ay.hi - ay.lo + 1 : 0;
+        const int slow = (nx > 4 || ny > 4) ? 1 : 0;
+        bw.inv = count ? 1.f / (float)count : 0.f;
+        bw.geo = ax.lo | (ay.lo << 11) | (min(nx, 15) << 22) | (min(ny, 15) << 26) | (slow << 30);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bw.wx[k] = (!slow && k < nx) ? tent_sum(ax, ax.lo + k) : 0.f;
+          bw.wy[k] = (!slow && k < ny) ? tent_sum(ay, ay.lo + k) : 0.f;
+        }
+      }
+      __syncthreads();
+      for (int it = tid; it < nr * nb * 8; it += kSlabThreads) {
+        const int j = it / (nb * 8), rem = it - j * nb * 8, bin = rem >> 3, chunk = rem & 7;
+        const int r = list[j0 + j];
+        const BinWin4 &bw = win[j * nb + bin];
+        const int geo = bw.geo;
+        const int x_lo = geo & 2047, y_lo = (geo >> 11) & 2047, nx = (geo >> 22) & 15, ny = (geo >> 26) & 15, slow = (geo >> 30) & 1;
+        float sum[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum[q] = 0.f;
+        const half_t *img = slab + chunk * 8;
+        if (!slow && nx > 0) {
+          const half_t *wbase = img + (y_lo * W + x_lo) * kSlabC;
+          auto window = [&](auto n_tag) {
+            constexpr int NW = decltype(n_tag)::value;
+            half8 v[NW][NW];
+#pragma unroll
+            for (int ky = 0; ky < NW; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < NW; ++kx) v[ky][kx] = *reinterpret_cast<const half8 *>(wbase + (min(ky, ny - 1) * W + min(kx, nx - 1)) * kSlabC);
+#pragma unroll
+            for (int ky = 0; ky < NW; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < NW; ++kx) {
+                const float wgt = bw.wy[ky] * bw.wx[kx];      // zero beyond (ny, nx)
+                fma_mix8(sum, wgt, v[ky][kx]);
+              }
+          };
+          if (nx <= 2 && ny <= 2) window(std::integral_constant<int, 2>{});
+          else if (nx <= 3 && ny <= 3) window(std::integral_constant<int, 3>{});
+          else window(std::integral_constant<int, 4>{});
+        } else if (slow) {     // a window beyond 4 cells per axis: weights on the fly, as dpsroi_fwd_kernel
+          const int ph = bin / P, pw = bin - ph * P;
+          const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
+          const AxisSamplesT<SM> ax = axis_samples<SM>(g.wstart, g.sub_w, S, W), ay = axis_samples<SM>(g.hstart, g.sub_h, S, H);
+          for (int y = ay.lo; y <= ay.hi; ++y) {
+            const float wy = tent_sum(ay, y);
+            if (wy == 0.f) continue;
+            for (int x = ax.lo; x <= ax.hi; ++x) {
+              const float wgt = wy * tent_sum(ax, x);
+              if (wgt == 0.f) continue;
+              const half8 v = *reinterpret_cast<const half8 *>(img + (y * W + x) * kSlabC);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) sum[q] += wgt * (float)v[q];
+            }
+          }
+        }
+        half8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (half_t)(sum[q] * bw.inv);
+        *reinterpret_cast<half8 *>(out + ((size_t)r * nb + bin) * C + sl * kSlabC + chunk * 8) = o;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -696,6 +863,7 @@ struct BinWinD {
 // SIMD.  Capped at 64 VGPRs (8 waves, ~170 B of scratch per lane) this kernel runs 253 -> 211 us; the forward gets SLOWER
 // (154 -> 211 / 267 us at 6 / 8 waves: its 4 x 4 window of loads spills; with only two window rows in flight it needs 108 VGPRs and
 // runs 157 us uncapped, 152 / 193 / 315 us capped at 5 / 6 / 8 waves), so only this one carries the cap.
+template <int SM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                    const float *__restrict__ rois, const float *__restrict__ trans,
                                                                    float *__restrict__ d_trans, int R, int H, int W, int C, int P,
@@ -706,7 +874,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (threadIdx.x < nb) {
     const int ph = threadIdx.x / P, pw = threadIdx.x - ph * P;
     const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-    const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+    const AxisSamplesT<SM> ax = axis_samples<SM>(g.wstart, g.sub_w, S, W), ay = axis_samples<SM>(g.hstart, g.sub_h, S, H);
     BinWinD &b = win[threadIdx.x];
     const int count = ax.n * ay.n;
     const float k = count ? trans_std / (float)count : 0.f;
@@ -716,12 +884,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     b.y_lo = ay.lo; b.ny = count ? ay.hi - ay.lo + 1 : 0;
     b.slow = (b.nx > kWinMax || b.ny > kWinMax) ? 1 : 0;
     if (!b.slow) {
-#pragma unroll
-      for (int q = 0; q < kWinMax; ++q) {
+      auto weights = [&](int q) {
         b.wx[q] = q < b.nx ? tent_sum(ax, ax.lo + q) : 0.f;
         b.dwx[q] = q < b.nx ? tent_dsum(ax, ax.lo + q) : 0.f;
         b.wy[q] = q < b.ny ? tent_sum(ay, ay.lo + q) : 0.f;
         b.dwy[q] = q < b.ny ? tent_dsum(ay, ay.lo + q) : 0.f;
+      };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) weights(q);
+      if (b.nx > 4 || b.ny > 4) {      // (a branch, not a select: the usual bin of a training RoI covers <= 4 cells per axis)
+#pragma unroll
+        for (int q = 4; q < kWinMax; ++q) weights(q);
+      } else {
+#pragma unroll
+        for (int q = 4; q < kWinMax; ++q) b.wx[q] = b.dwx[q] = b.wy[q] = b.dwy[q] = 0.f;
       }
     }
     if (threadIdx.x == 0) s_b = g.b;
@@ -749,9 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float kx = wy * b.dwx[qx], ky = dwy * b.wx[qx];
             if (kx == 0.f && ky == 0.f) continue;
             const half8 u = *reinterpret_cast<const half8 *>(row + (size_t)qx * C);
-            float dot = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dot += (float)u[j] * (float)go[j];
+            const float dot = dot8(u, go);
             gtx += kx * dot;
             gty += ky * dot;
           }
@@ -759,7 +933,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       } else {             // oversized window: weights on the fly, as dpsroi_bwd_trans_kernel
         const int ph = bin / P, pw = bin - ph * P;
         const RoiGeom g = roi_geom(rois, trans, r, ph, pw, P, S, scale, trans_std);
-        const AxisSamples ax = axis_samples(g.wstart, g.sub_w, S, W), ay = axis_samples(g.hstart, g.sub_h, S, H);
+        const AxisSamplesT<SM> ax = axis_samples<SM>(g.wstart, g.sub_w, S, W), ay = axis_samples<SM>(g.hstart, g.sub_h, S, H);
         for (int y = ay.lo; y <= ay.hi; ++y) {
           const float wy = tent_sum(ay, y), dwy = tent_dsum(ay, y);
           if (wy == 0.f && dwy == 0.f) continue;
@@ -795,12 +969,26 @@ static long blocks_for(long total) {
   return b < 1 ? 1 : (b > 16384 ? 16384 : b);
 }
 
-SN_EXPORT int sn_dpsroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int C,
-                                 int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream) {
+static int dpsroi_fwd_launch(const void *data, const float *rois, const float *trans, void *out, int R, int B, int H, int W, int C,
+                             int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream) {
   SN_REQUIRE(data && rois && out && R > 0 && C % 8 == 0 && pooled > 0 && sample_per_part > 0 && sample_per_part <= kMaxS,
              "sn_dpsroi_pool_fwd: bad arguments (sample_per_part <= %d)", kMaxS);
-  if (pooled * pooled <= kBinsMax)
-    hipLaunchKernelGGL(dpsroi_fwd_roi_kernel, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
+  // the slab-stationary kernel where the map fits (training chips) and the RoIs are many enough to amortise a slab load per workgroup
+  if (B > 0 && H * W <= kSlabPix && C % kSlabC == 0 && pooled * pooled <= kSlabBins && R >= 8 * B &&
+      (size_t)H * W * C * 2 < 0xFFFFFF00ul && sn_debug_get(SN_OPT_DPSROI_SLAB) != 0) {
+    const int wgs = B * (C / kSlabC);
+    const int T = wgs >= 256 ? 1 : (256 / wgs > 8 ? 8 : 256 / wgs);
+    if (sample_per_part <= 4)
+      hipLaunchKernelGGL(dpsroi_fwd_slab_kernel<4>, dim3((unsigned)(wgs * T)), dim3(kSlabThreads), 0, sn_stream(stream), (const half_t *)data,
+                         rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, T);
+    else
+      hipLaunchKernelGGL(dpsroi_fwd_slab_kernel<kMaxS>, dim3((unsigned)(wgs * T)), dim3(kSlabThreads), 0, sn_stream(stream), (const half_t *)data,
+                         rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, T);
+  } else if (pooled * pooled <= kBinsMax && sample_per_part <= 4)
+    hipLaunchKernelGGL(dpsroi_fwd_roi_kernel<4>, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
+                       (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+  else if (pooled * pooled <= kBinsMax)
+    hipLaunchKernelGGL(dpsroi_fwd_roi_kernel<kMaxS>, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
                        (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
   else
     hipLaunchKernelGGL(dpsroi_fwd_kernel, dim3((unsigned)blocks_for((long)R * pooled * pooled * (C / 8))), dim3(256), 0,
@@ -808,6 +996,18 @@ SN_EXPORT int sn_dpsroi_pool_fwd(const void *data, const float *rois, const floa
                        spatial_scale, trans_std);
   SN_CHECK_LAUNCH();
   return SN_OK;
+}
+
+SN_EXPORT int sn_dpsroi_pool_fwd(const void *data, const float *rois, const float *trans, void *out, int R, int H, int W, int C,
+                                 int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream) {
+  return dpsroi_fwd_launch(data, rois, trans, out, R, 0, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, stream);
+}
+
+// the same with the number of images B of `data` (every RoI's image index in [0, B)): lets the launch take the slab-stationary kernel
+SN_EXPORT int sn_dpsroi_pool_fwd_images(const void *data, const float *rois, const float *trans, void *out, int R, int B, int H, int W,
+                                        int C, int pooled, int sample_per_part, float spatial_scale, float trans_std, sn_stream_t stream) {
+  SN_REQUIRE(B > 0, "sn_dpsroi_pool_fwd_images: B = %d", B);
+  return dpsroi_fwd_launch(data, rois, trans, out, R, B, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, stream);
 }
 
 SN_EXPORT size_t sn_dpsroi_bwd_workspace_bytes(int R) { return sn_align(sizeof(int4) * (size_t)(R > 0 ? R : 1)); }
@@ -840,8 +1040,9 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
                "sn_dpsroi_pool_bwd: with trans, C/8 must be a power of two <= 64 (C=%d)", C);
     const long total = (long)R * pooled * pooled * cpr;
     if (pooled * pooled <= kBinsMax)
-      hipLaunchKernelGGL(dpsroi_bwd_trans_roi_kernel, dim3((unsigned)R), dim3(256), 0, s, (const half_t *)dout, (const half_t *)data,
-                         rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
+      hipLaunchKernelGGL((sample_per_part <= 4 ? dpsroi_bwd_trans_roi_kernel<4> : dpsroi_bwd_trans_roi_kernel<kMaxS>), dim3((unsigned)R),
+                         dim3(256), 0, s, (const half_t *)dout, (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled,
+                         sample_per_part, spatial_scale, trans_std);
     else
       hipLaunchKernelGGL(dpsroi_bwd_trans_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t *)dout,
                          (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);

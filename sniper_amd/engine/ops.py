@@ -1322,8 +1322,8 @@ class DPSROIPoolStep(Step):
         R = self.rois.shape[0]
         trans = ex.as_f32(self.trans) if self.trans else None
         if self.G == 1:
-            hip.call('sn_dpsroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), trans, self.y.t, R, h, w, c, self.P, self.S,
-                     self.scale, self.tstd, hip.stream())
+            hip.call('sn_dpsroi_pool_fwd_images', ex.as_act(self.x), ex.as_f32(self.rois), trans, self.y.t, R, n, h, w, c, self.P,
+                     self.S, self.scale, self.tstd, hip.stream())
         else:
             hip.call('sn_psroi_pool_fwd', ex.as_act(self.x), ex.as_f32(self.rois), trans, self.y.t, R, h, w, self.D, self.G,
                      self.P, self.S, self.scale, self.tstd, self.gm, hip.stream())

@@ -77,6 +77,15 @@ def test_deformable_psroi_pooling_at_6000_rois(with_trans):
     hip.call('sn_dpsroi_pool_fwd', dd, td(rois), None if trans is None else td(trans), out, R, H, W, C, P, S, 1.0 / SC, tstd, hip.stream())
     want = onn.dpsroi_pool_fast(f16r(data), rois, trans, P, S, 1.0 / SC, tstd)
     assert_close(out.float().cpu().numpy().transpose(0, 3, 1, 2), want, 1e-2, 1e-2, 'dpsroi fwd R=6000')
+    # the slab-stationary launch (what the executor calls: B known) writes the same rows, bit for bit; unsorted RoIs too
+    out_s = torch.full((R, P, P, C), 7.0, dtype=torch.float16, device=dev())
+    hip.call('sn_dpsroi_pool_fwd_images', dd, td(rois), None if trans is None else td(trans), out_s, R, B, H, W, C, P, S, 1.0 / SC, tstd,
+             hip.stream())
+    assert torch.equal(out_s, out)
+    perm = rs.permutation(R)
+    hip.call('sn_dpsroi_pool_fwd_images', dd, td(rois[perm]), None if trans is None else td(trans[perm]), out_s, R, B, H, W, C, P, S,
+             1.0 / SC, tstd, hip.stream())
+    assert torch.equal(out_s, out[torch.from_numpy(perm).to(dev())])
     dout = rs.standard_normal((R, C, P, P)).astype(np.float32)
     dod = torch.from_numpy(np.ascontiguousarray(dout.transpose(0, 2, 3, 1))).to(dev()).half()
     wd, wtr = onn.dpsroi_pool_backward_fast(f16r(dout), f16r(data), rois, trans, P, S, 1.0 / SC, tstd)

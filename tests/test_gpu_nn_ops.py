@@ -968,6 +968,11 @@ def test_dpsroi_pool_fwd_bwd_vs_oracle(B, C, H, W, R, SC):
         hip.call('sn_dpsroi_pool_fwd', dd, td(rois), None if tr is None else td(tr), out, R, H, W, C, P, S, 1.0 / SC, tstd, hip.stream())
         want = onn.dpsroi_pool(f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC, tstd)
         assert_close(out.float().cpu().numpy().transpose(0, 3, 1, 2), want, 1e-2, 1e-2, 'dpsroi fwd')
+        # the (image, 64-channel slab)-stationary kernel (taken with B known, C % 64 == 0, R >= 8 B): the per-RoI kernel's outputs
+        out_s = torch.full((R, P, P, C), 7.0, dtype=torch.float16, device=dev())
+        hip.call('sn_dpsroi_pool_fwd_images', dd, td(rois), None if tr is None else td(tr), out_s, R, B, H, W, C, P, S, 1.0 / SC, tstd,
+                 hip.stream())
+        assert torch.equal(out_s, out)
         dout = rs.standard_normal((R, C, P, P)).astype(np.float32)
         dod = torch.from_numpy(np.ascontiguousarray(dout.transpose(0, 2, 3, 1))).to(dev()).half()
         wd, wtr = onn.dpsroi_pool_backward(f16r(dout).astype(np.float64), f16r(data).astype(np.float64), rois, tr, P, S, 1.0 / SC, tstd)
