@@ -195,7 +195,7 @@ struct BinWin {
   float inv;
 };
 template <int SM>
-__global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
+__global__ __launch_bounds__(512) void dpsroi_fwd_roi_kernel(const half_t *__restrict__ data, const float *__restrict__ rois,
                                                              const float *__restrict__ trans, half_t *__restrict__ out, int R, int H,
                                                              int W, int C, int P, int S, float scale, float trans_std) {
   __shared__ BinWin win[kBinsMax];
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void dpsroi_fwd_roi_kernel(const half_t *__res
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
   half_t *orow = out + (size_t)r * nb * C;
-  for (int it = threadIdx.x; it < nb * cpr; it += 256) {
+  for (int it = threadIdx.x; it < nb * cpr; it += (int)blockDim.x) {
     const int bin = it / cpr, ch = (it - bin * cpr) * 8;
     const BinWin &b = win[bin];
     float sum[8];
@@ -864,7 +864,7 @@ struct BinWinD {
 // (154 -> 211 / 267 us at 6 / 8 waves: its 4 x 4 window of loads spills; with only two window rows in flight it needs 108 VGPRs and
 // runs 157 us uncapped, 152 / 193 / 315 us capped at 5 / 6 / 8 waves), so only this one carries the cap.
 template <int SM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void dpsroi_bwd_trans_roi_kernel(const half_t *__restrict__ dout, const half_t *__restrict__ data,
                                                                    const float *__restrict__ rois, const float *__restrict__ trans,
                                                                    float *__restrict__ d_trans, int R, int H, int W, int C, int P,
                                                                    int S, float scale, float trans_std) {
@@ -905,9 +905,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __syncthreads();
   const half_t *img0 = data + (size_t)s_b * H * W * C;
   const half_t *grow = dout + (size_t)r * nb * C;
-  const int items = nb * cpr, rounds = (items + 255) / 256;
+  const int bd = (int)blockDim.x, items = nb * cpr, rounds = (items + bd - 1) / bd;
   for (int rd = 0; rd < rounds; ++rd) {
-    const int it = rd * 256 + threadIdx.x;
+    const int it = rd * bd + threadIdx.x;
     const bool active = it < items;
     const int itc = active ? it : items - 1;
     const int bin = itc / cpr, ch = (itc - bin * cpr) * 8;
@@ -964,6 +964,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
 }
 
+// workgroup size of the per-RoI kernels (threads; a multiple of 64, >= the bin count): A/B knob, read once at load time
+static const int kRoiBlock = [] {
+  const char *v = getenv("SNIPER_DPSROI_BLOCK");
+  const int b = v && *v ? atoi(v) : 256;
+  return (b == 64 || b == 128 || b == 256 || b == 512) ? b : 256;
+}();
 static long blocks_for(long total) {
   long b = (total + 255) / 256;
   return b < 1 ? 1 : (b > 16384 ? 16384 : b);
@@ -985,7 +991,7 @@ static int dpsroi_fwd_launch(const void *data, const float *rois, const float *t
       hipLaunchKernelGGL(dpsroi_fwd_slab_kernel<kMaxS>, dim3((unsigned)(wgs * T)), dim3(kSlabThreads), 0, sn_stream(stream), (const half_t *)data,
                          rois, trans, (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std, T);
   } else if (pooled * pooled <= kBinsMax && sample_per_part <= 4)
-    hipLaunchKernelGGL(dpsroi_fwd_roi_kernel<4>, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
+    hipLaunchKernelGGL(dpsroi_fwd_roi_kernel<4>, dim3((unsigned)R), dim3(kRoiBlock), 0, sn_stream(stream), (const half_t *)data, rois, trans,
                        (half_t *)out, R, H, W, C, pooled, sample_per_part, spatial_scale, trans_std);
   else if (pooled * pooled <= kBinsMax)
     hipLaunchKernelGGL(dpsroi_fwd_roi_kernel<kMaxS>, dim3((unsigned)R), dim3(256), 0, sn_stream(stream), (const half_t *)data, rois, trans,
@@ -1041,7 +1047,7 @@ SN_EXPORT int sn_dpsroi_pool_bwd(const void *dout, const void *data, const float
     const long total = (long)R * pooled * pooled * cpr;
     if (pooled * pooled <= kBinsMax)
       hipLaunchKernelGGL((sample_per_part <= 4 ? dpsroi_bwd_trans_roi_kernel<4> : dpsroi_bwd_trans_roi_kernel<kMaxS>), dim3((unsigned)R),
-                         dim3(256), 0, s, (const half_t *)dout, (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled,
+                         dim3(kRoiBlock), 0, s, (const half_t *)dout, (const half_t *)data, rois, trans, d_trans, R, H, W, C, pooled,
                          sample_per_part, spatial_scale, trans_std);
     else
       hipLaunchKernelGGL(dpsroi_bwd_trans_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t *)dout,

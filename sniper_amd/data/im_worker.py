@@ -108,17 +108,22 @@ def decode_ahead(worker, images, threads=8):
         need.append(im)
     if len(need) < 2 or threads <= 1:
         return
+    # ONE pool per (device, thread count) for the process -- not one per caller stream: every PrefetchingIter worker has a stream of
+    # its own, and a pool keyed on it leaked eight threads per iterator ever built.  The stream is bound per TASK.
     dev, st = torch.cuda.current_device(), torch.cuda.current_stream()
-    key = (dev, st.cuda_stream, int(threads))
+    key = (dev, int(threads))
     pool = _DECODE_POOLS.get(key)
     if pool is None:
         from multiprocessing.pool import ThreadPool
 
         def init():
             torch.cuda.set_device(dev)
-            torch.cuda.set_stream(st)
         pool = _DECODE_POOLS[key] = ThreadPool(int(threads), initializer=init)
-    pool.map(worker._device_image, need, chunksize=1)
+
+    def task(im):
+        with torch.cuda.stream(st):
+            return worker._device_image(im)
+    pool.map(task, need, chunksize=1)
 
 
 class im_worker(object):

@@ -74,7 +74,8 @@ def patch_iterator_class(cls):
                 ev = torch.cuda.Event()
                 ev.record(st)
                 try:
-                    batch.ready_event = ev
+                    from ..iterators.PrefetchingIter import stamp_ready
+                    stamp_ready(batch, ev)
                 except AttributeError:
                     st.synchronize()
         return ok

@@ -8,7 +8,23 @@ waits for it on the device (`adopt_batch`: stream.wait_event + record_stream) --
 import collections
 import threading
 
+import numpy as np
+
 import sniper_amd.mx as mx
+
+
+def stamp_ready(batch, ev):
+    """Put the assembly stream's event on the batch AND on each of its device arrays: a reader that is not the adopting consumer
+    (reference / debug code calling `batch.data[i].asnumpy()`, a metric reading a label) waits for it in NDArray.asnumpy instead of
+    copying a half-written buffer -- `.cpu()` orders only with the CURRENT stream."""
+    batch.ready_event = ev
+    for group in (getattr(batch, 'data', None), getattr(batch, 'label', None)):
+        for a in (group or ()):
+            if hasattr(a, '_data') and not isinstance(getattr(a, '_data', None), np.ndarray):
+                try:
+                    a._ready_event = ev
+                except AttributeError:
+                    pass
 
 
 def adopt_batch(batch, stream=None):
@@ -89,7 +105,7 @@ class PrefetchingIter(mx.io.DataIter):
                     import torch
                     ev = torch.cuda.Event()
                     ev.record(stream)
-                    batch.ready_event = ev          # the consumer: stream.wait_event + adopt_batch (record_stream), below
+                    stamp_ready(batch, ev)          # the consumer: stream.wait_event + adopt_batch (record_stream), below
             except StopIteration:
                 batch = None
             except Exception as e:  # noqa: BLE001 -- surface worker failures in the consumer thread

@@ -118,6 +118,10 @@ class NDArray(object):
     def asnumpy(self):
         if isinstance(self._data, np.ndarray):
             return self._data
+        ev = getattr(self, '_ready_event', None)       # assembled on a prefetch worker's stream (PrefetchingIter.stamp_ready)
+        if ev is not None:
+            ev.synchronize()
+            self._ready_event = None
         return self._data.detach().float().cpu().numpy() if self._data.dtype in (torch.float16, torch.bfloat16) \
             else self._data.detach().cpu().numpy()
 
