@@ -34,6 +34,10 @@ _SLOT = threading.local()       # .job: which concurrent job of imdb_detection_w
                                 # streams are keyed by the SLOT, not the thread: the job threads of every call are new ones
 
 
+
+# RoIs per chip of the test-time graphs (detect_scale_worker builds the symbol with it; the reference: lib/inference.py:416,537)
+TEST_N_PROPOSALS = 400
+
 class nms_wrapper(object):
     """lib/nms/nms.py:15-23: hard NMS when thresh > 0, gaussian soft-NMS (sigma) otherwise."""
 
@@ -703,7 +707,7 @@ def detect_scale_worker(arguments, module_cache=None, lanes=1, image_cache=None,
         first = module_cache.get((tuple(scale), nbatch))
         mods = ([first] if first is not None else []) + list(module_cache.get(('__lanes__', tuple(scale), nbatch), []))
     while len(mods) < lanes:
-        sym_inst = sym_def(n_proposals=400, test_nbatch=nbatch)
+        sym_inst = sym_def(n_proposals=TEST_N_PROPOSALS, test_nbatch=nbatch)
         sym = sym_inst.get_symbol_rcnn(config, is_train=False)
         mod = mx.mod.Module(symbol=sym, context=context, data_names=[k[0] for k in test_iter.provide_data_single], label_names=None)
         mod.slice_inputs = False         # test time: a rank's batches are its own images (imdb_detection_wrapper shards the roidb)
@@ -877,7 +881,7 @@ def _multi_scale_detections(sym_def, config, imdb, roidb, context, arg_params, a
     dev_used = 0.0
     for scale_i, (nbatch, scale) in enumerate(zip(config.TEST.BATCH_IMAGES, config.TEST.SCALES)):
         if rows[0]:
-            per_chip = (imdb.num_classes - 1) * int(getattr(config.TEST, 'RPN_POST_NMS_TOP_N', 300)) * 40.0
+            per_chip = (imdb.num_classes - 1) * TEST_N_PROPOSALS * 40.0      # (the RoIs per chip of the graphs bound below: ADVICE r5)
             dev_used += sum(len(r['inference_crops']) for r in roidb) * per_chip
             if dev_used > dev_budget:
                 for d in detections:
