@@ -246,12 +246,15 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad, int use_cfg = -1) {
     const int nk_full = p.KH * p.KW * (p.Cin / 64);
     const int nk = by_class ? std::max(1, ((p.KH + 1) / 2) * ((p.KW + 1) / 2) * (p.Cin / 64)) : nk_full;    // the busiest class
     int cfg = use_cfg > 0 ? use_cfg : (forced >= 0 ? forced : conv_dma_choice(p.M, p.Nout, nk, dgrad));
+    if (by_class && cfg == 18 && use_cfg <= 0 && forced < 0) cfg = 16;      // (the specialised kernel carries no class arithmetic: conv_dma.hip kClassOk)
     // the persistent twins (24 / 26) of the 160 x 128 configurations: launches of >= 4 whole tiles per CU that divide over the 512
     // resident workgroups, short contractions (what a tile pays outside its K loop is what the persistent loop overlaps)
     // its epilogue: 16-byte fp16 rows, no bias, the residual / BatchNorm-input tile through the register prefetch
     const bool rows16 = !p.out_f32 && !p.out2 && !p.bias && p.out_ps % 8 == 0 && p.Nout % 8 == 0 && (!p.res || p.res_ps % 8 == 0) &&
                         (!p.bn_x || (p.stats && !p.res && p.bn_x_ps % 8 == 0));
-    const bool may_persist = !by_class && p.ksplit <= 1 && rows16 && conv_persist_tiles_per_wg(p.M, p.Nout, 160, 128) > 0;
+    // (and 1 x 1, stride 1, unpadded: the persistent kernel addresses a row's source pixel as the row itself)
+    const bool may_persist = !by_class && p.ksplit <= 1 && rows16 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 &&
+                             conv_persist_tiles_per_wg(p.M, p.Nout, 160, 128) > 0;
     if (use_cfg <= 0 && forced < 0 && (cfg == 14 || cfg == 16) && may_persist && nk >= 2 && nk <= 16 && sn_debug_get(SN_OPT_CONV_NO_PERSIST) == 0)
       cfg += 10;
     if ((cfg == 24 || cfg == 26) && (!may_persist || nk < 2)) cfg -= 10;      // forced on a launch that does not qualify: the plain twin
@@ -260,7 +263,7 @@ static ConvPlan conv_plan(const ConvParams &p, bool dgrad, int use_cfg = -1) {
       q.dma = cfg;
       q.bm = c.bm;
       q.ntiles = sn_div_up(p.Nout, c.bn);
-      const bool cls = by_class && c.bm * c.bn <= 160 * 128;      // (the 8-fragment-wide tiles are not instantiated for it)
+      const bool cls = by_class && c.bm * c.bn <= 160 * 128 && cfg != 18;      // (neither the 8-fragment-wide tiles nor the specialised kernel are instantiated for it)
       q.cls = cls ? 1 : 0;
       q.cls_mc = cls ? p.N * (p.Ho / 2) * (p.Wo / 2) : 0;
       q.mtiles = cls ? 4 * sn_div_up(q.cls_mc, c.bm) : sn_div_up(p.M, c.bm);

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   void *const ybase = (kSplitOk && p.ksplit > 1) ? (void *)(reinterpret_cast<float *>(p.y) + (size_t)kz * p.ksplit_stride) : p.y;
   // stride-2 data gradient by parity class (ConvParams::cls): row tile mt = (class, tile of the class's rows)
   // (not instantiated for the 8-fragment-wide tiles: their epilogue has no register to spare, and no stride-2 layer takes them)
-  constexpr bool kClassOk = !PERSIST && DGRAD && BM * BN <= 160 * 128;
+  // ... nor for the specialised kernel (round 6): with the class arithmetic in it hipcc's register assignment for the CONSUMER loop
+  // changes -- accumulators rotate through the fragment registers and the pinned read / MFMA interleave comes out as nine reads in a
+  // burst behind twenty MFMAs (tools/isa_loop_pattern.py; the data gradient's K loop ran 47k cycles against the forward's 32k on the
+  // same 3 x 3 layer, profiles/r06_conv_probe_skip_a.txt).  conv_plan sends a by-class launch to configuration 16 instead.
+  constexpr bool kClassOk = !PERSIST && !PS && DGRAD && BM * BN <= 160 * 128;
   const bool by_class = kClassOk && p.cls != 0;
   int mt_l = mt, cls_ph = 0, cls_pw = 0;
   if (by_class) {
@@ -187,7 +191,15 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   for (int i = 0; i < AGW; ++i) a_grp[i] = (lw + NL * i < PA) ? lw + NL * i : lw + NL * (i - 1);
 #pragma unroll
   for (int i = 0; i < BGW; ++i) b_grp[i] = (lw + NL * i < PB) ? lw + NL * i : lw + NL * (i - 1);
+  // (PERSIST: 1 x 1, stride 1, no padding, whole tiles -- conv_plan -- so a row's source pixel is the row itself and the per-tap state
+  //  (a_base / a_h / a_w / a_ok: 20 VGPRs that would stay live across the K loop) does not exist: a_voff comes straight from the row)
+  unsigned a_voff[AGW];
   auto gather_rows = [&](int gm0) {
+    if constexpr (PERSIST) {
+#pragma unroll
+      for (int i = 0; i < AGW; ++i) a_voff[i] = (unsigned)(gm0 + 8 * a_grp[i] + lrow) * ((unsigned)p.in_ps * 2u) + (unsigned)gchunk * 16u;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AGW; ++i) {
       const int m = gm0 + 8 * a_grp[i] + lrow;
@@ -236,8 +248,8 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     g_kh = tap / p.KW;
     g_kw = tap - g_kh * p.KW;
   }
-  unsigned a_voff[AGW];
   auto tap_setup = [&]() {
+    if constexpr (PERSIST) return;
 #pragma unroll
     for (int i = 0; i < AGW; ++i) {
       int sy, sx;
@@ -271,7 +283,9 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
 #pragma unroll
     for (int i = 0; i < BGW; ++i)
       dma16(rw, sb + b_grp[i] * 512, w_voff[i]);
-    if (++g_kc == kpt) {
+    if constexpr (PERSIST) {
+      ++g_kc;      // (one tap: fetch_seek re-positions at the tile boundary)
+    } else if (++g_kc == kpt) {
       g_kc = 0;
       g_kw += kstep;
       if (g_kw >= p.KW) { g_kw = kw0; g_kh += kstep; }
@@ -286,11 +300,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     tile_of(l, fmt, fnt);
     gather_rows(fmt * BM);
     gather_cols(fnt * BN);
-    const int tap = step / kpt;
-    g_kc = step - tap * kpt;
-    g_kh = tap / p.KW;
-    g_kw = tap - g_kh * p.KW;
-    tap_setup();
+    g_kc = step;       // (one tap; step < kpt)
   };
 
   floatx4 acc[MI][NI];
@@ -846,7 +856,7 @@ ConvDmaConfig conv_dma_config(int cfg) { return (cfg >= 1 && cfg <= kConvDmaConf
 
 template <bool DGRAD, int BM, int BN, int WMW, int WNW, int S, int MINW, bool PS = false, bool PERSIST = false>
 static void launch_one(const ConvParams &p, hipStream_t s) {
-  const int mtiles = (DGRAD && p.cls && BM * BN <= 160 * 128) ? 4 * sn_div_up(p.cls_mc, BM) : sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
+  const int mtiles = (DGRAD && !PS && p.cls && BM * BN <= 160 * 128) ? 4 * sn_div_up(p.cls_mc, BM) : sn_div_up(p.M, BM), ntiles = sn_div_up(p.Nout, BN);
   const int base = sn_div_up(mtiles, 8) * 8 * ntiles;
   ConvParams q = p;
   q.ksplit_grid = base;
