@@ -16,6 +16,8 @@ from sniper_amd import hip  # noqa: E402
 # name, H, W, Cin, Cout, K, stride, pad, dil, fwd launches / step, dgrad launches / step   (R101 C4 trunk + RPN + heads)
 LAYERS = [
     ('s1 1x1 64->256 @128', 128, 128, 64, 256, 1, 1, 0, 1, 3, 0),
+    ('s1 3x3 64->64 @128', 128, 128, 64, 64, 3, 1, 1, 1, 3, 0),
+    ('s1 1x1 256->64 @128', 128, 128, 256, 64, 1, 1, 0, 1, 2, 0),
     ('s2u1 1x1 256->128 @128', 128, 128, 256, 128, 1, 1, 0, 1, 1, 0),
     ('s2u1 3x3s2 128->128', 128, 128, 128, 128, 3, 2, 1, 1, 1, 1),
     ('s2u1 sc 1x1s2 256->512', 128, 128, 256, 512, 1, 2, 0, 1, 1, 0),
