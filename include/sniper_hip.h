@@ -211,6 +211,12 @@ size_t sn_conv_fwd_splitk_workspace_bytes(int N, int H, int W, int Cin, int in_p
 int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W, int Cin,
                        int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW, int stride, int pad,
                        int dil, int relu, void *ws, size_t ws_bytes, sn_stream_t stream);
+/* ... with an fp32 result and no residual (sn_conv_fwd's out_f32 = 1): the offset FullyConnected of the deformable RoI pooling
+ * (resnet_mx_101_e2e.py:288-291: 2 x 7 x 7 = 98 outputs over the RoIs of a test batch -- 10 tiles, 196 K-steps each -- read as the
+ * pooling's fp32 `trans`).  Any Cout; same workspace query. */
+int sn_conv_fwd_splitk_f32(const void *x, const void *w, const float *bias, float *y, int N, int H, int W, int Cin, int in_pix_stride,
+                           int Cout, int out_pix_stride, int KH, int KW, int stride, int pad, int dil, int relu, void *ws,
+                           size_t ws_bytes, sn_stream_t stream);
 /* Forward convolution with a SECOND output (test-time residual units): y as sn_conv_fwd / sn_conv_fwd_splitk write it (fp16) and
  * y2 = act(y2_scale * y + y2_shift) of the stored y, fp16, pixel stride y2_pix_stride -- the moving-statistics BatchNorm + ReLU that
  * opens the next pre-activation unit (resnet_mx_101_e2e.py:38-40) and reads the residual sum this epilogue writes.  ws / ws_bytes:

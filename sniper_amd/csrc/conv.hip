@@ -346,24 +346,39 @@ static SplitPlan conv_split_plan(const ConvParams &p) {
   // fewer tiles than CUs and a contraction worth splitting; about one tile per CU only with a long one (the RPN's 3 x 3 over 3072
   // channels on a 2-chip batch: 164 tiles x 432 K-steps)
   if (nk < 8 || tiles > 256 || (tiles >= 160 && nk < 64)) return SplitPlan{1, 0, -1};
-  int ks = (int)std::min<long>(std::min<long>(nk / 4, (448 + tiles - 1) / tiles), 8);
+  // (a dozen tiles -- the 98-channel offset FullyConnected over 600 RoIs: 10 tiles x 196 K-steps -- split 16 ways)
+  int ks = (int)std::min<long>(std::min<long>(nk / 4, (448 + tiles - 1) / tiles), tiles <= 16 ? 16 : 8);
   if (ks < 2) return SplitPlan{1, 0, -1};
   sp.ksplit = ks;
   sp.slab_elems = (size_t)p.M * p.Nout;
   return sp;
 }
 
-// out[m][n] = act(sum_z slab[z][m][n] + bias[n] + res[m][n]) as fp16; 8 channels per thread (Nout % 8 == 0)
+// out[m][n] = act(sum_z slab[z][m][n] + bias[n] + res[m][n]) as fp16; 8 channels per thread, 16-byte accesses when every pitch allows
+// (Nout % 8 == 0 ...), element by element otherwise (a 98-channel FullyConnected; no second output there)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int ksplit, size_t stride, long M, int Nout,
                                                             const float *__restrict__ bias, const half_t *__restrict__ res, int res_ps,
                                                             half_t *__restrict__ out, int out_ps, int relu,
                                                             half_t *__restrict__ out2, int out2_ps, const float *__restrict__ o2_scale,
-                                                            const float *__restrict__ o2_shift, int o2_relu) {
-  const int cpr = Nout >> 3;
+                                                            const float *__restrict__ o2_shift, int o2_relu, int out_f32) {
+  const int cpr = (Nout + 7) >> 3;
   const long total = M * cpr;
+  const bool vec = !out_f32 && (Nout & 7) == 0 && (out_ps & 7) == 0 && (!res || (res_ps & 7) == 0);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / cpr;
     const int n = (int)(i - m * cpr) * 8;
+    if (!vec) {
+      for (int r = 0; r < 8 && n + r < Nout; ++r) {
+        float a = 0.f;
+        for (int z = 0; z < ksplit; ++z) a += slab[(size_t)z * stride + (size_t)m * Nout + n + r];
+        if (bias) a += bias[n + r];
+        if (res) a += (float)res[(size_t)m * res_ps + n + r];
+        if (relu && a < 0.f) a = 0.f;
+        if (out_f32) reinterpret_cast<float *>(out)[(size_t)m * out_ps + n + r] = a;
+        else out[(size_t)m * out_ps + n + r] = (half_t)a;
+      }
+      continue;
+    }
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < ksplit; ++z) {
       const float *sp = slab + (size_t)z * stride + (size_t)m * Nout + n;
@@ -401,37 +416,54 @@ SN_EXPORT size_t sn_conv_fwd_splitk_workspace_bytes(int N, int H, int W, int Cin
   ConvParams p;
   conv_fwd_params(p, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH,
                   KW, stride, pad, dil, 0, 0);
-  if (p.Ho <= 0 || p.Wo <= 0 || Cout % 8 != 0 || out_pix_stride % 8 != 0 || res_pix_stride % 8 != 0) return 0;
+  if (p.Ho <= 0 || p.Wo <= 0) return 0;
   const SplitPlan sp = conv_split_plan(p);
   return sp.ksplit > 1 ? sn_align((size_t)sp.ksplit * sp.slab_elems * sizeof(float)) : 0;
 }
 
-SN_EXPORT int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W,
+static int conv_fwd_splitk_impl(const char *who, int out_f32, const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W,
                                  int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW,
                                  int stride, int pad, int dil, int relu, void *ws, size_t ws_bytes, sn_stream_t stream) {
   ConvParams p;
   conv_fwd_params(p, x, w, bias, residual, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, res_pix_stride, KH, KW, stride, pad,
                   dil, relu, 0);
-  if (int rc = conv_check(p, "sn_conv_fwd_splitk")) return rc;
+  if (int rc = conv_check(p, who)) return rc;
   const SplitPlan sp = conv_split_plan(p);
-  if (sp.ksplit <= 1 || Cout % 8 != 0 || out_pix_stride % 8 != 0 || (residual && res_pix_stride % 8 != 0))
-    return conv_launch<false>(p, sn_stream(stream));          // nothing to split: the plain forward
+  if (sp.ksplit <= 1) {
+    p.out_f32 = out_f32;
+    return conv_launch<false>(p, sn_stream(stream));
+  }          // nothing to split: the plain forward
   SN_REQUIRE(ws && ws_bytes >= (size_t)sp.ksplit * sp.slab_elems * sizeof(float),
-             "sn_conv_fwd_splitk: %zu bytes of scratch needed (sn_conv_fwd_splitk_workspace_bytes), got %zu",
+             "%s: %zu bytes of scratch needed (sn_conv_fwd_splitk_workspace_bytes), got %zu", who,
              (size_t)sp.ksplit * sp.slab_elems * sizeof(float), ws_bytes);
   ConvParams q = p;
   q.y = ws; q.out_f32 = 1; q.out_ps = p.Nout; q.bias = nullptr; q.res = nullptr; q.res_ps = 0; q.relu = 0;
   q.ksplit = sp.ksplit;
   q.ksplit_stride = (long)sp.slab_elems;
   if (int rc = conv_launch<false>(q, sn_stream(stream), sp.cfg)) return rc;
-  const long total = (long)p.M * (p.Nout / 8);
+  const long total = (long)p.M * ((p.Nout + 7) / 8);
   long blocks = (total + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), (const float *)ws, sp.ksplit,
                      sp.slab_elems, (long)p.M, p.Nout, bias, (const half_t *)residual, res_pix_stride, (half_t *)y, out_pix_stride, relu,
-                     (half_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, 0);
+                     (half_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, 0, out_f32);
   SN_CHECK_LAUNCH();
   return SN_OK;
+}
+
+SN_EXPORT int sn_conv_fwd_splitk(const void *x, const void *w, const float *bias, const void *residual, void *y, int N, int H, int W,
+                                 int Cin, int in_pix_stride, int Cout, int out_pix_stride, int res_pix_stride, int KH, int KW,
+                                 int stride, int pad, int dil, int relu, void *ws, size_t ws_bytes, sn_stream_t stream) {
+  return conv_fwd_splitk_impl("sn_conv_fwd_splitk", 0, x, w, bias, residual, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride,
+                              res_pix_stride, KH, KW, stride, pad, dil, relu, ws, ws_bytes, stream);
+}
+
+// ... with an fp32 result (the 2 x 7 x 7 offset FullyConnected over the RoIs of a test batch feeds the pooling's fp32 `trans`)
+SN_EXPORT int sn_conv_fwd_splitk_f32(const void *x, const void *w, const float *bias, float *y, int N, int H, int W, int Cin,
+                                     int in_pix_stride, int Cout, int out_pix_stride, int KH, int KW, int stride, int pad, int dil,
+                                     int relu, void *ws, size_t ws_bytes, sn_stream_t stream) {
+  return conv_fwd_splitk_impl("sn_conv_fwd_splitk_f32", 1, x, w, bias, nullptr, y, N, H, W, Cin, in_pix_stride, Cout, out_pix_stride, 0, KH,
+                              KW, stride, pad, dil, relu, ws, ws_bytes, stream);
 }
 
 // ---- forward with a second output (test-time residual units) ---------------------------------------------------------------
@@ -478,7 +510,7 @@ SN_EXPORT int sn_conv_fwd_dual(const void *x, const void *w, const float *bias, 
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, sn_stream(stream), (const float *)ws, sp.ksplit,
                        sp.slab_elems, (long)p.M, p.Nout, bias, (const half_t *)residual, res_pix_stride, (half_t *)y, out_pix_stride, relu,
-                       (half_t *)y2, y2_pix_stride, y2_scale, y2_shift, y2_relu);
+                       (half_t *)y2, y2_pix_stride, y2_scale, y2_shift, y2_relu, 0);
     SN_CHECK_LAUNCH();
     return SN_OK;
   }

@@ -198,23 +198,32 @@ __global__ __launch_bounds__(kBnFinThreads) void bn_finalize_kernel(const float 
                                                           float *__restrict__ run_var, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ save_mean,
                                                           float *__restrict__ save_invstd) {
+  // the per-channel inputs are requested BEFORE the partial sums: behind the reduction's barrier they would be a second dependent
+  // round trip to memory in a launch that is nothing but latency (180 of these per R101 step)
+  const int c0 = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool head = threadIdx.x < 32 && c0 < C;
+  float g = 1.f, bt = 0.f, rm = 0.f, rv = 0.f;
+  if (head) {
+    if (gamma) g = gamma[c0];
+    bt = beta[c0];
+    if (run_mean) { rm = run_mean[c0]; rv = run_var[c0]; }
+  }
   double sum, sumsq;
   int c;
   bn_sum_partials(part, nblk, C, sum, sumsq, c);
-  if (threadIdx.x >= 32 || c >= C) return;
+  if (!head) return;
   const double mean = sum / M;
   double var = sumsq / M - mean * mean;  // biased
   if (var < 0) var = 0;
-  const float g = gamma ? gamma[c] : 1.f;
   float sc, sh, invstd;
-  bn_fwd_coefs(mean, var, eps, g, beta[c], sc, sh, invstd);
+  bn_fwd_coefs(mean, var, eps, g, bt, sc, sh, invstd);
   scale[c] = sc;
   shift[c] = sh;
   save_mean[c] = (float)mean;
   save_invstd[c] = invstd;
   if (run_mean) {
-    run_mean[c] = bn_running(run_mean[c], (float)mean, momentum);
-    run_var[c] = bn_running(run_var[c], (float)var, momentum);
+    run_mean[c] = bn_running(rm, (float)mean, momentum);
+    run_var[c] = bn_running(rv, (float)var, momentum);
   }
 }
 
@@ -303,15 +312,23 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const half_t 
 __global__ __launch_bounds__(kBnFinThreads) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C,
                                                               const float *__restrict__ invstd, float *__restrict__ fin,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int c0 = blockIdx.x * 32 + (threadIdx.x & 31);      // (inputs first: see bn_finalize_kernel)
+  const bool head = threadIdx.x < 32 && c0 < C;
+  float is = 0.f, db0 = 0.f, dg0 = 0.f;
+  if (head) {
+    is = invstd[c0];
+    if (dbeta) db0 = dbeta[c0];
+    if (dgamma) dg0 = dgamma[c0];
+  }
   double sg, sgx;
   int c;
   bn_sum_partials(part, nblk, C, sg, sgx, c);
-  if (threadIdx.x >= 32 || c >= C) return;
-  const float db = (float)sg, dg = (float)(sgx * (double)invstd[c]);
+  if (!head) return;
+  const float db = (float)sg, dg = (float)(sgx * (double)is);
   fin[c] = db;
   fin[C + c] = dg;
-  if (dbeta) dbeta[c] += db;
-  if (dgamma) dgamma[c] += dg;
+  if (dbeta) dbeta[c] = db0 + db;
+  if (dgamma) dgamma[c] = dg0 + dg;
 }
 
 // dx = scale * (g - dbeta/M - xhat*dgamma/M) [+ acc] = ka*g + kb*x + kd with three per-channel registers

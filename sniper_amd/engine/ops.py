@@ -649,6 +649,28 @@ class ConvolutionStep(_GemmLike):
                self.s[0], self.p[0], self.d[0])
 
 
+def _fwd_splitk(step, x, w, bias, dst, geom):
+    """Test-time GEMM-shaped launches with a handful of output tiles (FullyConnected over a few hundred RoIs, the deformable
+    convolution's column GEMM on a 2-chip batch): the contraction split over copies of the tile grid, as ConvolutionStep.launch_fwd
+    does for its own layers.  True when the split launch was made (sn_conv_fwd_splitk_workspace_bytes is 0 for everything else)."""
+    ex = step.ex
+    if ex.for_training or ex.is_train:
+        return False
+    nbytes = getattr(step, '_splitk_bytes', None)
+    if nbytes is None:
+        nbytes = step._splitk_bytes = 0 if '0' in (os.environ.get('SNIPER_CONV_SPLITK', '1'), os.environ.get('SNIPER_FC_SPLITK', '1')) else \
+            int(hip.query('sn_conv_fwd_splitk_workspace_bytes', *geom))
+    if not nbytes:
+        return False
+    if getattr(step, 'out_f32', False):
+        N, H, W, C, ips, O, ops_, _rps, KH, KW, st, pad, dil = geom
+        hip.call('sn_conv_fwd_splitk_f32', x, w, bias, dst, N, H, W, C, ips, O, ops_, KH, KW, st, pad, dil, 0, ex.ws.get(nbytes), nbytes,
+                 hip.stream())
+    else:
+        hip.call('sn_conv_fwd_splitk', x, w, bias, None, dst, *geom, 0, ex.ws.get(nbytes), nbytes, hip.stream())
+    return True
+
+
 @register('FullyConnected')
 class FullyConnectedStep(_GemmLike):
     def setup_geom(self):
@@ -670,6 +692,8 @@ class FullyConnectedStep(_GemmLike):
         return self.x.nhwc()
 
     def launch_fwd(self, x, dst, bias):
+        if _fwd_splitk(self, x, self.w.w16, bias, dst, (self.N, 1, 1, self.C, self.C, self.O, self.O, 0, 1, 1, 1, 0, 1)):
+            return
         hip.call('sn_conv_fwd', x, self.w.w16, bias, None, dst, self.N, 1, 1, self.C, self.C, self.O, self.O, 0, 1, 1, 1, 0, 1, 0,
                  1 if self.out_f32 else 0, hip.stream())
 
@@ -717,8 +741,11 @@ class DeformableConvolutionStep(Step):
         hip.call('sn_deform_im2col', x, off, self.col, self.N, self.H, self.W, self.C, self.k[0], self.k[1], self.s[0], self.p[0],
                  self.d[0], self.dg, oc, 0, hip.stream())
         M, K = self.col.shape
-        hip.call('sn_conv_fwd', self.col, self.w.w16, self.b.master if self.b is not None else None, None, self.y.t, M, 1, 1, K, K,
-                 self.O, self.O, 0, 1, 1, 1, 0, 1, 0, 0, hip.stream())
+        bias = self.b.master if self.b is not None else None
+        if _fwd_splitk(self, self.col, self.w.w16, bias, self.y.t, (M, 1, 1, K, K, self.O, self.O, 0, 1, 1, 1, 0, 1)):
+            return
+        hip.call('sn_conv_fwd', self.col, self.w.w16, bias, None, self.y.t, M, 1, 1, K, K, self.O, self.O, 0, 1, 1, 1, 0, 1, 0, 0,
+                 hip.stream())
 
     def backward(self):
         ex = self.ex

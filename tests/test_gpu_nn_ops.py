@@ -698,6 +698,7 @@ def test_copy2d_vectorised_and_scalar_paths(rows, cols, in_ld, out_ld):
     (2, 3072, 36, 36, 512, 3, 1, 1, True, False, 1, True),            # ... of a 2-chip batch: 164 tiles, 432 K-steps
     (2592, 4608, 1, 1, 512, 1, 0, 1, True, False, 0, True),           # the deformable GEMM of that batch: 164 tiles, 72 K-steps
     (600, 12544, 1, 1, 1024, 1, 0, 1, True, False, 1, True),          # fc_new_1 over 600 RoIs: planned 128 x 256, split as 64 x 128
+    (600, 12544, 1, 1, 98, 1, 0, 1, True, False, 0, True),            # the offset FullyConnected: 98 channels (element-wise reduce), 10 tiles
     (20, 256, 32, 32, 256, 3, 1, 1, True, False, 1, False)])          # a training-size launch: enough tiles
 def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr, relu, split):
     """sn_conv_fwd_splitk (test-time launches with far fewer output tiles than CUs: contraction split over copies of the tile grid,
@@ -732,6 +733,16 @@ def test_conv_fwd_splitk_equals_plain_forward(N, C, H, W, O, K, pad, dil, hb, hr
     y2 = torch.full((N, H, W, O), 7.0, dtype=torch.float16, device=dev())
     hip.call('sn_conv_fwd_splitk', xd, wd, bd, rd, y2, *geom, relu, ws, need, hip.stream())
     assert torch.equal(y1, y2)          # deterministic
+    if not hr:                          # the fp32-output entry (no residual): against sn_conv_fwd's out_f32 and the fp16 result
+        f0 = torch.full((N, H, W, O), 7.0, dtype=torch.float32, device=dev())
+        f1 = torch.full((N, H, W, O), 7.0, dtype=torch.float32, device=dev())
+        hip.call('sn_conv_fwd', xd, wd, bd, None, f0, *geom, relu, 1, hip.stream())
+        hip.call('sn_conv_fwd_splitk_f32', xd, wd, bd, f1, N, H, W, C, C, O, O, K, K, 1, pad, dil, relu, ws, need, hip.stream())
+        torch.cuda.synchronize()
+        assert_close(f1.cpu().numpy(), f0.cpu().numpy(), 1e-4, 1e-4 * float(f0.abs().max()), 'split-K fp32 vs plain fp32')
+        assert torch.equal(f1.half(), y1)
+        if need == 0:
+            assert torch.equal(f0, f1)
 
 
 def test_weight_transpose_batched_equals_single():
