@@ -171,7 +171,11 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
   };
   // phase stamps (shader clock) of wave 0: [0] entry, [1] first stage landed, [2] K loop done, [3] stores drained, [4] exit
   auto stamp = [&](int k) {
-    if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    if (p.trace && threadIdx.x == 0) {
+      p.trace[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+      // [5] / [6]: the 100 MHz constant clock at entry / exit -- (t[4] - t[0]) / (t[6] - t[5]) x 100 = the shader clock the workgroup ran at
+      if (k == 0 || k == 4) p.trace[(size_t)blockIdx.x * 8 + (k ? 6 : 5)] = __builtin_amdgcn_s_memrealtime();
+    }
   };
   stamp(0);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -275,14 +279,16 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb) + cbo, 0, (int)(p.x_bytes - cbo), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wb) + wbo, 0, (int)(p.w_bytes - wbo), 0x00020000);
     half_t *const sa = lds + buf * STAGE, *const sb = b_lds + buf * STAGE;
-    if (!(PS && p.probe && (g_kh != kh0 || g_kw != kw0))) {      // (ConvParams::probe: timing probe, normally 0)
+    if (!(PS && (p.probe & 1) && (g_kh != kh0 || g_kw != kw0))) {      // (ConvParams::probe: timing probe, normally 0)
 #pragma unroll
       for (int i = 0; i < AGW; ++i)
         dma16(rx, sa + a_grp[i] * 512, a_voff[i]);
     }
+    if (!(PS && (p.probe & 2) && (g_kh != kh0 || g_kw != kw0 || g_kc != 0))) {      // (bit 1: the weight pieces of every K-step but the first)
 #pragma unroll
-    for (int i = 0; i < BGW; ++i)
-      dma16(rw, sb + b_grp[i] * 512, w_voff[i]);
+      for (int i = 0; i < BGW; ++i)
+        dma16(rw, sb + b_grp[i] * 512, w_voff[i]);
+    }
     if constexpr (PERSIST) {
       ++g_kc;      // (one tap: fetch_seek re-positions at the tile boundary)
     } else if (++g_kc == kpt) {

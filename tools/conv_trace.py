@@ -83,7 +83,9 @@ def main():
                     torch.cuda.synchronize()
                     hip.call('sn_conv_trace', None)
                     t = trace.cpu().numpy().reshape(-1, 8)
-                    t = t[t[:, 0] > 0][:, :5].astype(np.float64)
+                    t = t[t[:, 0] > 0]
+                    real = (t[:, 6] - t[:, 5]).astype(np.float64)          # 100 MHz ticks of the workgroup's life
+                    t = t[:, :5].astype(np.float64)
                     if not len(t):
                         print('%-26s %-5s cfg %d: no stamps (register-staged kernel chosen)' % (name, direction, c))
                         continue
@@ -91,10 +93,10 @@ def main():
                     ph = np.diff(t, axis=1)          # entry->first stage, K loop, stores drained, stats/exit
                     life = t[:, 4] - t[:, 0]
                     print('%-26s %-5s cfg %2d %s: %4d WGs, event %5.1f us | per WG (median cyc): fill %5.0f  kloop %5.0f  stores %5.0f  '
-                          'tail %5.0f  life %6.0f (p90 %6.0f)' % (
+                          'tail %5.0f  life %6.0f (p90 %6.0f)  clock %4.0f MHz' % (
                               name, direction, c, 'warm' if warm else 'cold', len(t), e0.elapsed_time(e1) * 1e3,
                               np.median(ph[:, 0]), np.median(ph[:, 1]), np.median(ph[:, 2]), np.median(ph[:, 3]), np.median(life),
-                              np.percentile(life, 90)), flush=True)
+                              np.percentile(life, 90), np.median(life[real > 0] / real[real > 0]) * 100.0), flush=True)
             hip.call('sn_conv_tune', -1)
 
 
