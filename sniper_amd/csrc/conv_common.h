@@ -44,7 +44,7 @@ struct ConvParams {
   int ksplit = 1, ksplit_grid = 0;
   long ksplit_stride = 0;
   unsigned long long *trace = nullptr;   // phase timeline of every workgroup (tools/conv_trace.py; SNIPER_CONV_TRACE), normally null
-  int probe = 0;          // TIMING PROBE (only with `trace`; SNIPER_CONV_PROBE_SKIP_A): bit 0 -- the specialised producers skip the A pieces of every tap but the first (what a halo-resident A operand would leave of the K loop); bit 1 -- the weight pieces of every K-step but the first (3: a K loop without operand traffic).  Wrong results
+  int probe = 0;          // TIMING PROBE (only with `trace`; SNIPER_CONV_PROBE_SKIP_A): bit 0 -- the specialised producers skip the A pieces of every tap but the first (what a halo-resident A operand would leave of the K loop); bit 1 -- the weight pieces of every K-step but the first (3: a K loop without operand traffic); bit 2 -- no step barrier (the loop without its rendezvous).  Wrong results
   // optional SECOND output of a forward convolution (sn_conv_fwd_dual, test-time graphs): y2 = act(scale * y + shift) of the stored
   // fp16 output -- the moving-statistics BatchNorm (+ ReLU) of the NEXT residual unit, which reads the residual sum this
   // convolution's epilogue writes and cannot fold into it (the sum has a second reader, the next add)

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
         if (S > 3 && young >= 2) wait_vmcnt<(S > 3 ? 2 : 0) * L>();
         else if (S > 2 && young == 1) wait_vmcnt<(S > 2 ? 1 : 0) * L>();
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        if (!(p.probe & 4)) __builtin_amdgcn_s_barrier();      // (probe bit 2: the K loop without its step barrier -- timing only)
         if (t + S - 1 < nk) issue(nxt);
         nxt = nxt + 1 == S ? 0 : nxt + 1;
       }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64 * (WMW * WNW + (PS ? 4 : 0)), MINW) void conv_dm
       };
       auto step_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of the stage behind this barrier has returned
-        __builtin_amdgcn_s_barrier();
+        if (!(p.probe & 4)) __builtin_amdgcn_s_barrier();
       };
       if (nk > 0) {
         step_barrier();
