@@ -1,6 +1,6 @@
+# inference leg A/B of the test-time FullyConnected / deformable-GEMM split-K routing (profiles/r06_infer_fc_splitk_ab.txt)
+#   gpurun -- 'bash tools/probes/infer_fc_splitk_ab.sh'
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONDONTWRITEBYTECODE=1
-timeout 600 python -m pytest tests/test_gpu_nn_ops.py -m gpu -q -x -k "splitk" -p no:cacheprovider 2>&1 | tail -5
-timeout 900 python -m pytest tests/test_gpu_inference.py tests/test_gpu_engine.py -m gpu -q -x -p no:cacheprovider -n 3 2>&1 | tail -5
 run() { env $1 python bench.py --steps 2 --warmup 1 --no-fit-path --no-cpu-baseline --no-c4 2>/tmp/iab.err | grep '^BENCH_DETAIL ' | tail -1 | cut -c14- | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); i=d['inference']
