@@ -833,7 +833,9 @@ class Executor(object):
                 self._infer_graph.replay()
                 return self.outputs
             self._infer_calls += 1
-            if self._infer_calls > 1 and _CAPTURE_ALLOWED:   # the first call ran eagerly: lazy allocations, parameter packing
+            # the first call runs eagerly (lazy allocations, parameter packing) -- unless this executor adopted every derived buffer of its
+            # Module (Module._exe_for: capture_first): then a new batch shape costs bind + capture, not bind + eager pass + capture
+            if (self._infer_calls > 1 or getattr(self, 'capture_first', False)) and _CAPTURE_ALLOWED:
                 import gc
                 gc.collect()
                 gc_was = gc.isenabled()

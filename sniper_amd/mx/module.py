@@ -136,7 +136,9 @@ class Module(object):
                           device=self._device, split_backward=split, act_pool=pool, share_params=share)
             if self._arg_params is not None:
                 if share is not None and ex.adopt_derived():
-                    pass                                         # parameters AND everything derived from them are the Module's: nothing to do
+                    # parameters AND everything derived from them are the Module's: nothing to do -- and nothing one-off left for a first,
+                    # eager forward to settle, so this shape's FIRST forward is already the capture (engine/executor.py forward)
+                    ex.capture_first = os.environ.get('SNIPER_CAPTURE_FIRST', '1') != '0'
                 elif share is not None and all(n in ex.shared_names for n in list(ex.params) + list(ex.aux)):
                     ex.refresh_compute_copies()                  # the values are there: only this shape's derived buffers
                 else:
