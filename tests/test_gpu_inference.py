@@ -675,6 +675,37 @@ def test_executor_cache_eviction_rebuilds_and_stays_correct(monkeypatch):
     assert len(small._act_pool.buffers) == len(keeps._act_pool.buffers)      # rebuilt shapes went back into the same pool
 
 
+def test_new_shape_of_a_warm_module_captures_on_its_first_forward(monkeypatch):
+    """A batch shape a warm test-time Module has not met: its executor adopts every derived buffer of the Module, so its FIRST forward
+    is the hipGraph capture (Module._exe_for: capture_first) -- outputs of that first call and of the replay behind it equal, bit for
+    bit, those of a Module that runs new shapes eagerly first (SNIPER_CAPTURE_FIRST=0)."""
+    from sniper_amd import config as cfgmod
+    cfg = cfgmod.res101_e2e_autofocus()
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 600, 100
+    bind = [('data', (2, 3, 256, 320)), ('im_info', (2, 3)), ('im_ids', (2,)), ('chip_ids', (2,))]
+    fast, another, rs = _bound_test_module(bind, cfg, 17)
+    slow = another()
+    warm = _test_batch(bind, 256, 320, rs, 0)
+    for m in (fast, slow):
+        for _ in range(3):
+            m.forward(warm, is_train=False)
+    for k, (h, w) in enumerate([(128, 192), (192, 256)]):
+        for rep in range(3):
+            batch = _test_batch(bind, h, w, rs, 10 * k + rep)
+            monkeypatch.delenv('SNIPER_CAPTURE_FIRST', raising=False)
+            fast.forward(batch, is_train=False)
+            a = [o.asnumpy() for o in fast.get_outputs()]
+            if rep == 0:
+                assert fast.exe._infer_graph is not None and fast.exe._infer_calls == 1      # captured by the first call
+            monkeypatch.setenv('SNIPER_CAPTURE_FIRST', '0')
+            slow.forward(batch, is_train=False)
+            b = [o.asnumpy() for o in slow.get_outputs()]
+            if rep == 0:
+                assert slow.exe._infer_graph is None                                         # ran eagerly
+            for name, x, y in zip(fast.output_names, a, b):
+                assert np.array_equal(x, y), ((h, w), rep, name)
+
+
 def test_bound_shapes_of_one_module_share_their_activation_memory():
     """Test-time executors of one Module lie over the same activation bytes (engine/executor.py::ActivationPool) and hold ONE set
     of parameters (share_params).  Three batch shapes visited in turn, five rounds (eager, capture, replays interleaved), then
