@@ -563,8 +563,9 @@ def bench_inference(passes=5, jobs=None):
                                          '(collect, FocusChips, iterator, first image preparation) are not amortised' % n_short}}
     # ---- what a batch shape the service has NOT met costs: 32 images of the other COCO aspect ratios of the
     # SURVEY 8(d) roidb through the same warm Modules -- their chips land in (H/64, W/64) buckets the passes above never bound.
-    # Pass 1 binds and runs them eagerly, pass 2 captures, pass 3 replays: cold_shape_ms = the extra time of passes 1 and 2 over
-    # pass 3 per newly bound executor; value_unseen_shapes = images/s of pass 1 (every shape new).
+    # Pass 1 binds them and (since the first-forward capture of round 6, Module._exe_for: capture_first) captures their hipGraphs, pass 2
+    # meets the (shape, lane) pairs pass 1 left, pass 3 replays: cold_shape_ms = the extra time of passes 1 and 2 over pass 3 per newly
+    # bound executor; value_unseen_shapes = images/s of pass 1 (every shape new; until round 5 that pass ran eagerly and pass 2 captured).
     try:
         sizes = [(480, 640), (427, 640), (375, 500), (640, 427)]             # (h, w): not the 640 x 480 of the passes above
         rs2 = np.random.RandomState(1)
@@ -576,7 +577,8 @@ def bench_inference(passes=5, jobs=None):
         t3, _ = one_pass(odd)
         new = bound_executors() - e0
         out['unseen_shapes'] = {'images': len(odd), 'new_executors': new, 'seconds_pass1_bind': round(t1, 3),
-                                'seconds_pass2_capture': round(t2, 3), 'seconds_pass3_replay': round(t3, 3)}
+                                'seconds_pass2_capture': round(t2, 3), 'seconds_pass3_replay': round(t3, 3),
+                                'capture_first': os.environ.get('SNIPER_CAPTURE_FIRST', '1') != '0'}
         out['value_unseen_shapes'] = round(len(odd) / t1, 2)
         out['cold_shape_ms'] = round(((t1 - t3) + (t2 - t3)) / max(new, 1) * 1e3, 1)
     except Exception as e:      # noqa: BLE001 -- a report
